@@ -1,0 +1,299 @@
+"""Generate the golden fixtures in this directory from the reference itself.
+
+Run ONLY in the build container, where the read-only reference checkout is
+mounted at /root/reference (it never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (r-papso/carca-replication, pure PyTorch) ships no tests or golden
+vectors, so parity is pinned by running its own modules on
+seeded inputs and storing inputs, weights and outputs as small .npz files:
+
+  g1_<cfg>.npz   eval forward + every intermediate        (carca.py:411-431)
+  g2_<cfg>.npz   train-mode forward (p=0), loss, all grads (train.py:86-95)
+  g3_adam.npz    3 Adam steps                              (training.py:174, train.py:90-96)
+  g4_metrics.npz compute_HR / compute_NDCG on fixed scores (train.py:15-32)
+  g5_data.npz    pad_profile truth table + seeded sequences (data.py:53-192)
+  g6_shapes.npz  squeeze() quirks, B=1 and N=1             (carca.py:346)
+  g7_<variant>.npz learnable / positional encoding, residual=False
+  g8_ranking.npz briefly trained weights -> per-user rank, HR@10, NDCG@10
+
+Only data is written: inputs and the reference's outputs.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+from src import carca as R  # noqa: E402  (the reference)
+from src import data as RD  # noqa: E402
+from src import train as RT  # noqa: E402
+from src.utils import get_mask  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(cfg, n_items, n_attrs, n_ctx, L, p=0.0, seed=0):
+    torch.manual_seed(seed)
+    enc = {"identity": lambda: R.IdentityEncoding(),
+           "learnable": lambda: R.LearnableEncoding(cfg["d"], L),
+           "positional": lambda: R.PositionalEncoding(cfg["d"], L)}[cfg.get("encoding", "identity")]()
+    emb = R.AllEmbedding(n_items, cfg["d"], cfg["g"], n_ctx, n_attrs, enc)
+    blocks = torch.nn.ModuleList([R.SelfAttentionBlock(cfg["d"], cfg["H"], p, cfg.get("residual_sa", True))
+                                  for _ in range(cfg["n_blocks"])])
+    dec = R.CrossAttentionBlock(cfg["d"], cfg["H"], p, cfg.get("residual_ca", True))
+    model = R.CARCA(d=cfg["d"], p=p, emb=emb, enc=blocks, dec=dec)
+    # the reference zero-inits every bias and unit-inits LayerNorm; perturb them so
+    # the fixtures can tell a dropped bias / gamma / beta from a kept one
+    gen = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if name.endswith(".bias") or (".norm" in name or name.startswith("norm.")) and name.endswith(".weight"):
+                prm.add_(0.05 * torch.randn(prm.shape, generator=gen))
+    return model
+
+
+def make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed, train_shape=False, distinct=False):
+    """Left-padded profiles with adversarial rows: row 0 all-pad, row 1 length 1, row 2 full."""
+    rng = np.random.default_rng(seed)
+    attrs = rng.random((n_items, n_attrs), dtype=np.float32)
+    attrs[0] = 0
+    lens = [0, 1, L] + [int(rng.integers(2, L)) for _ in range(max(0, B - 3))]
+    lens = lens[:B]
+    p_x = np.zeros((B, L), np.int32)
+    for u, ell in enumerate(lens):
+        if ell:
+            p_x[u, L - ell:] = rng.integers(1, n_items, size=ell)
+    p_c = rng.random((B, L, n_ctx), dtype=np.float32) * (p_x != 0)[..., None]
+    if train_shape:
+        # data.py:112-132: positives/negatives aligned with non-pad profile slots
+        pos = np.zeros((B, L), np.int32)
+        neg = np.zeros((B, L), np.int32)
+        for u in range(B):
+            nz = p_x[u] != 0
+            pos[u, nz] = rng.integers(1, n_items, size=int(nz.sum()))
+            neg[u, nz] = rng.integers(1, n_items, size=int(nz.sum()))
+        o_x = np.concatenate([pos, neg], axis=1)
+        oc_half = rng.random((B, L, n_ctx), dtype=np.float32) * (p_x != 0)[..., None]
+        o_c = np.concatenate([oc_half, oc_half], axis=1)
+        y_true = np.zeros((B, 2 * L), np.int32)
+        y_true[:, :L][p_x > 0] = 1
+    else:
+        if distinct:  # data.py:77-87: candidates distinct and outside the profile
+            o_x = np.zeros((B, N), np.int32)
+            for u in range(B):
+                pool = np.setdiff1d(np.arange(1, n_items), p_x[u])
+                o_x[u] = rng.choice(pool, size=N, replace=False)
+        else:
+            o_x = rng.integers(1, n_items, size=(B, N)).astype(np.int32)
+        o_c = np.repeat(rng.random((B, 1, n_ctx), dtype=np.float32), N, axis=1)
+        y_true = np.zeros((B, N), np.int32)
+        y_true[:, 0] = 1
+    p_a, o_a = attrs[p_x], attrs[o_x]
+    t = torch.from_numpy
+    return dict(p_x=t(p_x), p_a=t(p_a), p_c=t(p_c), o_x=t(o_x), o_a=t(o_a), o_c=t(o_c), y_true=t(y_true))
+
+
+def save(name, cfg, dims, params, ins, outs):
+    blob = {}
+    for k, v in cfg.items():
+        blob["cfg/" + k] = np.array(v)
+    for k, v in dims.items():
+        blob["dim/" + k] = np.array(v)
+    for k, v in params.items():
+        blob["param/" + k] = v.detach().cpu().numpy()
+    for k, v in ins.items():
+        blob["in/" + k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    for k, v in outs.items():
+        blob["out/" + k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **blob)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def eval_trace(model, x):
+    """Step through CARCA.forward (carca.py:411-431) keeping every intermediate."""
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        p_mask = get_mask(x["p_x"])
+        p_e = model.embeds.forward(x["p_x"], x["p_a"], x["p_c"], p_mask, False)
+        out["p_mask"], out["p_embed"] = p_mask, p_e
+        p_e = model.dropout.forward(p_e)
+        for i, blk in enumerate(model.encoder):
+            p_e = blk.forward(p_e, p_mask)
+            out[f"block{i}"] = p_e
+        p_e = model.norm.forward(p_e)
+        out["p_final"] = p_e
+        o_mask = get_mask(x["o_x"])
+        o_e = model.embeds.forward(x["o_x"], x["o_a"], x["o_c"], o_mask, True)
+        out["o_embed0"] = o_e
+        w, _ = model.decoder.attn.forward(o_e, p_e, p_e, q_mask=o_mask, k_mask=p_mask, causal=None, return_w=True)
+        B = o_e.shape[0]
+        H = model.decoder.attn.H
+        out["dec_w0"] = torch.stack(torch.split(w, B, dim=0), dim=1)  # [H*B,..] -> [B,H,Tq,Tk]
+        y = model.forward(profile=(x["p_x"], x["p_a"], x["p_c"]), targets=[(x["o_x"], x["o_a"], x["o_c"])])
+        y2 = model.decoder.forward(o_e, o_mask, p_e, p_mask)
+        assert torch.equal(y, y2)
+        out["y"] = y
+        loss = R.BinaryCrossEntropy().forward(y, x["y_true"], o_mask)
+        out["loss"] = loss
+    return out
+
+
+def train_trace(model, x):
+    """One train-mode step's forward/backward exactly as train.py:86-95 does it."""
+    model.train()
+    L = x["p_x"].shape[1]
+    pos = tuple(torch.split(x[k], L, dim=1)[0] for k in ("o_x", "o_a", "o_c"))
+    neg = tuple(torch.split(x[k], L, dim=1)[1] for k in ("o_x", "o_a", "o_c"))
+    model.zero_grad()
+    y = model.forward(profile=(x["p_x"], x["p_a"], x["p_c"]), targets=[pos, neg])
+    mask = get_mask(x["o_x"])
+    loss = R.BinaryCrossEntropy().forward(y, x["y_true"], mask)
+    loss.backward()
+    out = {"y": y.detach(), "loss": loss.detach()}
+    for n, prm in model.named_parameters():
+        out["grad/" + n] = prm.grad.detach().clone()
+    return out
+
+
+CFGS = {
+    "d90h3": dict(d=90, H=3, g=450, n_blocks=2),
+    "d90h2": dict(d=90, H=2, g=256, n_blocks=1),
+    "d128h4": dict(d=128, H=4, g=640, n_blocks=2),
+    "d64h2": dict(d=64, H=2, g=256, n_blocks=3),  # CLI defaults (training.py:41-47)
+}
+SHAPES = {  # B, L, N, n_items, n_attrs, n_ctx
+    "d90h3": (5, 50, 101, 500, 32, 6),
+    "d90h2": (4, 20, 11, 300, 19, 3),
+    "d128h4": (4, 50, 101, 500, 32, 6),
+    "d64h2": (4, 50, 101, 500, 40, 5),
+}
+
+
+def main():
+    torch.set_num_threads(4)
+    # ---- G1 / G2 --------------------------------------------------------- #
+    for name, cfg in CFGS.items():
+        B, L, N, n_items, n_attrs, n_ctx = SHAPES[name]
+        dims = dict(B=B, L=L, N=N, n_items=n_items, n_attrs=n_attrs, n_ctx=n_ctx)
+        model = build(cfg, n_items, n_attrs, n_ctx, L, p=0.0, seed=1)
+        x = make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed=11)
+        save("g1_" + name, cfg, dims, model.state_dict(), x, eval_trace(model, x))
+        xt = make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed=12, train_shape=True)
+        save("g2_" + name, cfg, dims, model.state_dict(), xt, train_trace(model, xt))
+
+    # ---- G3: three Adam steps (training.py:174) ---------------------------- #
+    cfg = CFGS["d90h2"]
+    B, L, N, n_items, n_attrs, n_ctx = SHAPES["d90h2"]
+    model = build(cfg, n_items, n_attrs, n_ctx, L, p=0.0, seed=2)
+    init = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0, betas=(0.9, 0.98))
+    xt = make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed=13, train_shape=True)
+    outs = {}
+    for step in range(3):
+        tr = train_trace(model, xt)
+        opt.step()
+        outs[f"loss{step}"] = tr["loss"]
+    for k, v in model.state_dict().items():
+        outs["final/" + k] = v.clone()
+    save("g3_adam", cfg, dict(B=B, L=L, N=N, n_items=n_items, n_attrs=n_attrs, n_ctx=n_ctx), init, xt, outs)
+
+    # ---- G4: metrics ------------------------------------------------------- #
+    rng = np.random.default_rng(4)
+    scores = torch.from_numpy(rng.permuted(np.tile(np.linspace(0.01, 0.99, 101, dtype=np.float32), (64, 1)), axis=1))
+    y_true = torch.zeros(64, 101, dtype=torch.int32)
+    y_true[:, 0] = 1
+    outs = {}
+    for k in (1, 5, 10, 20):
+        outs[f"hr{k}"] = np.float64(RT.compute_HR(scores, y_true, k))
+        outs[f"ndcg{k}"] = np.float64(RT.compute_NDCG(scores, y_true, k))
+    save("g4_metrics", {}, {}, {}, dict(scores=scores, y_true=y_true), outs)
+
+    # ---- G5: data pipeline ------------------------------------------------- #
+    outs = {}
+    for mode in ("train", "val", "test"):
+        for test in (True, False):
+            for n in range(1, 10):
+                idx = RD.pad_profile(list(range(100, 100 + n)), 5, mode, test)
+                outs[f"pad/{mode}/{int(test)}/{n}"] = np.array(idx, dtype=np.int64)
+    rng = np.random.default_rng(5)
+    n_items, n_attrs, n_ctx, L = 60, 7, 3, 6
+    attrs = rng.random((n_items, n_attrs), dtype=np.float32)
+    attrs[0] = 0
+    profile = [int(v) for v in rng.integers(1, n_items, size=9)]
+    ctx = {(7, it): rng.random(n_ctx, dtype=np.float32) for it in set(profile)}
+    random.seed(123)
+    seq = RD.get_train_sequences(7, profile, L, attrs, ctx, True)
+    for nm, v in zip(("p_x", "p_a", "p_c", "o_x", "o_a", "o_c", "y_true"), seq):
+        outs["train/" + nm] = v
+    random.seed(124)
+    seq = RD.get_test_sequences(7, profile, L, 10, attrs, ctx, "test", True)
+    for nm, v in zip(("p_x", "p_a", "p_c", "o_x", "o_a", "o_c", "y_true"), seq):
+        outs["test/" + nm] = v
+    ins = dict(attrs=attrs, profile=np.array(profile), user=np.array(7),
+               ctx_items=np.array(sorted(set(profile))),
+               ctx_vals=np.stack([ctx[(7, it)] for it in sorted(set(profile))]))
+    save("g5_data", {}, dict(L=L, n_items=n_items, n_attrs=n_attrs, n_ctx=n_ctx), {}, ins, outs)
+
+    # ---- G6: squeeze quirks ------------------------------------------------ #
+    cfg = CFGS["d90h2"]
+    _, L, N, n_items, n_attrs, n_ctx = SHAPES["d90h2"]
+    model = build(cfg, n_items, n_attrs, n_ctx, L, seed=3).eval()
+    x1 = make_inputs(3, L, N, n_items, n_attrs, n_ctx, seed=14)
+    xb1 = {k: v[2:3] for k, v in x1.items()}  # B=1 (the full-length row)
+    xn1 = {k: (v[:, :1] if k.startswith("o_") or k == "y_true" else v) for k, v in x1.items()}  # N=1
+    with torch.no_grad():
+        yb1 = model.forward((xb1["p_x"], xb1["p_a"], xb1["p_c"]), [(xb1["o_x"], xb1["o_a"], xb1["o_c"])])
+        yn1 = model.forward((xn1["p_x"], xn1["p_a"], xn1["p_c"]), [(xn1["o_x"], xn1["o_a"], xn1["o_c"])])
+    ins = {"b1/" + k: v for k, v in xb1.items()}
+    ins.update({"n1/" + k: v for k, v in xn1.items()})
+    save("g6_shapes", cfg, dict(L=L, N=N, n_items=n_items, n_attrs=n_attrs, n_ctx=n_ctx), model.state_dict(), ins,
+         dict(y_b1=yb1, y_n1=yn1))
+
+    # ---- G7: variants ------------------------------------------------------ #
+    for vname, extra in (("learnable", dict(encoding="learnable")), ("positional", dict(encoding="positional")),
+                         ("nores", dict(residual_sa=False, residual_ca=False))):
+        cfg = dict(CFGS["d90h2"], **extra)
+        B, L, N, n_items, n_attrs, n_ctx = SHAPES["d90h2"]
+        dims = dict(B=B, L=L, N=N, n_items=n_items, n_attrs=n_attrs, n_ctx=n_ctx)
+        model = build(cfg, n_items, n_attrs, n_ctx, L, seed=4)
+        x = make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed=15)
+        outs = eval_trace(model, x)
+        xt = make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed=16, train_shape=True)
+        tr = train_trace(model, xt)
+        ins = dict(x)
+        ins.update({"train/" + k: v for k, v in xt.items()})
+        outs.update({"train/" + k: v for k, v in tr.items()})
+        save("g7_" + vname, cfg, dims, model.state_dict(), ins, outs)
+
+    # ---- G8: ranking after a short training run ----------------------------- #
+    cfg = CFGS["d90h3"]
+    L, N, n_items, n_attrs, n_ctx = 20, 101, 400, 24, 4
+    model = build(cfg, n_items, n_attrs, n_ctx, L, p=0.0, seed=5)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    for step in range(40):
+        xt = make_inputs(32, L, N, n_items, n_attrs, n_ctx, seed=100 + step, train_shape=True)
+        train_trace(model, xt)
+        opt.step()
+    model.eval()
+    x = make_inputs(64, L, N, n_items, n_attrs, n_ctx, seed=17, distinct=True)
+    # distinct negatives, none equal to the positive, so that ranks are well defined
+    with torch.no_grad():
+        y = model.forward((x["p_x"], x["p_a"], x["p_c"]), [(x["o_x"], x["o_a"], x["o_c"])])
+    rank = (y[:, 1:] > y[:, :1]).sum(1)
+    ties = int((y[:, 1:] == y[:, :1]).sum())
+    outs = dict(y=y, rank=rank, ties=np.array(ties), hr10=np.float64(RT.compute_HR(y, x["y_true"], 10)),
+                ndcg10=np.float64(RT.compute_NDCG(y, x["y_true"], 10)))
+    save("g8_ranking", cfg, dict(B=64, L=L, N=N, n_items=n_items, n_attrs=n_attrs, n_ctx=n_ctx), model.state_dict(), x,
+         outs)
+
+
+if __name__ == "__main__":
+    main()
