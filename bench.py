@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: scored users/sec (1 + 100 candidates) of the CARCA eval forward on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (CARCA.forward, eval mode, reference call shape train.py:44)
+over one batch of synthetic Beauty-shaped users already resident in HBM: BASELINE.json configs[1]
+= SURVEY.md 8d "C2" (B=128 users, L=50, N=1+100, d=90, g=450, H=3, 2 blocks, n_attrs=4096, n_ctx=6,
+n_items=12,102).  Users shard across ranks with no data-path collective (weak scaling: every rank
+scores its own 128-user batch); the only collectives are the timing barrier and the max-over-ranks.
+
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (the F->g feature GEMM of
+AllEmbedding, 97% of the model's flops): algorithmic flops per launch / its mean duration measured
+with events on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle
+(oracle/carca_oracle.py, a port of the reference's PyTorch-CPU path) on all host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+C2 = dict(B=128, L=50, N=101, d=90, g=450, H=3, n_blocks=2, n_attrs=4096, n_ctx=6, n_items=12102)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_user(c):
+    """SURVEY.md 8d algorithmic flops per user (eval), 2 flops per MAC."""
+    L, N, d, g, F = c["L"], c["N"], c["d"], c["g"], c["n_attrs"] + c["n_ctx"]
+    E = (L + N) * (2 * F * g + 2 * (d + g) * d)
+    SA = c["n_blocks"] * (10 * L * d * d + 4 * L * L * d)
+    CA = 2 * N * d * d + 4 * L * d * d + 4 * N * L * d + 2 * N * d
+    feat = (L + N) * 2 * F * g
+    return dict(total=E + SA + CA, embed=E, sa=SA, ca=CA, feat=feat)
+
+
+def build_inputs(c, seed, device):
+    """SURVEY.md 8d synthetic inputs, generated on the host with numpy, moved to HBM once."""
+    import torch
+
+    from oracle.carca_oracle import synth_eval_batch  # input generator only (test infrastructure)
+
+    profile, target, _ = synth_eval_batch(c["B"], c["L"], c["N"], c["n_items"], c["n_attrs"], c["n_ctx"], seed=seed)
+    to = lambda t: tuple(x.to(device) for x in t)  # noqa: E731
+    return profile, target, to(profile), to(target)
+
+
+def build_model(c, device):
+    import torch
+
+    from tests.model_util import build_model as bm
+
+    torch.manual_seed(0)
+    model = bm(dict(d=c["d"], H=c["H"], n_blocks=c["n_blocks"]), c["n_items"], c["g"], c["n_ctx"], c["n_attrs"], c["L"])
+    return model.eval().to(device)
+
+
+def cpu_baseline(c, model, profile, target, budget_s=15.0):
+    """The CPU oracle (port of the reference's PyTorch-CPU forward) on all host cores, bounded sample."""
+    import torch
+
+    from oracle import carca_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = O.CarcaConfig(d=c["d"], H=c["H"], n_blocks=c["n_blocks"])
+    with torch.no_grad():
+        for _ in range(2):
+            O.carca_forward(P, cfg, profile, [target], training=False)
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 40 and (time.perf_counter() - t_start < budget_s or len(times) < 3):
+            t0 = time.perf_counter()
+            O.carca_forward(P, cfg, profile, [target], training=False)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": c["B"] / med, "unit": "users/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} batches of {c['B']} users (same C2 tensors, in RAM), median; "
+                      f"oracle/carca_oracle.py on torch-CPU, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=C2["B"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from carca_replication_amd import ops
+
+    c = dict(C2, B=args.batch)
+    model = build_model(c, device)
+    profile_cpu, target_cpu, profile, target = build_inputs(c, 1234 + rank, device)
+    fl = flops_per_user(c)
+
+    feat_events, ca_events = [], []
+
+    def step(record):
+        ev = None
+        if record:
+            ev = {"feat": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)),
+                  "cross": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))}
+            feat_events.append(ev["feat"])
+            ca_events.append(ev["cross"])
+        ops.set_stage_events(ev)
+        y = model(profile=profile, targets=[target])
+        ops.set_stage_events(None)
+        return y
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = step(True)
+        fence()
+        elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    feat_ms = sorted(a.elapsed_time(b) for a, b in feat_events)
+    ca_ms = sorted(a.elapsed_time(b) for a, b in ca_events)
+    feat_avg = sum(feat_ms) / len(feat_ms)
+    ca_avg = sum(ca_ms) / len(ca_ms)
+
+    if rank == 0:
+        users = world * c["B"] * args.steps
+        value = users / elapsed
+        feat_tflops = c["B"] * fl["feat"] / (feat_avg * 1e-3) / 1e12
+        ca_tflops = c["B"] * fl["ca"] / (ca_avg * 1e-3) / 1e12
+        out = {
+            "metric": "scored users/sec (1+100 candidates), CARCA eval forward",
+            "value": value, "unit": "users/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 synthetic Beauty-shape eval: per GPU B=%d users x (L=50 profile + 1+100 candidates), "
+                                   "d=90 g=450 H=3 2 SA blocks + cross-attention decoder, n_attrs=4096 n_ctx=6 "
+                                   "n_items=12102, random-init weights" % c["B"],
+                       "users_per_gpu_per_step": c["B"], "parallelism": f"users sharded x{world}, no data-path collective"},
+            "model_tflops": value * fl["total"] / 1e12,
+            "roofline": {"kernel": "gemm_rows_kernel<128,96,32,FEAT> (AllEmbedding feats_embed, carca.py:86)",
+                         "bound": "mfma", "achieved": feat_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_ms": feat_avg, "min_ms": feat_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["feat"] / 1e9},
+            "roofline_cross_score": {"kernel": "cross_score_kernel<96,32,3> (final norm + CrossAttentionBlock)",
+                                     "bound": "mfma", "achieved": ca_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": ca_tflops / PEAK_F32_MFMA_TFLOPS, "avg_ms": ca_avg,
+                                     "min_ms": ca_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["ca"] / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(c, model, profile_cpu, target_cpu)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

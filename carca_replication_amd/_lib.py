@@ -1,0 +1,181 @@
+"""Build and load libcarca_hip.so (the C ABI declared in include/carca_hip.h) with ctypes.
+
+The library is built IN-TREE (``carca_replication_amd/libcarca_hip.so``) by ``build()`` with
+``hipcc --offload-arch=gfx950``; the built file travels to the GPU box with the repo snapshot.
+There is no CPU fallback: if the library cannot be built or loaded, every op raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+import shutil
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB_PATH = os.path.join(_HERE, "libcarca_hip.so")
+_STAMP = LIB_PATH + ".srchash"
+SOURCES = ["api.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip"]
+HEADERS = ["carca_common.h", "attn_common.h"]
+
+MAX_SEGS = 4
+MAX_GROUPS = 3
+MAX_L = 64
+
+_lock = threading.Lock()
+_lib = None
+
+
+class CarcaHipError(RuntimeError):
+    pass
+
+
+def _source_hash() -> str:
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        p = os.path.join(_CSRC, name)
+        if os.path.exists(p):
+            with open(p, "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(_INCLUDE, "carca_hip.h"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def _hipcc() -> str | None:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def is_built() -> bool:
+    if not os.path.exists(LIB_PATH) or not os.path.exists(_STAMP):
+        return False
+    with open(_STAMP) as f:
+        return f.read().strip() == _source_hash()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into one shared library (cross-compiles without a GPU)."""
+    with _lock:
+        if not force and is_built():
+            return LIB_PATH
+        hipcc = _hipcc()
+        if hipcc is None:
+            raise CarcaHipError("hipcc not found: cannot build libcarca_hip.so (no CPU fallback exists)")
+        srcs = [os.path.join(_CSRC, s) for s in SOURCES if os.path.exists(os.path.join(_CSRC, s))]
+        objs = []
+        procs = []
+        os.makedirs(os.path.join(_HERE, "build"), exist_ok=True)
+        for s in srcs:
+            o = os.path.join(_HERE, "build", os.path.basename(s) + ".o")
+            objs.append(o)
+            cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for cmd, p in procs:
+            out, _ = p.communicate()
+            if p.returncode != 0:
+                raise CarcaHipError("hipcc failed: " + " ".join(cmd) + "\n" + out)
+            if verbose and out.strip():
+                print(out)
+        tmp = LIB_PATH + ".tmp"
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise CarcaHipError("link failed: " + " ".join(cmd) + "\n" + r.stdout)
+        os.replace(tmp, LIB_PATH)
+        with open(_STAMP, "w") as f:
+            f.write(_source_hash())
+        global _lib
+        _lib = None
+        return LIB_PATH
+
+
+# ---- ctypes mirrors of the structs in include/carca_hip.h ------------------------------------------
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", _fp), ("dst", _fp), ("rows", C.c_int32), ("cols", C.c_int32), ("src_ld", C.c_int32),
+                ("dst_rows", C.c_int32), ("dst_cols", C.c_int32), ("row_dh", C.c_int32), ("row_dhp", C.c_int32),
+                ("col_dh", C.c_int32), ("col_dhp", C.c_int32)]
+
+
+class RowSeg(C.Structure):
+    _fields_ = [("ids", _fp), ("attrs", _fp), ("ctx", _fp), ("e_out", _fp), ("rows", C.c_int32), ("T", C.c_int32),
+                ("add_pos", C.c_int32)]
+
+
+class SaWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wk", "wv", "bq", "bk", "bv", "w1", "w2",
+                                   "b1", "b2")]
+
+
+class CaWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in ("ln_w", "ln_b", "wq", "wk", "wv", "bq", "bk", "bv", "ffn_w_pad", "ffn_w", "ffn_b")]
+
+
+class TargetGroup(C.Structure):
+    _fields_ = [("o", _fp), ("ids", _fp), ("y", _fp), ("N", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/carca_hip.h declares
+_i, _f = C.c_int, C.c_float
+SIGNATURES = {
+    "carca_abi_version": (_i, []),
+    "carca_last_error": (C.c_char_p, []),
+    "carca_padded_dims": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "carca_pack_weights": (_i, [C.POINTER(PackDesc), _i, _fp]),
+    "carca_embed_fwd": (_i, [C.POINTER(RowSeg), _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),
+    "carca_sa_block_fwd": (_i, [_fp, _i, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SaWeights), _i, _fp]),
+    "carca_cross_score_fwd": (_i, [_fp, _i, _fp, _fp, C.POINTER(TargetGroup), _i, _i, _i, _i, _i, _i,
+                                   C.POINTER(CaWeights), _i, _i, _fp]),
+    "carca_bce_fwd": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp]),
+    "carca_rank_metrics": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),
+}
+
+
+def declared_symbols() -> list[str]:
+    """Function names declared in include/carca_hip.h (parsed from the header text)."""
+    import re
+
+    with open(os.path.join(_INCLUDE, "carca_hip.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(carca_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the library (building it first if the sources changed) and type its entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not is_built():
+        build()
+    with _lock:
+        if _lib is not None:
+            return _lib
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # fail loudly: there is no other implementation to fall back to
+            raise CarcaHipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.carca_abi_version() != 1:
+            raise CarcaHipError("libcarca_hip.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    msg = load().carca_last_error().decode(errors="replace")
+    kind = {-1: "unsupported configuration", -2: "bad argument"}.get(rc, f"hipError {rc}")
+    raise CarcaHipError(f"{what}: {kind}: {msg}")

@@ -1,0 +1,71 @@
+// Error plumbing, geometry helper and weight packing of the C ABI (include/carca_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "carca_common.h"
+#include "../../include/carca_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void carca_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int carca_abi_version(void) { return CARCA_ABI_VERSION; }
+extern "C" const char* carca_last_error(void) { return g_err; }
+
+extern "C" int carca_padded_dims(int d, int H, int* dpi, int* dhp, int* dpo) {
+  CARCA_CHECK_ARG(d >= 1 && H >= 1 && d % H == 0, "padded_dims: d=%d not divisible by H=%d", d, H);
+  CARCA_CHECK_SUPPORTED(d <= 128, "padded_dims: d=%d > 128 is not built", d);
+  const int p = round_up(d / H, 16);
+  if (dpi) *dpi = d <= 64 ? 64 : (d <= 96 ? 96 : 128);
+  if (dhp) *dhp = p;
+  if (dpo) *dpo = H * p;
+  return CARCA_OK;
+}
+
+namespace {
+constexpr int PACK_CHUNK = 32;
+struct PackArgs {
+  CarcaPackDesc d[PACK_CHUNK];
+};
+
+// one blockIdx.y per descriptor; threads stride over the destination index space
+__global__ void pack_kernel(const PackArgs pa) {
+  const CarcaPackDesc& ds = pa.d[blockIdx.y];
+  const int total = ds.dst_rows * ds.dst_cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int rp = i / ds.dst_cols, cp = i - rp * ds.dst_cols;
+    const int r = ds.row_dh > 0 ? unpad_feature(rp, ds.row_dh, ds.row_dhp) : rp;
+    const int c = ds.col_dh > 0 ? unpad_feature(cp, ds.col_dh, ds.col_dhp) : cp;
+    float v = 0.f;
+    if (r >= 0 && r < ds.rows && c >= 0 && c < ds.cols) v = ds.src[(size_t)r * ds.src_ld + c];
+    ds.dst[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(descs && n >= 1, "pack_weights: no descriptors");
+  for (int i = 0; i < n; ++i) {
+    const CarcaPackDesc& d = descs[i];
+    CARCA_CHECK_ARG(d.src && d.dst && d.rows >= 1 && d.cols >= 1 && d.src_ld >= d.cols && d.dst_rows >= 1 &&
+                        d.dst_cols >= 1,
+                    "pack_weights: descriptor %d malformed", i);
+    CARCA_CHECK_ARG((d.row_dh == 0) == (d.row_dhp == 0) && (d.col_dh == 0) == (d.col_dhp == 0) &&
+                        d.row_dh <= d.row_dhp && d.col_dh <= d.col_dhp,
+                    "pack_weights: descriptor %d has inconsistent head padding", i);
+  }
+  for (int base = 0; base < n; base += PACK_CHUNK) {
+    PackArgs pa{};
+    const int m = min(PACK_CHUNK, n - base);
+    for (int i = 0; i < m; ++i) pa.d[i] = descs[base + i];
+    hipLaunchKernelGGL(pack_kernel, dim3(8, m), dim3(256), 0, stream, pa);
+    CARCA_LAUNCH_CHECK();
+  }
+  return CARCA_OK;
+}

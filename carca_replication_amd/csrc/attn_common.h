@@ -1,0 +1,170 @@
+// Building blocks shared by the self-attention block (K2) and cross-attention scoring (K4) kernels.
+//
+// One workgroup owns one user; the user's profile (L <= 64 slots, padded to 16-slot tiles) lives
+// in LDS.  All products are 16x16x4 fp32 MFMA tiles D[m][n] = sum_k A[m][k] Bt[n][k] (carca_common.h).
+// A tile's result sits in the D layout: lane (n = l&15, mq = l>>4) holds rows m = 4*mq + r, r = 0..3.
+// A product that contracts over the PREVIOUS product's m index takes that result straight from
+// registers as its Bt operand (step r of group g contracts index 16g + 4*mq + r on both sides), so
+// Q^T -> scores^T -> P^T -> O^T -> (FFN1 -> FFN2) chain without touching LDS.  That is why
+//   - heads are padded to DHP = round_up(dh, 16) features: head boundaries fall on tile boundaries;
+//   - K is kept [key][head-padded feature], V transposed [head-padded feature][key].
+#pragma once
+#include "carca_common.h"
+
+#define ATT_LMAX 64
+#define ATT_LT 4      // 16-slot tiles in ATT_LMAX
+#define ATT_SK 72     // key stride of Vt rows: 64 + 8 (conflict-free ds_read_b128, brute-forced)
+
+template <int DPI, int DHP, int NH>
+struct AttGeom {
+  static constexpr int DPO = DHP * NH;
+  static constexpr int SI = DPI + 8;  // row stride of [slot][input feature] images
+  static constexpr int SO = DPO + 8;  // row stride of [slot][head-padded feature] images
+  static constexpr int NKG = DPI / 16;
+  static constexpr int NFH = DHP / 16;  // feature tiles per head
+  static constexpr int NF = DPO / 16;
+};
+
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 glb4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 zero4() {
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+
+// LayerNorm of one row held two elements per lane (columns lane and lane+64), torch semantics
+// (biased variance, eps inside the sqrt; carca.py:279,283,408).  Columns >= d must hold 0 on entry.
+__device__ __forceinline__ void row_layernorm(float& v0, float& v1, int lane, int d, const float* __restrict__ w,
+                                              const float* __restrict__ b) {
+  const float inv_d = 1.0f / (float)d;
+  const float mean = wave_sum(v0 + v1) * inv_d;
+  const float d0 = lane < d ? v0 - mean : 0.f;
+  const float d1 = lane + 64 < d ? v1 - mean : 0.f;
+  const float var = wave_sum(d0 * d0 + d1 * d1) * inv_d;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  v0 = lane < d ? d0 * rstd * w[lane] + b[lane] : 0.f;
+  v1 = lane + 64 < d ? d1 * rstd * w[lane + 64] + b[lane + 64] : 0.f;
+}
+
+// K^T-style projection tile: out[slot][16ft + 4mq + r] = sum_k W[16ft + 4mq + r][k] X[slot][k] + bias
+// (A = packed weight rows from global, Bt = slot rows from LDS); written as one 16-B LDS store per lane.
+template <int DPI>
+__device__ __forceinline__ void proj_tile_feat_major(const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                     const float* xs, int si, float* out, int so, int ft, int st,
+                                                     int lane) {
+  const int ln = lane & 15, mq = lane >> 4;
+  const float* wrow = Wp + (size_t)(16 * ft + ln) * DPI + 4 * mq;
+  const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
+  f32x4 acc = zero4();
+#pragma unroll
+  for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(glb4(wrow + 16 * kg), lds4(xrow + 16 * kg), acc);
+  const f32x4 bias = glb4(bp + 16 * ft + 4 * mq);
+  *reinterpret_cast<f32x4*>(out + (16 * st + ln) * so + 16 * ft + 4 * mq) = acc + bias;
+}
+
+// V^T-style projection tile: out[16ft + n][16st + 4mq + r] = sum_k X[16st + 4mq + r][k] W[16ft + n][k] + bias[16ft+n]
+// (A = slot rows from LDS, Bt = packed weight rows from global).
+template <int DPI>
+__device__ __forceinline__ void proj_tile_slot_major(const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                     const float* xs, int si, float* out, int sk, int ft, int st,
+                                                     int lane) {
+  const int ln = lane & 15, mq = lane >> 4;
+  const float* wrow = Wp + (size_t)(16 * ft + ln) * DPI + 4 * mq;
+  const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
+  f32x4 acc = zero4();
+#pragma unroll
+  for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(lds4(xrow + 16 * kg), glb4(wrow + 16 * kg), acc);
+  const float bias = bp[16 * ft + ln];
+  f32x4 o = {acc[0] + bias, acc[1] + bias, acc[2] + bias, acc[3] + bias};
+  *reinterpret_cast<f32x4*>(out + (16 * ft + ln) * sk + 16 * st + 4 * mq) = o;
+}
+
+// One head of attention for a 16-query tile, everything in registers.
+//   qfrag[kg]   : the queries' input rows as Bt fragments (lane (query, mq) holds k = 16kg + 4mq + 0..3)
+//   Ks, Vt      : LDS images of this user's keys / values
+//   key_ok(key, r-th) supplied by the caller through `okbits`: bit (4*kt + r) of okbits = this lane's
+//                 query may attend key 16kt + 4mq + r
+//   returns o[ft] = O^T tile rows (head-padded features 16ft + 4mq + r of head h) for the lane's query,
+//   and (optionally) leaves the probabilities in p[kt].
+template <int DPI, int DHP, int NH>
+__device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], const float* __restrict__ wq,
+                                            const float* __restrict__ bq, const float* Ks, const float* Vt, int h,
+                                            int nkt, unsigned okbits, float sqrt_dh,
+                                            f32x4 (&o)[DHP / 16], f32x4 (&p)[ATT_LT], int lane) {
+  using G = AttGeom<DPI, DHP, NH>;
+  const int ln = lane & 15, mq = lane >> 4;
+  // Q^T tiles of this head
+  f32x4 qt[G::NFH];
+#pragma unroll
+  for (int ft = 0; ft < G::NFH; ++ft) {
+    const float* wrow = wq + (size_t)(h * DHP + 16 * ft + ln) * DPI + 4 * mq;
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(glb4(wrow + 16 * kg), qfrag[kg], acc);
+    qt[ft] = acc + glb4(bq + h * DHP + 16 * ft + 4 * mq);
+  }
+  // scores^T tiles: rows = keys, cols = queries
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt) {
+    p[kt] = zero4();
+    if (kt < nkt) {
+      const float* krow = Ks + (16 * kt + ln) * G::SO + h * DHP + 4 * mq;
+      f32x4 acc = zero4();
+#pragma unroll
+      for (int ft = 0; ft < G::NFH; ++ft) acc = mfma16_group(lds4(krow + 16 * ft), qt[ft], acc);
+      p[kt] = acc;
+    }
+  }
+  // masked softmax over keys: (mask + QK^T) / sqrt(dh) -> softmax -> * mask   (carca.py:251-256).
+  // A masked score is -2^32/sqrt(dh) in the reference and underflows to an exact 0 weight next to
+  // any unmasked score; a row with no unmasked key becomes all zeros.  Same thing, said directly:
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (okbits >> (4 * kt + r)) & 1u;
+      const float sc = p[kt][r] / sqrt_dh;
+      p[kt][r] = sc;
+      mx = ok ? fmaxf(mx, sc) : mx;
+    }
+  mx = quad4_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (okbits >> (4 * kt + r)) & 1u;
+      const float e = ok ? expf(p[kt][r] - mx) : 0.f;
+      p[kt][r] = e;
+      sum += e;
+    }
+  sum = quad4_sum(sum);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt) p[kt] = p[kt] * inv;
+  // O^T tiles: rows = head features, cols = queries, contracting over keys
+#pragma unroll
+  for (int ft = 0; ft < G::NFH; ++ft) {
+    const float* vrow = Vt + (h * DHP + 16 * ft + ln) * ATT_SK + 4 * mq;
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int kt = 0; kt < ATT_LT; ++kt)
+      if (kt < nkt) acc = mfma16_group(lds4(vrow + 16 * kt), p[kt], acc);
+    o[ft] = acc;
+  }
+}
+
+// (DPI, DHP, H) combinations with a kernel instantiation; anything else is CARCA_ERR_UNSUPPORTED
+#define CARCA_ATT_DISPATCH(FN, ...)                                               \
+  do {                                                                            \
+    if (dpi == 64 && dhp == 16 && H == 4) return FN<64, 16, 4>(__VA_ARGS__);      \
+    if (dpi == 64 && dhp == 32 && H == 2) return FN<64, 32, 2>(__VA_ARGS__);      \
+    if (dpi == 64 && dhp == 64 && H == 1) return FN<64, 64, 1>(__VA_ARGS__);      \
+    if (dpi == 96 && dhp == 32 && H == 3) return FN<96, 32, 3>(__VA_ARGS__);      \
+    if (dpi == 96 && dhp == 48 && H == 2) return FN<96, 48, 2>(__VA_ARGS__);      \
+    if (dpi == 96 && dhp == 96 && H == 1) return FN<96, 96, 1>(__VA_ARGS__);      \
+    if (dpi == 128 && dhp == 32 && H == 4) return FN<128, 32, 4>(__VA_ARGS__);    \
+    if (dpi == 128 && dhp == 64 && H == 2) return FN<128, 64, 2>(__VA_ARGS__);    \
+    if (dpi == 128 && dhp == 128 && H == 1) return FN<128, 128, 1>(__VA_ARGS__);  \
+  } while (0)

@@ -1,0 +1,96 @@
+// Shared device helpers for the CARCA gfx950 kernels (wave64, fp32-input MFMA).
+//
+// MFMA operand maps used everywhere in this directory (MI355X guide, "FP32-input MFMA"):
+//   v_mfma_f32_16x16x4_f32 : lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15];
+//                            D: col j = l&15, row i = 4*(l>>4) + reg, reg in [0,4)
+//   v_mfma_f32_32x32x2_f32 : lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+//                            D: col j = l&31, row i = (reg&3) + 8*(reg>>2) + 4*(l>>5), reg in [0,16)
+// Every product here is written D[m][n] = sum_k A[m][k] * Bt[n][k] with BOTH operands read
+// k-contiguous, 16 B per lane: for a group of KG consecutive k (16 for 16x16x4, 8 for 32x32x2)
+// lane (row, q) reads k = KG*kg + 4*q .. +3 and MFMA step s of the group contracts k = KG*kg + 4*q + s.
+// The order of k inside a group is therefore permuted identically for A and Bt, which a sum allows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// 16-byte vector with 4-byte alignment: hipcc still emits global_load_dwordx4 for it
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+#define CARCA_WAVE 64
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// 4 MFMA steps of one 16-k group: a and b hold the lane's four k values
+__device__ __forceinline__ f32x4 mfma16_group(f32x4 a, f32x4 b, f32x4 c) {
+  c = mfma16(a[0], b[0], c);
+  c = mfma16(a[1], b[1], c);
+  c = mfma16(a[2], b[2], c);
+  c = mfma16(a[3], b[3], c);
+  return c;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reduce over the four lane quads that share l&15 (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float quad4_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float quad4_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+__host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// head-padded feature index -> original feature index, or -1 for a pad slot
+__device__ __forceinline__ int unpad_feature(int fp, int dh, int dhp) {
+  int h = fp / dhp, r = fp - h * dhp;
+  return r < dh ? h * dh + r : -1;
+}
+
+// error codes of the C ABI (include/carca_hip.h)
+#define CARCA_OK 0
+#define CARCA_ERR_UNSUPPORTED (-1)
+#define CARCA_ERR_BADARG (-2)
+
+void carca_set_error(const char* fmt, ...);
+#define CARCA_CHECK_ARG(cond, ...)            \
+  do {                                        \
+    if (!(cond)) {                            \
+      carca_set_error(__VA_ARGS__);           \
+      return CARCA_ERR_BADARG;                \
+    }                                         \
+  } while (0)
+#define CARCA_CHECK_SUPPORTED(cond, ...)      \
+  do {                                        \
+    if (!(cond)) {                            \
+      carca_set_error(__VA_ARGS__);           \
+      return CARCA_ERR_UNSUPPORTED;           \
+    }                                         \
+  } while (0)
+#define CARCA_LAUNCH_CHECK()                                               \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      carca_set_error("HIP launch failed: %s", hipGetErrorString(e_));     \
+      return (int)e_;                                                      \
+    }                                                                      \
+  } while (0)

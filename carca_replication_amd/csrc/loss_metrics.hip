@@ -1,0 +1,99 @@
+// K5: masked BinaryCrossEntropy (carca.py:441-444) and sort-free HR@k / NDCG@k (train.py:15-32).
+#include "carca_common.h"
+#include "../../include/carca_hip.h"
+
+namespace {
+
+// One 1024-thread block: fixed summation order, so the loss is bitwise reproducible run to run.
+__global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ y, const int32_t* __restrict__ y_true,
+                                                   const int32_t* __restrict__ ids, int n, float eps,
+                                                   float* __restrict__ scratch, float* __restrict__ loss_out,
+                                                   float* __restrict__ dy) {
+  __shared__ float red[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float sl = 0.f, sm = 0.f;
+  for (int i = tid; i < n; i += 1024) {
+    const float m = ids[i] != 0 ? 1.f : 0.f;
+    const float t = (float)y_true[i];
+    const float p = y[i];
+    const float l = -(t * logf(p + eps) + (1.0f - t) * logf(1.0f - p + eps));
+    sl += l * m;
+    sm += m;
+  }
+  sl = wave_sum(sl);
+  sm = wave_sum(sm);
+  if (lane == 0) {
+    red[0][wave] = sl;
+    red[1][wave] = sm;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float a = lane < 16 ? red[0][lane] : 0.f, b = lane < 16 ? red[1][lane] : 0.f;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+      scratch[0] = a;
+      scratch[1] = b;
+      loss_out[0] = a / b;  // 0/0 = NaN for an all-pad batch, as in the reference
+    }
+    red[0][0] = b;
+  }
+  if (dy) {
+    __syncthreads();
+    const float inv = 1.0f / red[0][0];
+    for (int i = tid; i < n; i += 1024) {
+      const float m = ids[i] != 0 ? 1.f : 0.f;
+      const float t = (float)y_true[i];
+      const float p = y[i];
+      // d/dp of -(t log(p+eps) + (1-t) log(1-p+eps)); NOT (p - t)/(p(1-p)) because of eps
+      dy[i] = m * inv * (-(t / (p + eps)) + (1.0f - t) / (1.0f - p + eps));
+    }
+  }
+}
+
+// one wave per user: rank of candidate 0 = number of strictly larger scores among candidates 1..N-1
+__global__ void rank_kernel(const float* __restrict__ y, int B, int N, int k, int32_t* __restrict__ rank,
+                            float* __restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (u >= B) return;
+  const float* yr = y + (size_t)u * N;
+  const float y0 = yr[0];
+  float gt = 0.f, eq = 0.f;
+  for (int j = 1 + lane; j < N; j += 64) {
+    const float v = yr[j];
+    gt += v > y0 ? 1.f : 0.f;
+    eq += v == y0 ? 1.f : 0.f;
+  }
+  gt = wave_sum(gt);
+  eq = wave_sum(eq);
+  if (lane == 0) {
+    const int r = (int)gt;
+    if (rank) rank[u] = r;
+    if (r < k) {
+      atomicAdd(&sums[0], 1.0f);
+      atomicAdd(&sums[1], 1.0f / log2f((float)r + 2.0f));
+    }
+    if (eq > 0.f) atomicAdd(&sums[2], eq);
+  }
+}
+
+}  // namespace
+
+extern "C" int carca_bce_fwd(const float* y, const int32_t* y_true, const int32_t* ids, int n, float eps,
+                             float* scratch, float* loss_out, float* dy, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(y && y_true && ids && scratch && loss_out && n >= 1, "bce_fwd: null pointer or n < 1");
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, stream, y, y_true, ids, n, eps, scratch, loss_out, dy);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_rank_metrics(const float* y, int B, int N, int k, int32_t* rank, float* sums, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(y && sums && B >= 1 && N >= 1 && k >= 1, "rank_metrics: null pointer or bad dims");
+  const int blocks = (B + 3) / 4;
+  hipLaunchKernelGGL(rank_kernel, dim3(blocks), dim3(256), 0, stream, y, B, N, k, rank, sums);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}

@@ -1,0 +1,445 @@
+"""Host-side mirror of the reference's model surface (src/carca.py, src/abstract.py, src/utils.py).
+
+Same class names, constructor signatures, attribute names (hence identical ``state_dict`` keys and
+shapes), same parameter-creation order (hence identical weights under the
+same ``torch.manual_seed``) and the same ``forward`` contracts -- but every forward runs the
+hand-written gfx950 kernels behind the C ABI (include/carca_hip.h).  There is NO eager/ATen
+implementation of the model math in this file: called with CPU tensors, or without the HIP
+library, the modules raise ``CarcaHipError``.
+
+reference                                     here
+---------                                     ----
+get_mask                utils.py:6-7          folded into every kernel as (ids != 0)
+AllEmbedding.forward    carca.py:85-95        ops.embed_fwd        (csrc/embed.hip)
+SelfAttentionBlock      carca.py:297-318      ops.sa_block_fwd     (csrc/sa_block.hip)
+CARCA.norm + CrossAttentionBlock carca.py:421,338-349  ops.cross_score_fwd (csrc/cross_score.hip)
+CARCA.forward           carca.py:411-431      CARCA.forward below: 1 pack + 3 embed + n_blocks + 1 launches
+BinaryCrossEntropy      carca.py:441-444      ops.bce_fwd          (csrc/loss_metrics.hip)
+"""
+from __future__ import annotations
+
+import math
+from abc import ABC, abstractmethod
+from typing import Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib, ops
+from ._lib import CarcaHipError
+
+# ------------------------------------------------------------------------------------------------
+# plug-in interfaces (abstract.py:8-50)
+# ------------------------------------------------------------------------------------------------
+
+
+class Model(nn.Module, ABC):
+    """abstract.py:8-14"""
+
+    @abstractmethod
+    def forward(self, profile: Tuple[Tensor, Tensor, Tensor], targets: List[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
+        ...
+
+
+class Embedding(nn.Module, ABC):
+    """abstract.py:17-23"""
+
+    @abstractmethod
+    def forward(self, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
+        ...
+
+
+class Encoding(nn.Module, ABC):
+    """abstract.py:26-32"""
+
+    @abstractmethod
+    def forward(self, x: Tensor) -> Tensor:
+        ...
+
+
+class Encoder(nn.Module, ABC):
+    """abstract.py:35-41"""
+
+    @abstractmethod
+    def forward(self, x: Tensor, mask: Tensor) -> Tensor:
+        ...
+
+
+class Decoder(nn.Module, ABC):
+    """abstract.py:44-50"""
+
+    @abstractmethod
+    def forward(self, o: Tensor, o_mask: Tensor, p: Tensor, p_mask: Tensor) -> Tensor:
+        ...
+
+
+def get_mask(input: Tensor) -> Tensor:
+    """utils.py:6-7.  Kept for callers (train.py:45,92); the kernels derive the mask from the ids."""
+    return torch.where(input == 0.0, 0.0, 1.0)
+
+
+def to(*tensors: Tensor, device: str) -> Tuple[Tensor, ...]:
+    """utils.py:10-11"""
+    return tuple(t.to(device) for t in tensors)
+
+
+# ------------------------------------------------------------------------------------------------
+# encodings (carca.py:15-60): an additive [T, d] table, folded into the embed kernel's epilogue
+# ------------------------------------------------------------------------------------------------
+
+
+class IdentityEncoding(Encoding):
+    def position_table(self, T: int) -> Optional[Tensor]:
+        return None
+
+    def forward(self, x: Tensor) -> Tensor:
+        return x
+
+
+class LearnableEncoding(Encoding):
+    def __init__(self, d: int, max_len: int):
+        super().__init__()
+        self.max_len = max_len
+        self.encoding = nn.Embedding(max_len, d)
+        nn.init.xavier_uniform_(self.encoding.weight)
+
+    def position_table(self, T: int) -> Tensor:
+        if T > self.max_len:
+            raise CarcaHipError(f"sequence length {T} exceeds LearnableEncoding.max_len={self.max_len}")
+        return self.encoding.weight[:T]
+
+    def forward(self, x: Tensor) -> Tensor:
+        raise CarcaHipError("LearnableEncoding is applied inside the fused embedding kernel; call AllEmbedding/CARCA")
+
+
+class PositionalEncoding(Encoding):
+    def __init__(self, d_model: int, max_len: int):
+        super().__init__()
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(1, max_len, d_model)
+        pe[0, :, 0::2] = torch.sin(position * div_term)
+        pe[0, :, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe)
+
+    def position_table(self, T: int) -> Tensor:
+        if T > self.pe.shape[1]:
+            raise CarcaHipError(f"sequence length {T} exceeds PositionalEncoding.max_len={self.pe.shape[1]}")
+        return self.pe[0, :T]
+
+    def forward(self, x: Tensor) -> Tensor:
+        raise CarcaHipError("PositionalEncoding is applied inside the fused embedding kernel; call AllEmbedding/CARCA")
+
+
+# ------------------------------------------------------------------------------------------------
+# AllEmbedding (carca.py:66-95)
+# ------------------------------------------------------------------------------------------------
+
+
+class AllEmbedding(Embedding):
+    def __init__(self, n_items: int, d: int, g: int, n_ctx: int, n_attrs: int, enc: Encoding):
+        super().__init__()
+        self.d = d
+        self.enc = enc
+        self.items_embed = nn.Embedding(num_embeddings=n_items, embedding_dim=d, padding_idx=0)
+        self.feats_embed = nn.Linear(in_features=n_ctx + n_attrs, out_features=g)
+        self.joint_embed = nn.Linear(in_features=g + d, out_features=d)
+        for m in (self.items_embed, self.feats_embed, self.joint_embed):
+            nn.init.xavier_uniform_(m.weight)
+        with torch.no_grad():
+            self.items_embed.weight[0].zero_()
+        nn.init.zeros_(self.feats_embed.bias)
+        nn.init.zeros_(self.joint_embed.bias)
+
+    def _pos(self, T: int) -> Optional[Tensor]:
+        if hasattr(self.enc, "position_table"):
+            return self.enc.position_table(T)
+        raise CarcaHipError(f"encoding {type(self.enc).__name__} has no position_table(); cannot be fused")
+
+    def embed_segments(self, segs, ld_e: int):
+        """segs: [(x, a, c, is_target)] -> ([e [B,T,ld_e]], zq).  One fused call for all segments."""
+        pos = None
+        if any(not tgt for (_, _, _, tgt) in segs):
+            T = next(x.shape[1] for (x, _, _, tgt) in segs if not tgt)
+            pos = self._pos(T)
+        call = [(x, a, c, (not tgt) and pos is not None) for (x, a, c, tgt) in segs]
+        return ops.embed_fwd(call, self.items_embed.weight, self.feats_embed.weight, self.feats_embed.bias,
+                             self.joint_embed.weight, self.joint_embed.bias, pos, ld_e)
+
+    def forward(self, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
+        """`mask` must be get_mask(x) (it always is in the reference, carca.py:413-426); the kernel uses x != 0."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd import embed_with_grad
+
+            return embed_with_grad(self, x, a, c, target)
+        (e,), _ = self.embed_segments([(x, a, c, target)], ld_e=self.d)
+        return e
+
+
+# ------------------------------------------------------------------------------------------------
+# attention (carca.py:204-349)
+# ------------------------------------------------------------------------------------------------
+
+
+class MultiHeadAttention(nn.Module):
+    """Parameter holder with the reference's names (carca.py:204-226).
+
+    Its arithmetic (carca.py:228-265) runs fused inside SelfAttentionBlock / CrossAttentionBlock.
+    """
+
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float):
+        super().__init__()
+        assert embed_dim % num_heads == 0.0, "Embedding dim must be divisible by number of heads"
+        self.d = embed_dim
+        self.H = num_heads
+        self.WQ = nn.Linear(in_features=embed_dim, out_features=embed_dim)
+        self.WK = nn.Linear(in_features=embed_dim, out_features=embed_dim)
+        self.WV = nn.Linear(in_features=embed_dim, out_features=embed_dim)
+        self.softmax = nn.Softmax(dim=-1)
+        self.dropout = nn.Dropout(p=dropout)
+        for m in (self.WQ, self.WK, self.WV):
+            nn.init.xavier_uniform_(m.weight)
+        for m in (self.WQ, self.WK, self.WV):
+            nn.init.zeros_(m.bias)
+
+    def pack_items(self, dpi: int, dhp: int, dpo: int) -> List[ops.PackItem]:
+        dh = self.d // self.H
+        mats = [ops.PackItem(m.weight, dpo, dpi, row_heads=(dh, dhp)) for m in (self.WQ, self.WK, self.WV)]
+        vecs = [ops.PackItem(m.bias, 1, dpo, col_heads=(dh, dhp)) for m in (self.WQ, self.WK, self.WV)]
+        return mats + vecs
+
+    def forward(self, query, key, value, q_mask, k_mask, causal: int = None, return_w: bool = False):
+        raise CarcaHipError("MultiHeadAttention runs fused inside SelfAttentionBlock / CrossAttentionBlock kernels; "
+                            "call the block instead")
+
+
+class _PackedModule:
+    """Mixin: (re)packs this module's parameters into the kernels' layout when any of them changed."""
+
+    def _packed(self, items_fn, device) -> ops.PackedWeights:
+        key = (tuple((p.data_ptr(), p._version) for p in self._pack_params()), self._pack_shape(), str(device))
+        cache = self.__dict__.get("_pack_cache")
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        if cache is not None and cache[0][1:] == key[1:]:
+            pw = cache[1]  # same geometry: refill the same device buffer
+            pw.items = items_fn()
+        else:
+            pw = ops.PackedWeights(items_fn(), device)
+        pw.pack()
+        self.__dict__["_pack_cache"] = (key, pw)
+        return pw
+
+    def __getstate__(self):  # torch.save(model) pickles whole modules (train.py:124): drop the ctypes cache
+        state = dict(self.__dict__)
+        state.pop("_pack_cache", None)
+        state.pop("_final_norm_params", None)
+        return state
+
+
+class SelfAttentionBlock(Encoder, _PackedModule):
+    def __init__(self, d: int, H: int, p: float, residual: bool):
+        super().__init__()
+        self.residual = residual
+        self.norm1 = nn.LayerNorm(normalized_shape=d)
+        self.attn = MultiHeadAttention(embed_dim=d, num_heads=H, dropout=p)
+        self.norm2 = nn.LayerNorm(normalized_shape=d)
+        self.ffn_1 = nn.Conv1d(in_channels=d, out_channels=d, kernel_size=1)
+        self.lrelu = nn.LeakyReLU()
+        self.dropout1 = nn.Dropout(p=p)
+        self.ffn_2 = nn.Conv1d(in_channels=d, out_channels=d, kernel_size=1)
+        self.dropout2 = nn.Dropout(p=p)
+        nn.init.xavier_uniform_(self.ffn_1.weight)
+        nn.init.xavier_uniform_(self.ffn_2.weight)
+        nn.init.zeros_(self.ffn_1.bias)
+        nn.init.zeros_(self.ffn_2.bias)
+
+    # -- packing -------------------------------------------------------------------------------
+    def _pack_params(self):
+        return list(self.parameters())
+
+    def _pack_shape(self):
+        return (self.attn.d, self.attn.H)
+
+    def _items(self) -> List[ops.PackItem]:
+        d, H = self.attn.d, self.attn.H
+        dpi, dhp, dpo = ops.padded_dims(d, H)
+        vec = lambda t: ops.PackItem(t, 1, dpi)  # noqa: E731
+        return ([vec(self.norm1.weight), vec(self.norm1.bias), vec(self.norm2.weight), vec(self.norm2.bias)]
+                + self.attn.pack_items(dpi, dhp, dpo)
+                + [ops.PackItem(self.ffn_1.weight[:, :, 0], dpi, dpi), ops.PackItem(self.ffn_2.weight[:, :, 0], dpi, dpi),
+                   vec(self.ffn_1.bias), vec(self.ffn_2.bias)])
+
+    def weights_struct(self, device) -> "_lib.SaWeights":
+        pw = self._packed(self._items, device)
+        w = _lib.SaWeights()
+        names = ["ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wk", "wv", "bq", "bk", "bv", "w1", "w2", "b1", "b2"]
+        for i, n in enumerate(names):
+            setattr(w, n, pw.ptr(i))
+        w._keepalive = pw
+        return w
+
+    def _check_mode(self):
+        if self.training and self.attn.dropout.p > 0:
+            raise CarcaHipError("dropout p > 0 in training mode is not built in the HIP path yet; use p = 0 or eval()")
+
+    def forward(self, x: Tensor, mask: Tensor) -> Tensor:
+        """x [B, L, >=d], mask [B, L] (0 = pad) -> [B, L, d] (a view of a padded buffer)."""
+        self._check_mode()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd import sa_block_with_grad
+
+            return sa_block_with_grad(self, x, mask)
+        d = self.attn.d
+        y = ops.sa_block_fwd(x, mask != 0, self.weights_struct(x.device), d, self.attn.H, self.residual)
+        return y[..., :d]
+
+
+class CrossAttentionBlock(Decoder, _PackedModule):
+    def __init__(self, d: int, H: int, p: float, residual: bool):
+        super().__init__()
+        self.residual = residual
+        self.attn = MultiHeadAttention(embed_dim=d, num_heads=H, dropout=p)
+        self.ffn = nn.Linear(in_features=d, out_features=1)
+        self.sig = nn.Sigmoid()
+        nn.init.xavier_uniform_(self.ffn.weight)
+        nn.init.zeros_(self.ffn.bias)
+
+    def _pack_params(self):
+        extra = list(self.__dict__.get("_final_norm_params", ()))
+        return list(self.parameters()) + extra
+
+    def _pack_shape(self):
+        return (self.attn.d, self.attn.H, len(self.__dict__.get("_final_norm_params", ())))
+
+    def _items(self) -> List[ops.PackItem]:
+        d, H = self.attn.d, self.attn.H
+        dpi, dhp, dpo = ops.padded_dims(d, H)
+        dh = d // H
+        items = self.attn.pack_items(dpi, dhp, dpo)
+        items += [ops.PackItem(self.ffn.weight, 1, dpo, col_heads=(dh, dhp)), ops.PackItem(self.ffn.weight, 1, dpi),
+                  ops.PackItem(self.ffn.bias, 1, 4)]
+        for t in self.__dict__.get("_final_norm_params", ()):
+            items.append(ops.PackItem(t, 1, dpi))
+        return items
+
+    def weights_struct(self, device, final_norm: Optional[nn.LayerNorm]) -> "_lib.CaWeights":
+        # the final LayerNorm of CARCA (carca.py:421) is fused into this kernel's prologue
+        self.__dict__["_final_norm_params"] = (final_norm.weight, final_norm.bias) if final_norm is not None else ()
+        pw = self._packed(self._items, device)
+        w = _lib.CaWeights()
+        for i, n in enumerate(["wq", "wk", "wv", "bq", "bk", "bv", "ffn_w_pad", "ffn_w", "ffn_b"]):
+            setattr(w, n, pw.ptr(i))
+        if final_norm is not None:
+            w.ln_w, w.ln_b = pw.ptr(9), pw.ptr(10)
+        else:
+            w.ln_w, w.ln_b = None, None
+        w._keepalive = pw
+        return w
+
+    def _check_mode(self):
+        if self.training and self.attn.dropout.p > 0:
+            raise CarcaHipError("dropout p > 0 in training mode is not built in the HIP path yet; use p = 0 or eval()")
+
+    def forward(self, o: Tensor, o_mask: Tensor, p: Tensor, p_mask: Tensor) -> Tensor:
+        """Standalone decoder call: p is already final-normed (as in carca.py:421-428)."""
+        self._check_mode()
+        if torch.is_grad_enabled() and (o.requires_grad or p.requires_grad or
+                                        any(q.requires_grad for q in self.parameters())):
+            from .autograd import cross_with_grad
+
+            return cross_with_grad(self, o, o_mask, p, p_mask)
+        d, H = self.attn.d, self.attn.H
+        dpi, _, _ = ops.padded_dims(d, H)
+        o_pad = _pad_cols(o, dpi)
+        (y,), _ = ops.cross_score_fwd(p, p_mask != 0, [(o_pad, o_mask != 0)], self.weights_struct(o.device, None), d, H,
+                                      self.residual, self.training)
+        return y.squeeze()  # bare squeeze, as carca.py:346
+
+
+def _pad_cols(t: Tensor, width: int) -> Tensor:
+    """[.., w] -> contiguous [.., width] with zero pad columns (data movement only)."""
+    if t.shape[-1] == width and t.is_contiguous():
+        return t
+    out = t.new_zeros(*t.shape[:-1], width)
+    out[..., : t.shape[-1]] = t
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# CARCA (carca.py:401-431)
+# ------------------------------------------------------------------------------------------------
+
+
+class CARCA(Model):
+    def __init__(self, d: int, p: float, emb: Embedding, enc: Iterable[Encoder], dec: Decoder):
+        super().__init__()
+        self.embeds = emb
+        self.dropout = nn.Dropout(p=p)
+        self.encoder = enc
+        self.norm = nn.LayerNorm(normalized_shape=d)
+        self.decoder = dec
+
+    def _fusable(self) -> bool:
+        return (isinstance(self.embeds, AllEmbedding) and isinstance(self.decoder, CrossAttentionBlock)
+                and all(isinstance(b, SelfAttentionBlock) for b in self.encoder))
+
+    def forward(self, profile: Tuple[Tensor, Tensor, Tensor], targets: List[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
+        if not self._fusable():
+            raise CarcaHipError(
+                "only the AllEmbedding + SelfAttentionBlock + CrossAttentionBlock path is built in HIP "
+                "(SURVEY.md section 8: the other embeddings/decoders are ablations outside the hot path)")
+        if self.training and self.dropout.p > 0:
+            raise CarcaHipError("dropout p > 0 in training mode is not built in the HIP path yet; use p = 0 or eval()")
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            from .autograd import carca_forward_with_grad
+
+            ys = carca_forward_with_grad(self, profile, targets)
+        else:
+            ys = self.forward_nograd(profile, targets)
+        # each group's scores are squeezed the way CrossAttentionBlock does (carca.py:346), then joined (carca.py:431)
+        return torch.cat([y.squeeze() for y in ys], dim=-1)
+
+    def forward_nograd(self, profile, targets, trace: Optional[dict] = None) -> List[Tensor]:
+        p_x, p_a, p_c = profile
+        if len(targets) > _lib.MAX_GROUPS:
+            raise CarcaHipError(f"at most {_lib.MAX_GROUPS} target groups per call")
+        d = self.embeds.d
+        H = self.decoder.attn.H
+        dpi, _, _ = ops.padded_dims(d, H)
+        segs = [(p_x, p_a, p_c, False)] + [(o_x, o_a, o_c, True) for (o_x, o_a, o_c) in targets]
+        es, _ = self.embeds.embed_segments(segs, ld_e=dpi)
+        x = es[0]
+        if trace is not None:
+            trace["p_embed"] = x[..., :d]
+            for gi in range(len(targets)):
+                trace[f"o_embed{gi}"] = es[gi + 1][..., :d]
+        for i, blk in enumerate(self.encoder):
+            blk._check_mode()
+            x = ops.sa_block_fwd(x, p_x, blk.weights_struct(x.device), d, blk.attn.H, blk.residual)
+            if trace is not None:
+                trace[f"block{i}"] = x[..., :d]
+        self.decoder._check_mode()
+        groups = [(es[gi + 1], targets[gi][0]) for gi in range(len(targets))]
+        ys, p_normed = ops.cross_score_fwd(x, p_x, groups, self.decoder.weights_struct(x.device, self.norm), d, H,
+                                           self.decoder.residual, self.training, want_normed=trace is not None)
+        if trace is not None:
+            trace["p_final"] = p_normed[..., :d]
+        return ys
+
+
+# ------------------------------------------------------------------------------------------------
+# loss (carca.py:437-444)
+# ------------------------------------------------------------------------------------------------
+
+
+class BinaryCrossEntropy(nn.Module):
+    def forward(self, y_pred: Tensor, y_true: Tensor, mask: Tensor, eps: float = 1e-8) -> Tensor:
+        if torch.is_grad_enabled() and y_pred.requires_grad:
+            from .autograd import bce_with_grad
+
+            return bce_with_grad(y_pred, y_true, mask, eps)
+        loss, _ = ops.bce_fwd(y_pred, y_true, mask != 0, eps)
+        return loss

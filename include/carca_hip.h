@@ -1,0 +1,149 @@
+/* carca_hip.h -- C ABI of libcarca_hip.so: the MI355X (gfx950) CARCA hot path.
+ *
+ * The reference (r-papso/carca-replication) is pure PyTorch and has no FFI of its own; its
+ * plug-in boundary is the nn.Module ABCs of src/abstract.py:8-50.  This library sits UNDER
+ * those modules: each entry point replaces the ATen op sequence of one reference method, named
+ * below with file:line.  The Python host layer (carca_replication_amd/modules.py) keeps the
+ * reference's class names, constructors, state_dict keys and forward() semantics and binds
+ * these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (ids: int32) unless it says "host";
+ *  - tensors are row-major; `ld*` is a row stride in elements; activation strides must be
+ *    multiples of 4 elements and bases 16-byte aligned (torch allocations are);
+ *  - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, nothing
+ *    synchronises, nothing is allocated, nothing is retained after the call returns
+ *    (graph-capturable); callers own all memory;
+ *  - return 0 on success, a negative CARCA_ERR_* for a rejected call (message from
+ *    carca_last_error()), a positive hipError_t for a failed launch.  Never aborts.
+ */
+#ifndef CARCA_HIP_H
+#define CARCA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CARCA_ABI_VERSION 1
+#define CARCA_OK 0
+#define CARCA_ERR_UNSUPPORTED (-1) /* shape outside what the kernels were built for */
+#define CARCA_ERR_BADARG (-2)      /* null pointer, misaligned stride, ... */
+
+#define CARCA_MAX_SEGS 4   /* profile + up to 3 target groups per embed call */
+#define CARCA_MAX_GROUPS 3 /* target groups per scoring call (train: pos, neg) */
+#define CARCA_MAX_L 64     /* profile slots one workgroup keeps in LDS */
+#define CARCA_EMBED_GATHER 1
+#define CARCA_EMBED_FEAT 2
+#define CARCA_EMBED_JOINT 4
+#define CARCA_EMBED_ALL 7
+
+int carca_abi_version(void);
+const char* carca_last_error(void); /* host string, thread-local, valid until the next call */
+
+/* ------------------------------------------------------------------------------------------
+ * Padded geometry shared by every entry point.  For model width d and H heads (dh = d/H):
+ *   DPI = 64 / 96 / 128 (smallest >= d) padded input-feature count (k of the projections)
+ *   DHP = round_up(dh, 16)           padded per-head width
+ *   DPO = H * DHP                    head-padded output-feature count
+ * Activations travel between kernels as [rows, DPI] with zeroed pad columns.
+ * ---------------------------------------------------------------------------------------- */
+int carca_padded_dims(int d, int H, int* dpi, int* dhp, int* dpo);
+
+/* ---- weight packing -----------------------------------------------------------------------
+ * Copies parameter matrices (state_dict layout) into the zero-padded, 16-byte-aligned,
+ * optionally head-permuted layout the attention kernels read MFMA fragments from.
+ * dst[rp][cp] = src[r][c] where rp (cp) is r (c) itself, or its head-padded position when
+ * row_dh (col_dh) > 0; every dst element is written (pads = 0).  descs is a HOST array. */
+typedef struct CarcaPackDesc {
+  const float* src; /* [rows, cols], row stride src_ld */
+  float* dst;       /* [dst_rows, dst_cols] dense */
+  int32_t rows, cols, src_ld;
+  int32_t dst_rows, dst_cols;
+  int32_t row_dh, row_dhp; /* 0,0 = plain rows */
+  int32_t col_dh, col_dhp; /* 0,0 = plain cols */
+} CarcaPackDesc;
+int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream);
+
+/* ---- a1 + a2 + a9: AllEmbedding.forward over several row segments ---------------------------
+ * Replaces get_mask (utils.py:6-7) + AllEmbedding.forward (carca.py:85-95) + the additive
+ * encodings (carca.py:25-31, 54-60) for the profile and every target group in ONE call:
+ *   q = [attrs ; ctx] W_f^T + b_f ; z = E[ids] * sqrt(d) ; e = [z ; q] W_j^T + b_j (+ pos[t]) ;
+ *   e *= (ids != 0).
+ * zq is workspace AND the tensor the backward needs: [sum(rows), d + g], rows of segment s
+ * start at sum(rows of earlier segments).  e_out rows have stride ld_e >= d, columns d..ld_e-1
+ * are written as zeros.  `stages` selects which of the three launches to issue (bit 0 gather,
+ * bit 1 feature GEMM, bit 2 joint GEMM; 7 = all) so a profiler can bracket one of them with events. */
+typedef struct CarcaRowSeg {
+  const int32_t* ids; /* [rows] item ids, 0 = pad */
+  const float* attrs; /* [rows, n_attrs] */
+  const float* ctx;   /* [rows, n_ctx] */
+  float* e_out;       /* [rows, ld_e] */
+  int32_t rows;       /* B * T */
+  int32_t T;          /* slots per user (position index = row % T) */
+  int32_t add_pos;    /* 1: add pos[row % T] (profile side, carca.py:91-92) */
+} CarcaRowSeg;
+int carca_embed_fwd(const CarcaRowSeg* segs /*host*/, int nseg, int n_attrs, int n_ctx, int d, int g,
+                    const float* items_w /*[n_items,d]*/, const float* feats_w /*[g,n_attrs+n_ctx]*/,
+                    const float* feats_b /*[g]*/, const float* joint_w /*[d,d+g]*/, const float* joint_b /*[d]*/,
+                    const float* pos /*[T,d] or NULL*/, float* zq, int ld_e, int stages, void* stream);
+
+/* ---- a3 + a4: SelfAttentionBlock.forward -----------------------------------------------------
+ * Replaces SelfAttentionBlock.forward (carca.py:297-318) incl. MultiHeadAttention.forward
+ * (carca.py:228-265) with causal=0, in eval mode / dropout p = 0.  One workgroup per user.
+ * Pointers in CarcaSaWeights are PACKED (carca_pack_weights): projections [DPO, DPI] with
+ * head-padded rows, biases [DPO] head-padded, ffn matrices [DPI, DPI], LayerNorm vectors [DPI]. */
+typedef struct CarcaSaWeights {
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b; /* [DPI] */
+  const float *wq, *wk, *wv;                  /* [DPO, DPI] */
+  const float *bq, *bk, *bv;                  /* [DPO] */
+  const float *w1, *w2;                       /* [DPI, DPI] */
+  const float *b1, *b2;                       /* [DPI] */
+} CarcaSaWeights;
+int carca_sa_block_fwd(const float* x /*[B*L, ldx]*/, int ldx, const int32_t* ids /*[B*L]*/, float* y /*[B*L, ldy]*/,
+                       int ldy, int B, int L, int d, int H, const CarcaSaWeights* w /*host struct*/, int residual,
+                       void* stream);
+
+/* ---- a5 + a6: final LayerNorm + CrossAttentionBlock.forward, grouped --------------------------
+ * Replaces CARCA.forward's final norm (carca.py:421) and, for every target group,
+ * CrossAttentionBlock.forward (carca.py:338-349): K/V projections of the normed profile are
+ * computed once per user, then each group's targets are scored:
+ *   y = sigmoid(ffn(MHA(o, p, p) + o)), tril(-1) masking iff training (carca.py:339).
+ * One workgroup per user.  y_out[g] is [B, N_g] dense. */
+typedef struct CarcaCaWeights {
+  const float *ln_w, *ln_b; /* final norm [DPI]; both NULL = p_raw is already normed (standalone decoder) */
+  const float *wq, *wk, *wv; /* [DPO, DPI] */
+  const float *bq, *bk, *bv; /* [DPO] */
+  const float* ffn_w_pad;    /* decoder.ffn.weight in head-padded order [DPO] */
+  const float* ffn_w;        /* decoder.ffn.weight plain, zero-padded [DPI] */
+  const float* ffn_b;        /* [1] */
+} CarcaCaWeights;
+typedef struct CarcaTargetGroup {
+  const float* o;     /* embedded targets [B*N, ldo] */
+  const int32_t* ids; /* [B*N] */
+  float* y;           /* [B*N] */
+  int32_t N;
+} CarcaTargetGroup;
+int carca_cross_score_fwd(const float* p_raw /*[B*L, ldp] encoder output BEFORE the final norm*/, int ldp,
+                          const int32_t* p_ids /*[B*L]*/, float* p_normed /*[B*L, ldp] or NULL*/,
+                          const CarcaTargetGroup* groups /*host*/, int ngroups, int ldo, int B, int L, int d, int H,
+                          const CarcaCaWeights* w /*host struct*/, int residual, int training, void* stream);
+
+/* ---- a8: BinaryCrossEntropy.forward (carca.py:441-444) -----------------------------------------
+ * loss = sum(l * m) / sum(m), l = -(t log(y+eps) + (1-t) log(1-y+eps)), m = (ids != 0).
+ * scratch: 2 floats, zeroed by the call; loss_out: 1 float.  dy (optional) receives dloss/dy. */
+int carca_bce_fwd(const float* y, const int32_t* y_true, const int32_t* ids, int n, float eps, float* scratch,
+                  float* loss_out, float* dy /*or NULL*/, void* stream);
+
+/* ---- M: compute_HR / compute_NDCG (train.py:15-32) without the sort ----------------------------
+ * rank[u] = #{j > 0 : y[u][j] > y[u][0]}; sums[0] += [rank < k], sums[1] += [rank<k]/log2(rank+2),
+ * sums[2] += #{j > 0 : y[u][j] == y[u][0]} (ties: the reference's unstable sort is undefined there).
+ * sums is accumulated into (caller zeroes it once per evaluation). */
+int carca_rank_metrics(const float* y /*[B,N]*/, int B, int N, int k, int32_t* rank /*[B] or NULL*/,
+                       float* sums /*[3]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARCA_HIP_H */

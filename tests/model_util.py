@@ -1,0 +1,54 @@
+"""Helpers shared by the GPU parity tests: build the HIP-backed model from a fixture / oracle params."""
+import torch
+
+from carca_replication_amd import modules as M
+
+
+def build_model(cfg, n_items, g, n_ctx, n_attrs, L, p=0.0):
+    """cfg: dict with d, H, n_blocks and optional encoding / residual_sa / residual_ca (as in make_golden.py)."""
+    d, H = int(cfg["d"]), int(cfg["H"])
+    enc_name = str(cfg.get("encoding", "identity"))
+    if enc_name == "identity":
+        enc = M.IdentityEncoding()
+    elif enc_name == "learnable":
+        enc = M.LearnableEncoding(d, L)
+    elif enc_name == "positional":
+        enc = M.PositionalEncoding(d, L)
+    else:
+        raise ValueError(enc_name)
+    emb = M.AllEmbedding(n_items, d, g, n_ctx, n_attrs, enc)
+    blocks = torch.nn.ModuleList([M.SelfAttentionBlock(d, H, p, bool(cfg.get("residual_sa", True)))
+                                  for _ in range(int(cfg["n_blocks"]))])
+    dec = M.CrossAttentionBlock(d, H, p, bool(cfg.get("residual_ca", True)))
+    return M.CARCA(d=d, p=p, emb=emb, enc=blocks, dec=dec)
+
+
+def model_from_fixture(fx, device="cuda"):
+    dm = fx.dim
+    g = int(fx.params["embeds.feats_embed.weight"].shape[0])
+    model = build_model(fx.cfg, int(dm["n_items"]), g, int(dm["n_ctx"]), int(dm["n_attrs"]), int(dm["L"]))
+    missing, unexpected = model.load_state_dict(fx.params, strict=True)
+    assert not missing and not unexpected
+    return model.to(device)
+
+
+def model_from_params(params, cfg, device="cuda"):
+    """params: oracle-style flat dict (state_dict keys)."""
+    n_items, d = params["embeds.items_embed.weight"].shape
+    g, F = params["embeds.feats_embed.weight"].shape
+    L = 1
+    if "embeds.enc.encoding.weight" in params:
+        L = params["embeds.enc.encoding.weight"].shape[0]
+    if "embeds.enc.pe" in params:
+        L = params["embeds.enc.pe"].shape[1]
+    c = dict(d=cfg.d, H=cfg.H, n_blocks=cfg.n_blocks, encoding=cfg.encoding, residual_sa=cfg.residual_sa,
+             residual_ca=cfg.residual_ca)
+    model = build_model(c, n_items, g, 0, F, L)  # n_ctx + n_attrs only matters through their sum
+    model.load_state_dict(params, strict=True)
+    return model.to(device)
+
+
+def dev(t, device="cuda"):
+    if isinstance(t, (tuple, list)):
+        return type(t)(dev(x, device) for x in t)
+    return t.to(device)
