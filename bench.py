@@ -62,13 +62,29 @@ def build_model(c, device):
     return model.eval().to(device)
 
 
+def host_cores():
+    """CPU threads this process may really use: cgroup quota, else affinity, else cpu_count."""
+    env = os.environ.get("CARCA_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(c, model, profile, target, budget_s=15.0):
     """The CPU oracle (port of the reference's PyTorch-CPU forward) on all host cores, bounded sample."""
     import torch
 
     from oracle import carca_oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     cfg = O.CarcaConfig(d=c["d"], H=c["H"], n_blocks=c["n_blocks"])

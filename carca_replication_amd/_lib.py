@@ -154,6 +154,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must load ITS libamdhip64.so.7 first: the library below has the same soname, and a process
+    # that resolves it to /opt/rocm's copy before torch starts ends up with a runtime that sees no device
+    import torch  # noqa: F401
+
     if not is_built():
         build()
     with _lock:
