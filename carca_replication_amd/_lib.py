@@ -18,7 +18,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libcarca_hip.so")
 _STAMP = LIB_PATH + ".srchash"
-SOURCES = ["api.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip"]
+SOURCES = ["api.hip", "gemm.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip"]
 HEADERS = ["carca_common.h", "attn_common.h"]
 
 MAX_SEGS = 4
@@ -110,6 +110,29 @@ class RowSeg(C.Structure):
                 ("add_pos", C.c_int32)]
 
 
+class GemmSeg(C.Structure):
+    _fields_ = [("a0", _fp), ("a1", _fp), ("c", _fp), ("ids", _fp), ("add", _fp), ("gate", _fp), ("rowscale", _fp),
+                ("rows", C.c_int32), ("T", C.c_int32), ("add_pos", C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("seg", GemmSeg * MAX_SEGS), ("nseg", C.c_int32), ("lda0", C.c_int32), ("lda1", C.c_int32),
+                ("K0", C.c_int32), ("K1", C.c_int32), ("bt0", _fp), ("bt1", _fp), ("ldb0", C.c_int32),
+                ("ldb1", C.c_int32), ("N", C.c_int32), ("ldc", C.c_int32), ("ncols_out", C.c_int32), ("bias", _fp),
+                ("pos", _fp), ("colvec", _fp), ("ld_add", C.c_int32), ("ld_gate", C.c_int32),
+                ("gate_slope", C.c_float), ("mask_rows", C.c_int32)]
+
+
+class WgradSeg(C.Structure):
+    _fields_ = [("dy", _fp), ("x", _fp), ("ids", _fp), ("rows", C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("seg", WgradSeg * MAX_SEGS), ("nseg", C.c_int32), ("ld_dy", C.c_int32), ("ld_x", C.c_int32),
+                ("N", C.c_int32), ("K", C.c_int32), ("dw", _fp), ("ldw", C.c_int32), ("db", _fp),
+                ("mask_rows", C.c_int32)]
+
+
 class SaWeights(C.Structure):
     _fields_ = [(n, _fp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wk", "wv", "bq", "bk", "bv", "w1", "w2",
                                    "b1", "b2")]
@@ -131,6 +154,8 @@ SIGNATURES = {
     "carca_padded_dims": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "carca_pack_weights": (_i, [C.POINTER(PackDesc), _i, _fp]),
     "carca_embed_fwd": (_i, [C.POINTER(RowSeg), _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),
+    "carca_gemm_rows": (_i, [C.POINTER(GemmDesc), _fp]),
+    "carca_gemm_wgrad": (_i, [C.POINTER(WgradDesc), _fp]),
     "carca_sa_block_fwd": (_i, [_fp, _i, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SaWeights), _i, _fp]),
     "carca_cross_score_fwd": (_i, [_fp, _i, _fp, _fp, C.POINTER(TargetGroup), _i, _i, _i, _i, _i, _i,
                                    C.POINTER(CaWeights), _i, _i, _fp]),

@@ -254,3 +254,120 @@ def rank_metrics(y: Tensor, k: int, sums: Optional[Tensor] = None, want_rank: bo
     _lib.check(lib.carca_rank_metrics(y.data_ptr(), B, N, k, rank.data_ptr() if want_rank else None, sums.data_ptr(),
                                       _stream()), "rank_metrics")
     return sums, rank
+
+
+# --------------------------------------------------------------------------------------------------
+# dense building blocks (used by the backward pass; the forward reaches gemm_rows through embed_fwd)
+# --------------------------------------------------------------------------------------------------
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[Tensor] = None, K1: int = 0,
+              bias: Optional[Tensor] = None, pos: Optional[Tensor] = None, colvec: Optional[Tensor] = None,
+              gate_slope: float = 0.01, mask_rows: bool = False, ncols_out: Optional[int] = None) -> List[Tensor]:
+    """C_s[m][n] = sum_k A_s[m][k] Bt[n][k] (+ epilogue) for every row segment s.
+
+    segs: list of dicts with keys a0 [rows, lda0] and optionally a1, ids, add, gate, rowscale, T, add_pos, out.
+    All 2-D operands are row-major views whose LAST stride is 1; their row stride is taken from .stride(0).
+    Returns the output tensors [rows, out_ld] (allocated here unless the segment brings 'out').
+    """
+    lib = _lib.load()
+    if not 1 <= len(segs) <= _lib.MAX_SEGS:
+        raise CarcaHipError("gemm_rows: 1..4 segments")
+    D = _lib.GemmDesc()
+    D.nseg = len(segs)
+    outs, keep = [], []
+
+    def ld_of(t, name):
+        if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
+            raise CarcaHipError(f"gemm_rows: {name} must be a 2-D fp32 view with unit inner stride")
+        _need_cuda(t)
+        return t.stride(0)
+
+    lda0 = lda1 = ld_add = ld_gate = None
+    for i, sg in enumerate(segs):
+        a0 = sg["a0"]
+        rows = a0.shape[0]
+        S = D.seg[i]
+        l0 = ld_of(a0, "a0")
+        lda0 = l0 if lda0 is None else lda0
+        if l0 != lda0:
+            raise CarcaHipError("gemm_rows: all segments must share lda0")
+        S.a0 = a0.data_ptr()
+        a1 = sg.get("a1")
+        if K1:
+            l1 = ld_of(a1, "a1")
+            lda1 = l1 if lda1 is None else lda1
+            S.a1 = a1.data_ptr()
+        out = sg.get("out")
+        if out is None:
+            out = torch.empty(rows, out_ld, dtype=torch.float32, device=a0.device)
+        if ld_of(out, "out") != out_ld:
+            raise CarcaHipError("gemm_rows: out row stride != out_ld")
+        S.c = out.data_ptr()
+        outs.append(out)
+        ids = sg.get("ids")
+        if ids is not None:
+            ids = _ids32(ids.reshape(-1))
+            keep.append(ids)
+            S.ids = ids.data_ptr()
+        add, gate, rs = sg.get("add"), sg.get("gate"), sg.get("rowscale")
+        if add is not None:
+            la = ld_of(add, "add")
+            ld_add = la if ld_add is None else ld_add
+            S.add = add.data_ptr()
+        if gate is not None:
+            lg = ld_of(gate, "gate")
+            ld_gate = lg if ld_gate is None else ld_gate
+            S.gate = gate.data_ptr()
+        if rs is not None:
+            rs = _f32(rs.reshape(-1))
+            keep.append(rs)
+            S.rowscale = rs.data_ptr()
+        S.rows, S.T, S.add_pos = rows, int(sg.get("T", 1)), int(bool(sg.get("add_pos", False)))
+    D.lda0, D.lda1, D.K0, D.K1 = lda0, lda1 or 0, K0, K1
+    D.bt0, D.ldb0 = bt0.data_ptr(), ld_of(bt0, "bt0")
+    if K1:
+        D.bt1, D.ldb1 = bt1.data_ptr(), ld_of(bt1, "bt1")
+    D.N, D.ldc, D.ncols_out = N, out_ld, out_ld if ncols_out is None else ncols_out
+    D.bias, D.pos, D.colvec = _ptr(bias), _ptr(pos), _ptr(colvec)
+    D.ld_add, D.ld_gate, D.gate_slope, D.mask_rows = ld_add or 0, ld_gate or 0, gate_slope, int(mask_rows)
+    _lib.check(lib.carca_gemm_rows(C.byref(D), _stream()), "gemm_rows")
+    return outs
+
+
+def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, mask_rows: bool = False) -> None:
+    """dw[n][k] += sum_r dy[r][n] x[r][k] (and db[n] += sum_r dy[r][n]) over all segments' rows.
+
+    segs: list of dicts with dy [rows, >=N], x [rows, >=K], optional ids.  dw is a 2-D fp32 view (unit inner stride).
+    """
+    lib = _lib.load()
+    D = _lib.WgradDesc()
+    D.nseg = len(segs)
+    keep = []
+    ld_dy = ld_x = None
+    for i, sg in enumerate(segs):
+        dy, x = sg["dy"], sg["x"]
+        for t in (dy, x):
+            _need_cuda(t)
+            if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
+                raise CarcaHipError("gemm_wgrad: dy/x must be 2-D fp32 views with unit inner stride")
+        if dy.shape[0] != x.shape[0]:
+            raise CarcaHipError("gemm_wgrad: dy and x row counts differ")
+        ld_dy = dy.stride(0) if ld_dy is None else ld_dy
+        ld_x = x.stride(0) if ld_x is None else ld_x
+        if dy.stride(0) != ld_dy or x.stride(0) != ld_x:
+            raise CarcaHipError("gemm_wgrad: all segments must share row strides")
+        S = D.seg[i]
+        S.dy, S.x, S.rows = dy.data_ptr(), x.data_ptr(), dy.shape[0]
+        ids = sg.get("ids")
+        if ids is not None:
+            ids = _ids32(ids.reshape(-1))
+            keep.append(ids)
+            S.ids = ids.data_ptr()
+    if dw.dim() != 2 or dw.stride(1) != 1 or dw.dtype != torch.float32:
+        raise CarcaHipError("gemm_wgrad: dw must be a 2-D fp32 view with unit inner stride")
+    D.ld_dy, D.ld_x, D.N, D.K = ld_dy, ld_x, N, K
+    D.dw, D.ldw, D.db, D.mask_rows = dw.data_ptr(), dw.stride(0), _ptr(db), int(mask_rows)
+    _lib.check(lib.carca_gemm_wgrad(C.byref(D), _stream()), "gemm_wgrad")

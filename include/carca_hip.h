@@ -66,6 +66,66 @@ typedef struct CarcaPackDesc {
 } CarcaPackDesc;
 int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream);
 
+/* ---- building block: row GEMM  C[m][n] = sum_k A[m][k] * Bt[n][k]  (+ epilogue) ------------------
+ * The tiled fp32-MFMA kernel behind AllEmbedding's two Linear layers (carca.py:86,89) and every
+ * dense input-gradient product of the backward pass.  Rows come from up to CARCA_MAX_SEGS segments
+ * (one launch for profile + target groups); k runs over up to two column sources (a0 | a1), each
+ * with its own Bt, so torch.cat((a, c), -1) @ W^T never materialises the concatenation.
+ * Epilogue, in this order, each part optional:
+ *   v = acc + bias[n] + pos[(row % T)][n] + add[row][n] + rowscale[row] * colvec[n]
+ *   v *= (gate[row][n] > 0 ? 1 : gate_slope)            (LeakyReLU', from the saved activation)
+ *   v  = ids[row] != 0 ? v : 0                          (when mask_rows)
+ *   C[row][n] = v for n < N;  C[row][n] = 0 for N <= n < ncols_out                              */
+typedef struct CarcaGemmSeg {
+  const float* a0;       /* [rows, lda0] */
+  const float* a1;       /* [rows, lda1] or NULL when K1 == 0 */
+  float* c;              /* [rows, ldc] */
+  const int32_t* ids;    /* [rows] or NULL (needed by mask_rows / add_pos) */
+  const float* add;      /* [rows, ld_add] or NULL */
+  const float* gate;     /* [rows, ld_gate] or NULL */
+  const float* rowscale; /* [rows] or NULL */
+  int32_t rows, T, add_pos;
+} CarcaGemmSeg;
+typedef struct CarcaGemmDesc {
+  CarcaGemmSeg seg[CARCA_MAX_SEGS];
+  int32_t nseg;
+  int32_t lda0, lda1, K0, K1;
+  const float* bt0; /* [N, ldb0] */
+  const float* bt1; /* [N, ldb1] or NULL */
+  int32_t ldb0, ldb1;
+  int32_t N, ldc, ncols_out;
+  const float* bias;   /* [N] or NULL */
+  const float* pos;    /* [T, N] or NULL */
+  const float* colvec; /* [N] or NULL */
+  int32_t ld_add, ld_gate;
+  float gate_slope;
+  int32_t mask_rows;
+} CarcaGemmDesc;
+int carca_gemm_rows(const CarcaGemmDesc* desc /*host*/, void* stream);
+
+/* ---- building block: weight-gradient GEMM  dW[n][k] += sum_r dY[r][n] * X[r][k] -------------------
+ * The contraction runs over ROWS (users x slots), split across workgroups; partial tiles are
+ * combined with fp32 atomic adds into dW (caller zeroes dW / db first; summation order, hence the
+ * last bits, varies run to run).  db[n] += sum_r dY[r][n] when db != NULL.  Rows whose ids == 0
+ * are skipped when mask_rows (the e * mask of carca.py:94 seen from the backward side). */
+typedef struct CarcaWgradSeg {
+  const float* dy;    /* [rows, ld_dy] */
+  const float* x;     /* [rows, ld_x] */
+  const int32_t* ids; /* [rows] or NULL */
+  int32_t rows;
+} CarcaWgradSeg;
+typedef struct CarcaWgradDesc {
+  CarcaWgradSeg seg[CARCA_MAX_SEGS];
+  int32_t nseg;
+  int32_t ld_dy, ld_x;
+  int32_t N, K; /* dW is [N, K] */
+  float* dw;
+  int32_t ldw;
+  float* db; /* [N] or NULL */
+  int32_t mask_rows;
+} CarcaWgradDesc;
+int carca_gemm_wgrad(const CarcaWgradDesc* desc /*host*/, void* stream);
+
 /* ---- a1 + a2 + a9: AllEmbedding.forward over several row segments ---------------------------
  * Replaces get_mask (utils.py:6-7) + AllEmbedding.forward (carca.py:85-95) + the additive
  * encodings (carca.py:25-31, 54-60) for the profile and every target group in ONE call:

@@ -1,0 +1,86 @@
+"""GPU unit tests of the dense building blocks (C ABI: carca_gemm_rows, carca_gemm_wgrad, ...).
+
+These are floating-point kernels, so each is compared with a plain torch fp32/fp64 statement of the
+same product on the same seeded inputs (tolerance: fp32 accumulation over K <= 4102 terms).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1)
+
+
+def _close(got, want, tol=2e-5):
+    scale = float(want.abs().max()) + 1e-12
+    err = float((got.double().cpu() - want.double()).abs().max())
+    assert err <= tol * scale, (err, scale)
+
+
+@pytest.mark.parametrize("rows,N,K0,K1", [(300, 90, 77, 0), (129, 450, 4096, 6), (64, 33, 5, 3), (1, 1, 1, 0),
+                                          (257, 200, 96, 96)])
+def test_gemm_rows_plain(rows, N, K0, K1):
+    from carca_replication_amd import ops
+
+    a0, a1 = _rand(rows, K0, seed=1), _rand(rows, max(K1, 1), seed=2)
+    bt = _rand(N, K0 + K1, seed=3)
+    bias = _rand(N, seed=4)
+    want = a0.double() @ bt[:, :K0].double().T + bias.double()
+    if K1:
+        want = want + a1.double() @ bt[:, K0:].double().T
+    btc = bt.cuda()
+    out_ld = ((N + 3) // 4) * 4 + 4
+    (got,) = ops.gemm_rows([dict(a0=a0.cuda(), a1=a1.cuda() if K1 else None)], btc[:, :K0], N, K0, out_ld,
+                           bt1=btc[:, K0:] if K1 else None, K1=K1, bias=bias.cuda())
+    _close(got[:, :N], want)
+    assert float(got[:, N:].abs().max()) == 0.0  # pad columns are written as zeros
+
+
+def test_gemm_rows_epilogue_and_segments():
+    from carca_replication_amd import ops
+
+    N, K, T = 90, 64, 7
+    rows = [70, 131, 5]
+    bt, bias, pos, colvec = _rand(N, K, seed=1), _rand(N, seed=2), _rand(T, N, seed=3), _rand(N, seed=4)
+    segs, wants = [], []
+    for i, r in enumerate(rows):
+        a = _rand(r, K, seed=10 + i)
+        ids = (torch.rand(r, generator=torch.Generator().manual_seed(20 + i)) > 0.3).int()
+        add, gate, rs = _rand(r, N, seed=30 + i), _rand(r, N, seed=40 + i), _rand(r, seed=50 + i)
+        v = a.double() @ bt.double().T + bias.double()
+        if i == 0:
+            v = v + pos.double()[torch.arange(r) % T]
+        v = v + add.double() + rs.double()[:, None] * colvec.double()[None, :]
+        v = v * torch.where(gate > 0, 1.0, 0.01).double()
+        v = v * (ids != 0).double()[:, None]
+        wants.append(v)
+        segs.append(dict(a0=a.cuda(), ids=ids.cuda(), add=add.cuda(), gate=gate.cuda(), rowscale=rs.cuda(), T=T,
+                         add_pos=(i == 0)))
+    outs = ops.gemm_rows(segs, bt.cuda(), N, K, 96, bias=bias.cuda(), pos=pos.cuda(), colvec=colvec.cuda(),
+                         gate_slope=0.01, mask_rows=True)
+    for got, want in zip(outs, wants):
+        _close(got[:, :N], want)
+
+
+@pytest.mark.parametrize("rows,N,K", [([200], 96, 96), ([6400], 90, 540), ([31, 64, 1], 450, 130), ([300], 7, 6),
+                                      ([1000, 500], 450, 1024)])
+def test_gemm_wgrad(rows, N, K):
+    from carca_replication_amd import ops
+
+    segs, want_w, want_b = [], torch.zeros(N, K, dtype=torch.float64), torch.zeros(N, dtype=torch.float64)
+    for i, r in enumerate(rows):
+        dy, x = _rand(r, N + 3, seed=60 + i), _rand(r, K + 2, seed=70 + i)
+        ids = (torch.rand(r, generator=torch.Generator().manual_seed(80 + i)) > 0.25).int()
+        m = (ids != 0).double()[:, None]
+        want_w += (dy[:, :N].double() * m).T @ x[:, :K].double()
+        want_b += (dy[:, :N].double() * m).sum(0)
+        segs.append(dict(dy=dy.cuda(), x=x.cuda(), ids=ids.cuda()))
+    dw = torch.zeros(N, K + 5, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    ops.gemm_wgrad(segs, N, K, dw, db, mask_rows=True)
+    _close(dw[:, :K], want_w, tol=5e-5)
+    _close(db, want_b, tol=5e-5)
+    assert float(dw[:, K:].abs().max()) == 0.0
