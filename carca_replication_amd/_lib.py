@@ -102,7 +102,7 @@ _fp = C.c_void_p  # device pointers travel as integers
 class PackDesc(C.Structure):
     _fields_ = [("src", _fp), ("dst", _fp), ("rows", C.c_int32), ("cols", C.c_int32), ("src_ld", C.c_int32),
                 ("dst_rows", C.c_int32), ("dst_cols", C.c_int32), ("row_dh", C.c_int32), ("row_dhp", C.c_int32),
-                ("col_dh", C.c_int32), ("col_dhp", C.c_int32)]
+                ("col_dh", C.c_int32), ("col_dhp", C.c_int32), ("transposed", C.c_int32)]
 
 
 class RowSeg(C.Structure):
@@ -133,6 +133,18 @@ class WgradDesc(C.Structure):
                 ("mask_rows", C.c_int32)]
 
 
+class SaSave(C.Structure):
+    _fields_ = [(n, _fp) for n in ("qn", "qh", "kh", "vh", "r", "s2", "h1")]
+
+
+class CaSave(C.Structure):
+    _fields_ = [("kh", _fp), ("vh", _fp), ("qh", _fp * MAX_GROUPS)]
+
+
+class CrossBwdGroup(C.Structure):
+    _fields_ = [("qh", _fp), ("y", _fp), ("dy", _fp), ("ids", _fp), ("dqh", _fp), ("dlogit", _fp), ("N", C.c_int32)]
+
+
 class SaWeights(C.Structure):
     _fields_ = [(n, _fp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wk", "wv", "bq", "bk", "bv", "w1", "w2",
                                    "b1", "b2")]
@@ -156,9 +168,17 @@ SIGNATURES = {
     "carca_embed_fwd": (_i, [C.POINTER(RowSeg), _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     "carca_gemm_rows": (_i, [C.POINTER(GemmDesc), _fp]),
     "carca_gemm_wgrad": (_i, [C.POINTER(WgradDesc), _fp]),
-    "carca_sa_block_fwd": (_i, [_fp, _i, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SaWeights), _i, _fp]),
+    "carca_sa_block_fwd": (_i, [_fp, _i, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SaWeights), _i, C.POINTER(SaSave),
+                                _fp]),
     "carca_cross_score_fwd": (_i, [_fp, _i, _fp, _fp, C.POINTER(TargetGroup), _i, _i, _i, _i, _i, _i,
-                                   C.POINTER(CaWeights), _i, _i, _fp]),
+                                   C.POINTER(CaWeights), _i, _i, C.POINTER(CaSave), _fp]),
+    "carca_layernorm_bwd": (_i, [_fp, _i, _fp, _i, _fp, _i, _i, _fp, _i, _fp, _i, _i, _fp, _fp, _fp]),
+    "carca_embed_scatter": (_i, [_fp, _i, _fp, _i, _i, _f, _fp, _fp]),
+    "carca_colsum": (_i, [_fp, _i, _i, _i, _fp, _fp, _i, _fp, _fp]),
+    "carca_sa_attn_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    "carca_cross_attn_bwd": (_i, [_fp, _fp, _fp, C.POINTER(CrossBwdGroup), _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i,
+                                  _fp]),
+    "carca_unpack_grads": (_i, [C.POINTER(PackDesc), _i, _i, _fp]),
     "carca_bce_fwd": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp]),
     "carca_rank_metrics": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),
 }

@@ -1,0 +1,238 @@
+"""torch.autograd glue for the HIP backward pass.
+
+The reference trains with plain torch.autograd over src/carca.py; here one autograd.Function wraps the
+whole CARCA.forward (carca.py:411-431) and its backward is a fixed sequence of C-ABI launches
+(include/carca_hip.h): attention cores (csrc/backward.hip), dense input/weight gradients
+(carca_gemm_rows / carca_gemm_wgrad, csrc/gemm.hip), LayerNorm backward, embedding scatter-add.
+Torch only allocates the buffers, keeps the saved tensors alive and routes the returned gradients.
+Gradients were checked against the reference's own loss.backward() (fixture G2, tests/test_hip_backward.py).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+from torch import Tensor
+
+from . import ops
+from ._lib import CarcaHipError
+
+
+def _zeros_like_params(params):
+    return [torch.zeros_like(p) for p in params]
+
+
+class _Packs:
+    """Transposed / head-padded weight copies and gradient staging buffers of one attention-bearing module."""
+
+    def __init__(self, attn, extra_fwd: List[ops.PackItem], device):
+        d, H = attn.d, attn.H
+        self.d, self.H = d, H
+        self.dpi, self.dhp, self.dpo = ops.padded_dims(d, H)
+        self.dh = d // H
+        hp = (self.dh, self.dhp)
+        # Bt operands of the input-gradient GEMMs: Bt[n = input feature][k = head-padded output feature] = W[k][n]
+        items = [ops.PackItem(m.weight, self.dpi, self.dpo, col_heads=hp, transposed=True)
+                 for m in (attn.WQ, attn.WK, attn.WV)]
+        self.wT = ops.PackedWeights(items + extra_fwd, device)
+        self.wT.pack()
+        # head-padded staging for d WQ/WK/WV [DPO, d] and their biases [DPO]
+        gitems = [ops.PackItem(m.weight, self.dpo, d, row_heads=hp) for m in (attn.WQ, attn.WK, attn.WV)]
+        gitems += [ops.PackItem(m.bias, 1, self.dpo, col_heads=hp) for m in (attn.WQ, attn.WK, attn.WV)]
+        self.g = ops.PackedWeights(gitems, device)
+        self.g.buf.zero_()
+
+
+def _attn_param_grads(packs: _Packs, attn, grads_by_param):
+    real = [grads_by_param[id(m.weight)] for m in (attn.WQ, attn.WK, attn.WV)]
+    real += [grads_by_param[id(m.bias)] for m in (attn.WQ, attn.WK, attn.WV)]
+    packs.g.unpack_into(real, accumulate=True)
+
+
+class _CarcaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, profile, targets, *params):
+        from .modules import AllEmbedding  # noqa: F401
+
+        p_x, p_a, p_c = profile
+        emb, dec = model.embeds, model.decoder
+        d, H = emb.d, dec.attn.H
+        dpi, dhp, dpo = ops.padded_dims(d, H)
+        B, L = p_x.shape
+        c_ = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731  (train.py:86-88 passes split views)
+        segs = [(c_(p_x), c_(p_a), c_(p_c), False)] + [(c_(o_x), c_(o_a), c_(o_c), True) for (o_x, o_a, o_c) in targets]
+        p_x = segs[0][0]
+        es, zq = emb.embed_segments(segs, ld_e=dpi)
+        x = es[0]
+        blocks = []
+        for blk in model.encoder:
+            blk._check_mode()
+            y, saved = ops.sa_block_fwd(x, p_x, blk.weights_struct(x.device), d, blk.attn.H, blk.residual, save=True)
+            saved["x_in"] = x
+            blocks.append(saved)
+            x = y
+        dec._check_mode()
+        groups = [(es[gi + 1], segs[gi + 1][0]) for gi in range(len(targets))]
+        cw = dec.weights_struct(x.device, model.norm)
+        ys, p_normed, csave = ops.cross_score_fwd(x, p_x, groups, cw, d, H, dec.residual, model.training, save=True)
+        ctx.model = model
+        ctx.params = params
+        ctx.st = dict(p_x=p_x, segs=segs, es=es, zq=zq, blocks=blocks, enc_out=x, p_normed=p_normed, csave=csave,
+                      training=model.training, cw=cw, B=B, L=L, ngroups=len(ys))
+        ctx.save_for_backward(*ys)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        model, params, st = ctx.model, ctx.params, ctx.st
+        emb, dec = model.embeds, model.decoder
+        d, H = emb.d, dec.attn.H
+        dpi, dhp, dpo = ops.padded_dims(d, H)
+        dh = d // H
+        B, L = st["B"], st["L"]
+        p_x = st["p_x"]
+        dev = p_x.device
+        grads = _zeros_like_params(params)
+        gbp = {id(p): g for p, g in zip(params, grads)}
+        ys = ctx.saved_tensors
+        ngroups = st["ngroups"]
+        g_feats = emb.feats_embed.weight.shape[0]
+        n_attrs = st["segs"][0][1].shape[-1]
+
+        # ---------------- decoder: sigmoid/ffn head + cross-attention (carca.py:340-347) ----------------
+        cp = _Packs(dec.attn, [], dev)
+        d_wpad = torch.zeros(dpo, dtype=torch.float32, device=dev)
+        bgroups = []
+        for gi in range(ngroups):
+            dy = dys[gi] if dys[gi] is not None else torch.zeros_like(ys[gi])
+            bgroups.append((st["csave"]["qh"][gi], ys[gi], dy.contiguous(), st["segs"][gi + 1][0]))
+        ffn_w_pad_ptr = st["cw"].ffn_w_pad
+        dqhs, dls, dkh, dvh = ops.cross_attn_bwd(st["csave"]["kh"], st["csave"]["vh"], p_x, bgroups, ffn_w_pad_ptr,
+                                                 d_wpad, B, L, d, H, st["training"])
+        g_ffn_w, g_ffn_b = gbp[id(dec.ffn.weight)], gbp[id(dec.ffn.bias)]
+        o_rows = [st["es"][gi + 1].view(-1, dpi) for gi in range(ngroups)]
+        o_ids = [st["segs"][gi + 1][0] for gi in range(ngroups)]
+        for gi in range(ngroups):
+            ops.colsum(dls[gi].view(-1, 1), 1, g_ffn_b)                       # d ffn.bias = sum dlogit
+            if dec.residual:
+                ops.colsum(o_rows[gi], d, g_ffn_w, rowscale=dls[gi])          # residual part of d ffn.weight
+        wp_item = ops.PackedWeights([ops.PackItem(dec.ffn.weight, 1, dpo, col_heads=(dh, dhp))], dev)
+        wp_item.buf.copy_(d_wpad)                                             # attention part, head-padded
+        wp_item.unpack_into([g_ffn_w], accumulate=True)
+        # d o_g = dQ_g . W_Q (+ dlogit (x) w), masked like e * mask (carca.py:94)
+        wq_t, wk_t, wv_t = cp.wT.view(0), cp.wT.view(1), cp.wT.view(2)
+        ffn_w_plain = dec.ffn.weight.detach().reshape(-1)
+        des_t = ops.gemm_rows([dict(a0=dqhs[gi], rowscale=dls[gi] if dec.residual else None, ids=o_ids[gi])
+                               for gi in range(ngroups)], wq_t, d, dpo, dpi,
+                              colvec=ffn_w_plain if dec.residual else None, mask_rows=True)
+        ops.gemm_wgrad([dict(dy=dqhs[gi], x=o_rows[gi]) for gi in range(ngroups)], dpo, d, cp.g.view(0),
+                       cp.g.view(3).view(-1))
+        pn = st["p_normed"].view(-1, st["p_normed"].shape[-1])
+        ops.gemm_wgrad([dict(dy=dkh, x=pn)], dpo, d, cp.g.view(1), cp.g.view(4).view(-1))
+        ops.gemm_wgrad([dict(dy=dvh, x=pn)], dpo, d, cp.g.view(2), cp.g.view(5).view(-1))
+        _attn_param_grads(cp, dec.attn, gbp)
+        (dp,) = ops.gemm_rows([dict(a0=dkh, a1=dvh)], wk_t, d, dpo, dpi, bt1=wv_t, K1=dpo)
+        # final LayerNorm (carca.py:421)
+        enc_out = st["enc_out"].view(-1, dpi)
+        dx = ops.layernorm_bwd(dp, enc_out, model.norm.weight.detach(), d, dpi, dgamma=gbp[id(model.norm.weight)],
+                               dbeta=gbp[id(model.norm.bias)])
+
+        # ---------------- encoder blocks, last to first (carca.py:297-318) --------------------------------
+        for blk, sv in zip(reversed(list(model.encoder)), reversed(st["blocks"])):
+            extra = [ops.PackItem(blk.ffn_1.weight[:, :, 0], dpi, dpi, transposed=True),
+                     ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi, dpi, transposed=True)]
+            bp = _Packs(blk.attn, extra, dev)
+            w1_t, w2_t = bp.wT.view(3), bp.wT.view(4)
+            x_in = sv["x_in"].view(-1, dpi)
+            dy = dx
+            # f = ffn_2(lrelu(ffn_1(s))) (+ s)
+            (dh1pre,) = ops.gemm_rows([dict(a0=dy, gate=sv["h1"])], w2_t, d, d, dpi, gate_slope=0.01)
+            ops.gemm_wgrad([dict(dy=dy, x=sv["h1"])], d, d, gbp[id(blk.ffn_2.weight)].view(d, d),
+                           gbp[id(blk.ffn_2.bias)])
+            (ds,) = ops.gemm_rows([dict(a0=dh1pre, add=dy if blk.residual else None)], w1_t, d, d, dpi)
+            ops.gemm_wgrad([dict(dy=dh1pre, x=sv["s2"])], d, d, gbp[id(blk.ffn_1.weight)].view(d, d),
+                           gbp[id(blk.ffn_1.bias)])
+            # s = LayerNorm2(r), r = attention (+ q)
+            dr = ops.layernorm_bwd(ds, sv["r"], blk.norm2.weight.detach(), d, dpi, dgamma=gbp[id(blk.norm2.weight)],
+                                   dbeta=gbp[id(blk.norm2.bias)])
+            dqh, dkh_b, dvh_b = ops.sa_attn_bwd(sv["qh"], sv["kh"], sv["vh"], dr, p_x, B, L, d, blk.attn.H)
+            bq_t, bk_t, bv_t = bp.wT.view(0), bp.wT.view(1), bp.wT.view(2)
+            (dqn,) = ops.gemm_rows([dict(a0=dqh, add=dr if blk.residual else None)], bq_t, d, dpo, dpi)
+            (dx_kv,) = ops.gemm_rows([dict(a0=dkh_b, a1=dvh_b)], bk_t, d, dpo, dpi, bt1=bv_t, K1=dpo)
+            ops.gemm_wgrad([dict(dy=dqh, x=sv["qn"])], dpo, d, bp.g.view(0), bp.g.view(3).view(-1))
+            ops.gemm_wgrad([dict(dy=dkh_b, x=x_in)], dpo, d, bp.g.view(1), bp.g.view(4).view(-1))
+            ops.gemm_wgrad([dict(dy=dvh_b, x=x_in)], dpo, d, bp.g.view(2), bp.g.view(5).view(-1))
+            _attn_param_grads(bp, blk.attn, gbp)
+            # q = LayerNorm1(x); K, V from x itself
+            dx = ops.layernorm_bwd(dqn, x_in, blk.norm1.weight.detach(), d, dpi, addend=dx_kv,
+                                   dgamma=gbp[id(blk.norm1.weight)], dbeta=gbp[id(blk.norm1.bias)])
+
+        # ---------------- embedding (carca.py:85-95) ---------------------------------------------------
+        des = [dx] + des_t                      # d e per segment, [rows, dpi]; profile rows still unmasked
+        ids_seg = [s[0] for s in st["segs"]]
+        nseg = len(des)
+        row0 = [0]
+        for s in st["segs"]:
+            row0.append(row0[-1] + s[0].numel())
+        zq = st["zq"]
+        zq_seg = [zq[row0[i]: row0[i + 1]] for i in range(nseg)]
+        # positional table (learnable encoding only; carca.py:25-31)
+        enc = emb.enc
+        if hasattr(enc, "encoding"):
+            ops.colsum(des[0], d, gbp[id(enc.encoding.weight)], ids=ids_seg[0], T=L)
+        g_joint_w, g_joint_b = gbp[id(emb.joint_embed.weight)], gbp[id(emb.joint_embed.bias)]
+        ops.gemm_wgrad([dict(dy=des[i], x=zq_seg[i], ids=ids_seg[i]) for i in range(nseg)], d, d + g_feats, g_joint_w,
+                       g_joint_b, mask_rows=True)
+        wj_t = ops.PackedWeights([ops.PackItem(emb.joint_embed.weight, d + g_feats, dpi, transposed=True)], dev)
+        wj_t.pack()
+        dzq = ops.gemm_rows([dict(a0=des[i], ids=ids_seg[i]) for i in range(nseg)], wj_t.view(0), d + g_feats, d,
+                            d + g_feats, mask_rows=True)
+        g_items = gbp[id(emb.items_embed.weight)]
+        for i in range(nseg):
+            ops.embed_scatter(dzq[i], ids_seg[i], d, float(d) ** 0.5, g_items)
+        g_feats_w, g_feats_b = gbp[id(emb.feats_embed.weight)], gbp[id(emb.feats_embed.bias)]
+        ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x=st["segs"][i][1].view(-1, n_attrs)) for i in range(nseg)], g_feats,
+                       n_attrs, g_feats_w[:, :n_attrs], g_feats_b)
+        n_ctx = st["segs"][0][2].shape[-1]
+        if n_ctx > 0:
+            ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x=st["segs"][i][2].view(-1, n_ctx)) for i in range(nseg)], g_feats,
+                           n_ctx, g_feats_w[:, n_attrs:], None)
+        ctx.st = None
+        return (None, None, None) + tuple(grads)
+
+
+def carca_forward_with_grad(model, profile, targets) -> List[Tensor]:
+    params = [p for p in model.parameters()]
+    if any(t.requires_grad for t in profile) or any(t.requires_grad for grp in targets for t in grp):
+        raise CarcaHipError("gradients with respect to the input tensors (ids/attrs/ctx) are not produced")
+    return list(_CarcaFn.apply(model, tuple(profile), [tuple(g) for g in targets], *params))
+
+
+class _BceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_pred, y_true, ids_mask, eps):
+        loss, dy = ops.bce_fwd(y_pred.detach(), y_true, ids_mask, eps, want_grad=True)
+        ctx.save_for_backward(dy)
+        ctx.shape = y_pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dy,) = ctx.saved_tensors
+        return dy.view(ctx.shape) * g, None, None, None
+
+
+def bce_with_grad(y_pred, y_true, mask, eps):
+    return _BceFn.apply(y_pred, y_true, mask != 0, eps)
+
+
+def embed_with_grad(module, x, a, c, target):
+    raise CarcaHipError("training through a stand-alone AllEmbedding is not built; train through CARCA.forward")
+
+
+def sa_block_with_grad(module, x, mask):
+    raise CarcaHipError("training through a stand-alone SelfAttentionBlock is not built; train through CARCA.forward")
+
+
+def cross_with_grad(module, o, o_mask, p, p_mask):
+    raise CarcaHipError("training through a stand-alone CrossAttentionBlock is not built; train through CARCA.forward")

@@ -42,18 +42,51 @@ __global__ void pack_kernel(const PackArgs pa) {
     const int r = ds.row_dh > 0 ? unpad_feature(rp, ds.row_dh, ds.row_dhp) : rp;
     const int c = ds.col_dh > 0 ? unpad_feature(cp, ds.col_dh, ds.col_dhp) : cp;
     float v = 0.f;
-    if (r >= 0 && r < ds.rows && c >= 0 && c < ds.cols) v = ds.src[(size_t)r * ds.src_ld + c];
+    if (r >= 0 && r < ds.rows && c >= 0 && c < ds.cols)
+      v = ds.transposed ? ds.src[(size_t)c * ds.src_ld + r] : ds.src[(size_t)r * ds.src_ld + c];
     ds.dst[i] = v;
   }
 }
+// gradients travel the other way: real[r][c] (+)= packed[pad(r)][pad(c)]
+__global__ void unpack_kernel(const PackArgs pa, int accumulate) {
+  const CarcaPackDesc& ds = pa.d[blockIdx.y];
+  const int total = ds.rows * ds.cols;
+  float* real = const_cast<float*>(ds.src);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / ds.cols, c = i - r * ds.cols;
+    const int rp = ds.row_dh > 0 ? (r / ds.row_dh) * ds.row_dhp + r % ds.row_dh : r;
+    const int cp = ds.col_dh > 0 ? (c / ds.col_dh) * ds.col_dhp + c % ds.col_dh : c;
+    const float v = ds.dst[(size_t)rp * ds.dst_cols + cp];
+    float* q = ds.transposed ? &real[(size_t)c * ds.src_ld + r] : &real[(size_t)r * ds.src_ld + c];
+    *q = accumulate ? *q + v : v;
+  }
+}
 }  // namespace
+
+extern "C" int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(descs && n >= 1, "unpack_grads: no descriptors");
+  for (int i = 0; i < n; ++i) {
+    const CarcaPackDesc& d = descs[i];
+    CARCA_CHECK_ARG(d.src && d.dst && d.rows >= 1 && d.cols >= 1 && d.dst_rows >= 1 && d.dst_cols >= 1,
+                    "unpack_grads: descriptor %d malformed", i);
+  }
+  for (int base = 0; base < n; base += PACK_CHUNK) {
+    PackArgs pa{};
+    const int m = min(PACK_CHUNK, n - base);
+    for (int i = 0; i < m; ++i) pa.d[i] = descs[base + i];
+    hipLaunchKernelGGL(unpack_kernel, dim3(8, m), dim3(256), 0, stream, pa, accumulate);
+    CARCA_LAUNCH_CHECK();
+  }
+  return CARCA_OK;
+}
 
 extern "C" int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(descs && n >= 1, "pack_weights: no descriptors");
   for (int i = 0; i < n; ++i) {
     const CarcaPackDesc& d = descs[i];
-    CARCA_CHECK_ARG(d.src && d.dst && d.rows >= 1 && d.cols >= 1 && d.src_ld >= d.cols && d.dst_rows >= 1 &&
+    CARCA_CHECK_ARG(d.src && d.dst && d.rows >= 1 && d.cols >= 1 && d.src_ld >= (d.transposed ? d.rows : d.cols) && d.dst_rows >= 1 &&
                         d.dst_cols >= 1,
                     "pack_weights: descriptor %d malformed", i);
     CARCA_CHECK_ARG((d.row_dh == 0) == (d.row_dhp == 0) && (d.col_dh == 0) == (d.col_dhp == 0) &&

@@ -51,15 +51,18 @@ __device__ __forceinline__ void row_layernorm(float& v0, float& v1, int lane, in
 template <int DPI>
 __device__ __forceinline__ void proj_tile_feat_major(const float* __restrict__ Wp, const float* __restrict__ bp,
                                                      const float* xs, int si, float* out, int so, int ft, int st,
-                                                     int lane) {
+                                                     int lane, float* __restrict__ save = nullptr, int dpo = 0,
+                                                     int L = 0) {
   const int ln = lane & 15, mq = lane >> 4;
   const float* wrow = Wp + (size_t)(16 * ft + ln) * DPI + 4 * mq;
   const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
   f32x4 acc = zero4();
 #pragma unroll
   for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(glb4(wrow + 16 * kg), lds4(xrow + 16 * kg), acc);
-  const f32x4 bias = glb4(bp + 16 * ft + 4 * mq);
-  *reinterpret_cast<f32x4*>(out + (16 * st + ln) * so + 16 * ft + 4 * mq) = acc + bias;
+  acc = acc + glb4(bp + 16 * ft + 4 * mq);
+  *reinterpret_cast<f32x4*>(out + (16 * st + ln) * so + 16 * ft + 4 * mq) = acc;
+  if (save && 16 * st + ln < L)  // [slot][head-padded feature], saved for backward
+    *reinterpret_cast<f32x4*>(save + (size_t)(16 * st + ln) * dpo + 16 * ft + 4 * mq) = acc;
 }
 
 // V^T-style projection tile: out[16ft + n][16st + 4mq + r] = sum_k X[16st + 4mq + r][k] W[16ft + n][k] + bias[16ft+n]
@@ -67,7 +70,8 @@ __device__ __forceinline__ void proj_tile_feat_major(const float* __restrict__ W
 template <int DPI>
 __device__ __forceinline__ void proj_tile_slot_major(const float* __restrict__ Wp, const float* __restrict__ bp,
                                                      const float* xs, int si, float* out, int sk, int ft, int st,
-                                                     int lane) {
+                                                     int lane, float* __restrict__ save = nullptr, int dpo = 0,
+                                                     int L = 0) {
   const int ln = lane & 15, mq = lane >> 4;
   const float* wrow = Wp + (size_t)(16 * ft + ln) * DPI + 4 * mq;
   const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
@@ -77,6 +81,11 @@ __device__ __forceinline__ void proj_tile_slot_major(const float* __restrict__ W
   const float bias = bp[16 * ft + ln];
   f32x4 o = {acc[0] + bias, acc[1] + bias, acc[2] + bias, acc[3] + bias};
   *reinterpret_cast<f32x4*>(out + (16 * ft + ln) * sk + 16 * st + 4 * mq) = o;
+  if (save) {  // [slot][head-padded feature]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * st + 4 * mq + r < L) save[(size_t)(16 * st + 4 * mq + r) * dpo + 16 * ft + ln] = o[r];
+  }
 }
 
 // One head of attention for a 16-query tile, everything in registers.
@@ -90,7 +99,8 @@ template <int DPI, int DHP, int NH>
 __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], const float* __restrict__ wq,
                                             const float* __restrict__ bq, const float* Ks, const float* Vt, int h,
                                             int nkt, unsigned okbits, float sqrt_dh,
-                                            f32x4 (&o)[DHP / 16], f32x4 (&p)[ATT_LT], int lane) {
+                                            f32x4 (&o)[DHP / 16], f32x4 (&p)[ATT_LT], int lane,
+                                            float* __restrict__ qh_row = nullptr) {
   using G = AttGeom<DPI, DHP, NH>;
   const int ln = lane & 15, mq = lane >> 4;
   // Q^T tiles of this head
@@ -102,6 +112,7 @@ __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], cons
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(glb4(wrow + 16 * kg), qfrag[kg], acc);
     qt[ft] = acc + glb4(bq + h * DHP + 16 * ft + 4 * mq);
+    if (qh_row) *reinterpret_cast<f32x4*>(qh_row + h * DHP + 16 * ft + 4 * mq) = qt[ft];  // saved for backward
   }
   // scores^T tiles: rows = keys, cols = queries
 #pragma unroll

@@ -1,0 +1,596 @@
+// Backward-pass kernels that are not plain GEMMs (those are carca_gemm_rows / carca_gemm_wgrad):
+//   carca_layernorm_bwd     nn.LayerNorm backward (the autograd of carca.py:298,304,421)
+//   carca_embed_scatter     gradient of nn.Embedding(padding_idx=0) * sqrt(d)  (carca.py:87-88)
+//   carca_colsum            (weighted, masked, position-folded) column sums: dpos, d ffn.weight, ...
+//   carca_sa_attn_bwd       attention core of MultiHeadAttention (carca.py:246-260) inside SelfAttentionBlock
+//   carca_cross_attn_bwd    same inside CrossAttentionBlock + sigmoid/ffn head (carca.py:340-347)
+// The reference has no hand-written backward: it is torch.autograd over those lines; the formulas
+// below are their derivatives, checked against the reference's own parameter gradients (fixture G2).
+#include "attn_common.h"
+#include "../../include/carca_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row, two columns per lane (d <= 128)
+//   xh = (x - mean) * rstd ; g = dy * gamma ; dx = rstd * (g - mean(g) - xh * mean(g * xh)) (+ addend)
+//   dgamma += dy * xh ; dbeta += dy    (per-block partial sums, then one atomic per column)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int ld_dy,
+                                                            const float* __restrict__ x, int ld_x,
+                                                            const float* __restrict__ gamma, int rows, int d,
+                                                            const float* __restrict__ addend, int ld_add,
+                                                            float* __restrict__ dx, int ld_dx, int ncols_out,
+                                                            float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  __shared__ float red[2][4][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = lane, c1 = lane + 64;
+  const bool ok0 = c0 < d, ok1 = c1 < d;
+  const float g0 = ok0 ? gamma[c0] : 0.f, g1 = ok1 ? gamma[c1] : 0.f;
+  const float inv_d = 1.0f / (float)d;
+  float dg0 = 0.f, dg1 = 0.f, db0 = 0.f, db1 = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * ld_x;
+    const float* dr = dy + (size_t)row * ld_dy;
+    const float x0 = ok0 ? xr[c0] : 0.f, x1 = ok1 ? xr[c1] : 0.f;
+    const float y0 = ok0 ? dr[c0] : 0.f, y1 = ok1 ? dr[c1] : 0.f;
+    const float mean = wave_sum(x0 + x1) * inv_d;
+    const float e0 = ok0 ? x0 - mean : 0.f, e1 = ok1 ? x1 - mean : 0.f;
+    const float rstd = 1.0f / sqrtf(wave_sum(e0 * e0 + e1 * e1) * inv_d + 1e-5f);
+    const float h0 = e0 * rstd, h1 = e1 * rstd;
+    const float a0 = y0 * g0, a1 = y1 * g1;
+    const float m1 = wave_sum(a0 + a1) * inv_d;
+    const float m2 = wave_sum(a0 * h0 + a1 * h1) * inv_d;
+    float o0 = rstd * (a0 - m1 - h0 * m2), o1 = rstd * (a1 - m1 - h1 * m2);
+    if (addend) {
+      const float* ar = addend + (size_t)row * ld_add;
+      if (ok0) o0 += ar[c0];
+      if (ok1) o1 += ar[c1];
+    }
+    dg0 += y0 * h0;
+    dg1 += y1 * h1;
+    db0 += y0;
+    db1 += y1;
+    float* outr = dx + (size_t)row * ld_dx;
+    {
+      if (c0 < ncols_out) outr[c0] = ok0 ? o0 : 0.f;
+      if (c1 < ncols_out) outr[c1] = ok1 ? o1 : 0.f;
+    }
+  }
+  if (dgamma) {
+    red[0][wave][c0] = dg0;
+    red[0][wave][c1] = dg1;
+    red[1][wave][c0] = db0;
+    red[1][wave][c1] = db1;
+    __syncthreads();
+    if (tid < 128 && tid < d) {
+      const float sg = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
+      const float sb = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
+      atomicAdd(&dgamma[tid], sg);
+      atomicAdd(&dbeta[tid], sb);
+    }
+  }
+}
+
+// d_items[ids[r]][c] += scale * dz[r][c] for ids[r] != 0 (padding_idx = 0 gets no gradient)
+__global__ void embed_scatter_kernel(const float* __restrict__ dz, int ld_dz, const int32_t* __restrict__ ids,
+                                     int rows, int d, float scale, float* __restrict__ d_items) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int row = wave; row < rows; row += nwaves) {
+    const int id = ids[row];
+    if (id == 0) continue;
+    const float* src = dz + (size_t)row * ld_dz;
+    float* dst = d_items + (size_t)id * d;
+    for (int c = lane; c < d; c += 64) atomicAdd(&dst[c], scale * src[c]);
+  }
+}
+
+// out[(row % T)][c] += sum over this block's rows of  w(row) * x[row][c],  w = rowscale * (ids != 0)
+// grid.x blocks of 256 threads; thread = column (cols <= 256), rows strided by block
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld_x, int rows, int cols,
+                                                     const float* __restrict__ rowscale,
+                                                     const int32_t* __restrict__ ids, int T,
+                                                     float* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= cols) return;
+  if (T == 1) {
+    float s = 0.f;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+      float w = rowscale ? rowscale[row] : 1.f;
+      if (ids && ids[row] == 0) w = 0.f;
+      s += w * x[(size_t)row * ld_x + c];
+    }
+    atomicAdd(&out[c], s);
+  } else {
+    // one block per position t (grid.x == T): rows t, t+T, t+2T, ...
+    const int t = blockIdx.x;
+    float s = 0.f;
+    for (int row = t; row < rows; row += T) {
+      float w = rowscale ? rowscale[row] : 1.f;
+      if (ids && ids[row] == 0) w = 0.f;
+      s += w * x[(size_t)row * ld_x + c];
+    }
+    atomicAdd(&out[(size_t)t * cols + c], s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// attention backward
+// ---------------------------------------------------------------------------------------------------
+#define ATT_SP 72  // row stride of the [key][query] probability / dS images (64 + 8)
+
+// scale + masked softmax of a lane's score registers (same arithmetic as attend_head)
+__device__ __forceinline__ void masked_softmax(f32x4 (&p)[ATT_LT], unsigned okbits, float sqrt_dh) {
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (okbits >> (4 * kt + r)) & 1u;
+      const float sc = p[kt][r] / sqrt_dh;
+      p[kt][r] = sc;
+      mx = ok ? fmaxf(mx, sc) : mx;
+    }
+  mx = quad4_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (okbits >> (4 * kt + r)) & 1u;
+      const float e = ok ? expf(p[kt][r] - mx) : 0.f;
+      p[kt][r] = e;
+      sum += e;
+    }
+  sum = quad4_sum(sum);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt) p[kt] = p[kt] * inv;
+}
+
+// Phase 1 of one (16-query tile, head): recompute P, form dS, emit dQ, park P^T and dS^T in LDS.
+//   dofrag(ft) must return the lane's Bt fragment of dO: dO[q][hDHP + 16ft + 4mq + 0..3]
+//   returns p (probabilities) so that the cross kernel can also form O.
+template <int DHP, int SO, typename DoFrag>
+__device__ __forceinline__ void attn_bwd_phase1(const float* Qs, const float* Ks, const float* __restrict__ vh_user,
+                                                int L, int dpo, int h, int qrow, int qcol, int nkt, unsigned okbits,
+                                                float sqrt_dh, DoFrag dofrag, float* PT, float* DST,
+                                                float* __restrict__ dq_row, f32x4 (&p)[ATT_LT], int lane) {
+  constexpr int NFH = DHP / 16;
+  const int ln = lane & 15, mq = lane >> 4;
+  f32x4 qf[NFH], dof[NFH];
+#pragma unroll
+  for (int ft = 0; ft < NFH; ++ft) {
+    qf[ft] = lds4(Qs + qrow * SO + h * DHP + 16 * ft + 4 * mq);
+    dof[ft] = dofrag(ft);
+  }
+  f32x4 dp[ATT_LT];
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt) {
+    p[kt] = zero4();
+    dp[kt] = zero4();
+    if (kt < nkt) {
+      const float* krow = Ks + (16 * kt + ln) * SO + h * DHP + 4 * mq;
+      const int vr = min(16 * kt + ln, L - 1);
+      const float* vrow = vh_user + (size_t)vr * dpo + h * DHP + 4 * mq;
+      f32x4 s = zero4(), t = zero4();
+#pragma unroll
+      for (int ft = 0; ft < NFH; ++ft) {
+        s = mfma16_group(lds4(krow + 16 * ft), qf[ft], s);    // S^T[key][q]
+        t = mfma16_group(glb4(vrow + 16 * ft), dof[ft], t);   // dP^T[key][q] = V[key] . dO[q]
+      }
+      p[kt] = s;
+      dp[kt] = t;
+    }
+  }
+  masked_softmax(p, okbits, sqrt_dh);
+  float dot = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dot += p[kt][r] * dp[kt][r];
+  dot = quad4_sum(dot);
+  f32x4 ds[ATT_LT];
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ds[kt][r] = p[kt][r] * (dp[kt][r] - dot) / sqrt_dh;
+  // dQ^T[f][q] = sum_key K[key][f] dS^T[key][q]   (A read transposed: one ds_read_b32 per step)
+#pragma unroll
+  for (int ft = 0; ft < NFH; ++ft) {
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int kt = 0; kt < ATT_LT; ++kt)
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc = mfma16(Ks[(16 * kt + 4 * mq + r) * SO + h * DHP + 16 * ft + ln], ds[kt][r], acc);
+      }
+    if (dq_row) *reinterpret_cast<f32x4*>(dq_row + h * DHP + 16 * ft + 4 * mq) = acc;
+  }
+#pragma unroll
+  for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      PT[(16 * kt + 4 * mq + r) * ATT_SP + qcol] = p[kt][r];
+      DST[(16 * kt + 4 * mq + r) * ATT_SP + qcol] = ds[kt][r];
+    }
+}
+
+// Phase 2 tile: out[key][f] = sum_q  M[key][q] * R[q][f]   (M = DST -> dK with R = Q ; M = PT -> dV with R = dO)
+//   rfrag(qt, s) must return R[16qt + 4mq + s][hDHP + 16ft + ln]  (the transposed Bt operand)
+template <typename RFrag>
+__device__ __forceinline__ f32x4 attn_bwd_phase2_tile(const float* M, int kt, int qt_begin, int qt_end, RFrag rfrag,
+                                                      int lane) {
+  const int ln = lane & 15, mq = lane >> 4;
+  f32x4 acc = zero4();
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    const f32x4 a = lds4(M + (16 * kt + ln) * ATT_SP + 16 * qt + 4 * mq);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma16(a[s], rfrag(qt, s), acc);
+  }
+  return acc;
+}
+
+// ---- SelfAttentionBlock's attention core --------------------------------------------------------------
+template <int DPI, int DHP, int NH>
+__global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restrict__ qh, const float* __restrict__ kh,
+                                                          const float* __restrict__ vh,
+                                                          const float* __restrict__ d_attn /*[B*L, ld] plain*/,
+                                                          int ld_da, const int32_t* __restrict__ ids,
+                                                          float* __restrict__ dqh, float* __restrict__ dkh,
+                                                          float* __restrict__ dvh, int L, int dh) {
+  using G = AttGeom<DPI, DHP, NH>;
+  constexpr int SO = G::SO, DPO = G::DPO, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Qs = lds;                  // [64][SO]
+  float* Ks = Qs + ATT_LMAX * SO;   // [64][SO]
+  float* Os = Ks + ATT_LMAX * SO;   // [64][SO]  dO
+  float* PT = Os + ATT_LMAX * SO;   // [64][ATT_SP]
+  float* DST = PT + ATT_LMAX * ATT_SP;
+
+  const int u = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int LT = (L + 15) >> 4;
+  const int32_t* uid = ids + (size_t)u * L;
+  const unsigned long long pmask = __ballot(lane < L && uid[lane < L ? lane : 0] != 0);
+  const size_t ubase = (size_t)u * L;
+
+  // ---- load Q, K, dO rows (16 B per thread, coalesced) ----------------------------------------------
+  constexpr int V4 = DPO / 4;
+  for (int i = tid; i < 16 * LT * V4; i += 512) {
+    const int r = i / V4, c4 = i - r * V4;
+    f32x4 q = zero4(), k = zero4(), o = zero4();
+    if (r < L) {
+      const size_t off = (ubase + r) * DPO + 4 * c4;
+      q = glb4(qh + off);
+      k = glb4(kh + off);
+      const float* dar = d_attn + (ubase + r) * ld_da;  // plain feature order -> head-padded order
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = unpad_feature(4 * c4 + e, dh, DHP);
+        o[e] = j >= 0 ? dar[j] : 0.f;
+      }
+    }
+    *reinterpret_cast<f32x4*>(Qs + r * SO + 4 * c4) = q;
+    *reinterpret_cast<f32x4*>(Ks + r * SO + 4 * c4) = k;
+    *reinterpret_cast<f32x4*>(Os + r * SO + 4 * c4) = o;
+  }
+  __syncthreads();
+
+  const float sqrt_dh = sqrtf((float)dh);
+  const int ln = lane & 15, mq = lane >> 4;
+  const float* vh_user = vh + ubase * DPO;
+#pragma unroll 1
+  for (int h = 0; h < NH; ++h) {
+    for (int qt = wave; qt < LT; qt += NW) {
+      const int q = 16 * qt + ln;
+      const bool q_ok = (pmask >> q) & 1ull;
+      unsigned okbits = 0;
+#pragma unroll
+      for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * mq + r;
+          okbits |= ((q_ok && key <= q && ((pmask >> key) & 1ull)) ? 1u : 0u) << (4 * kt + r);
+        }
+      f32x4 p[ATT_LT];
+      auto dofrag = [&](int ft) { return lds4(Os + q * SO + h * DHP + 16 * ft + 4 * mq); };
+      float* dq_row = q < L ? dqh + (ubase + q) * DPO : nullptr;
+      attn_bwd_phase1<DHP, SO>(Qs, Ks, vh_user, L, DPO, h, q, q, qt + 1, okbits, sqrt_dh, dofrag, PT, DST, dq_row, p,
+                               lane);
+    }
+    __syncthreads();
+    // dK / dV tiles: job = (which, kt, ft); queries that can see key tile kt are tiles qt >= kt
+    const int njobs = 2 * LT * G::NFH;
+    for (int job = wave; job < njobs; job += NW) {
+      const int which = job / (LT * G::NFH);
+      const int jj = job - which * LT * G::NFH;
+      const int kt = jj / G::NFH, ft = jj - kt * G::NFH;
+      const float* R = which == 0 ? Qs : Os;
+      auto rfrag = [&](int qt, int s) { return R[(16 * qt + 4 * mq + s) * SO + h * DHP + 16 * ft + ln]; };
+      const f32x4 acc = attn_bwd_phase2_tile(which == 0 ? DST : PT, kt, kt, LT, rfrag, lane);
+      float* out = which == 0 ? dkh : dvh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * mq + r;
+        if (key < L) out[(ubase + key) * DPO + h * DHP + 16 * ft + ln] = acc[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- CrossAttentionBlock's attention core + scoring head ------------------------------------------------
+struct CrossBwdGroups {
+  CarcaCrossBwdGroup g[CARCA_MAX_GROUPS];
+  int n;
+};
+
+template <int DPI, int DHP, int NH>
+__global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __restrict__ kh,
+                                                             const float* __restrict__ vh,
+                                                             const int32_t* __restrict__ p_ids,
+                                                             const CrossBwdGroups groups,
+                                                             const float* __restrict__ ffn_w_pad,
+                                                             float* __restrict__ dkh, float* __restrict__ dvh,
+                                                             float* __restrict__ d_ffn_w_pad, int L, int dh,
+                                                             int training) {
+  using G = AttGeom<DPI, DHP, NH>;
+  constexpr int SO = G::SO, DPO = G::DPO, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Qs = lds;                       // [64][SO] one chunk of <= 64 targets
+  float* Ks = Qs + ATT_LMAX * SO;        // [64][SO]
+  float* PT = Ks + ATT_LMAX * SO;        // [64][ATT_SP]
+  float* DST = PT + ATT_LMAX * ATT_SP;   // [64][ATT_SP]
+  float* dls = DST + ATT_LMAX * ATT_SP;  // [64] dlogit of the chunk
+  float* wps = dls + 64;                 // [DPO] ffn weight, head-padded
+  float* dwp = wps + DPO;                // [DPO] its gradient, accumulated over the user's targets
+
+  const int u = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int LT = (L + 15) >> 4;
+  const int32_t* uid = p_ids + (size_t)u * L;
+  const unsigned long long pmask = __ballot(lane < L && uid[lane < L ? lane : 0] != 0);
+  const size_t ubase = (size_t)u * L;
+  constexpr int V4 = DPO / 4;
+
+  for (int i = tid; i < 16 * LT * V4; i += 512) {
+    const int r = i / V4, c4 = i - r * V4;
+    f32x4 k = zero4();
+    if (r < L) k = glb4(kh + (ubase + r) * DPO + 4 * c4);
+    *reinterpret_cast<f32x4*>(Ks + r * SO + 4 * c4) = k;
+  }
+  for (int i = tid; i < DPO; i += 512) {
+    wps[i] = ffn_w_pad[i];
+    dwp[i] = 0.f;
+  }
+
+  const float sqrt_dh = sqrtf((float)dh);
+  const int ln = lane & 15, mq = lane >> 4;
+  const float* vh_user = vh + ubase * DPO;
+  bool first_pass = true;
+  for (int gi = 0; gi < groups.n; ++gi) {
+    const CarcaCrossBwdGroup grp = groups.g[gi];
+    for (int n0 = 0; n0 < grp.N; n0 += 64) {
+      const int nq = min(64, grp.N - n0), QT = (nq + 15) >> 4;
+      const size_t gbase = (size_t)u * grp.N + n0;
+      __syncthreads();  // previous chunk's phase 2 is done with Qs / dls
+      for (int i = tid; i < 16 * QT * V4; i += 512) {
+        const int r = i / V4, c4 = i - r * V4;
+        f32x4 q = zero4();
+        if (r < nq) q = glb4(grp.qh + (gbase + r) * DPO + 4 * c4);
+        *reinterpret_cast<f32x4*>(Qs + r * SO + 4 * c4) = q;
+      }
+      if (tid < 64) {
+        float dl = 0.f;
+        if (tid < nq) {
+          const float yv = grp.y[gbase + tid];
+          dl = grp.dy[gbase + tid] * yv * (1.0f - yv);  // d sigmoid
+          if (grp.dlogit) grp.dlogit[gbase + tid] = dl;
+        }
+        dls[tid] = dl;
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int h = 0; h < NH; ++h) {
+        for (int qt = wave; qt < QT; qt += NW) {
+          const int qloc = 16 * qt + ln;      // row in the chunk
+          const int nslot = n0 + qloc;        // target slot in the group
+          const bool in_range = qloc < nq;
+          const bool q_ok = in_range && grp.ids[gbase + (in_range ? qloc : 0)] != 0;
+          unsigned okbits = 0;
+#pragma unroll
+          for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = 16 * kt + 4 * mq + r;
+              const bool ok = q_ok && ((pmask >> key) & 1ull) && (!training || key < nslot);
+              okbits |= (ok ? 1u : 0u) << (4 * kt + r);
+            }
+          const int nkt = training ? min(LT, (n0 >> 4) + qt + 1) : LT;
+          const float dl = dls[qloc];
+          f32x4 p[ATT_LT];
+          auto dofrag = [&](int ft) { return lds4(wps + h * DHP + 16 * ft + 4 * mq) * dl; };  // dO = dl (x) w_pad
+          float* dq_row = in_range ? grp.dqh + (gbase + qloc) * DPO : nullptr;
+          attn_bwd_phase1<DHP, SO>(Qs, Ks, vh_user, L, DPO, h, qloc, qloc, nkt, okbits, sqrt_dh, dofrag, PT, DST,
+                                   dq_row, p, lane);
+          // d w_pad[f] += sum_q dl[q] * O[q][f],  O^T[f][q] = sum_key V[key][f] P^T[key][q]
+#pragma unroll
+          for (int ft = 0; ft < G::NFH; ++ft) {
+            f32x4 acc = zero4();
+#pragma unroll
+            for (int kt = 0; kt < ATT_LT; ++kt)
+              if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int vr = min(16 * kt + 4 * mq + r, L - 1);
+                  acc = mfma16(vh_user[(size_t)vr * DPO + h * DHP + 16 * ft + ln], p[kt][r], acc);
+                }
+              }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = acc[r] * dl;
+              v += __shfl_xor(v, 1, 64);
+              v += __shfl_xor(v, 2, 64);
+              v += __shfl_xor(v, 4, 64);
+              v += __shfl_xor(v, 8, 64);
+              if (ln == 0) atomicAdd(&dwp[h * DHP + 16 * ft + 4 * mq + r], v);
+            }
+          }
+        }
+        __syncthreads();
+        const int njobs = 2 * LT * G::NFH;
+        for (int job = wave; job < njobs; job += NW) {
+          const int which = job / (LT * G::NFH);
+          const int jj = job - which * LT * G::NFH;
+          const int kt = jj / G::NFH, ft = jj - kt * G::NFH;
+          f32x4 acc;
+          if (which == 0) {
+            auto rfrag = [&](int qt, int s) { return Qs[(16 * qt + 4 * mq + s) * SO + h * DHP + 16 * ft + ln]; };
+            acc = attn_bwd_phase2_tile(DST, kt, 0, QT, rfrag, lane);
+          } else {
+            const float wv = wps[h * DHP + 16 * ft + ln];
+            auto rfrag = [&](int qt, int s) { return dls[16 * qt + 4 * mq + s] * wv; };
+            acc = attn_bwd_phase2_tile(PT, kt, 0, QT, rfrag, lane);
+          }
+          float* out = which == 0 ? dkh : dvh;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * mq + r;
+            if (key < L) {
+              float* dst = out + (ubase + key) * DPO + h * DHP + 16 * ft + ln;
+              // the same lane owns this element in every chunk: plain read-modify-write, no race
+              *dst = first_pass ? acc[r] : *dst + acc[r];
+            }
+          }
+        }
+        __syncthreads();
+      }
+      first_pass = false;
+    }
+  }
+  for (int i = tid; i < DPO; i += 512) atomicAdd(&d_ffn_w_pad[i], dwp[i]);
+}
+
+template <int DPI, int DHP, int NH>
+int launch_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const float* d_attn, int ld_da,
+                       const int32_t* ids, float* dqh, float* dkh, float* dvh, int B, int L, int d,
+                       hipStream_t stream) {
+  using G = AttGeom<DPI, DHP, NH>;
+  const size_t lds_bytes = sizeof(float) * (3 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP);
+  auto kern = sa_attn_bwd_kernel<DPI, DHP, NH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      carca_set_error("sa_attn_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds_bytes, stream, qh, kh, vh, d_attn, ld_da, ids, dqh, dkh, dvh, L, d / NH);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+template <int DPI, int DHP, int NH>
+int launch_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids, const CrossBwdGroups& groups,
+                          const float* ffn_w_pad, float* dkh, float* dvh, float* d_ffn_w_pad, int B, int L, int d,
+                          int training, hipStream_t stream) {
+  using G = AttGeom<DPI, DHP, NH>;
+  const size_t lds_bytes = sizeof(float) * (2 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP + 64 + 2 * G::DPO);
+  auto kern = cross_attn_bwd_kernel<DPI, DHP, NH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      carca_set_error("cross_attn_bwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds_bytes, stream, kh, vh, p_ids, groups, ffn_w_pad, dkh, dvh,
+                     d_ffn_w_pad, L, d / NH, training);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+}  // namespace
+
+extern "C" int carca_layernorm_bwd(const float* dy, int ld_dy, const float* x, int ld_x, const float* gamma, int rows,
+                                   int d, const float* addend, int ld_add, float* dx, int ld_dx, int ncols_out,
+                                   float* dgamma, float* dbeta, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(dy && x && gamma && dx && rows >= 1 && d >= 1, "layernorm_bwd: null pointer or bad dims");
+  CARCA_CHECK_SUPPORTED(d <= 128, "layernorm_bwd: d=%d > 128", d);
+  CARCA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
+  CARCA_CHECK_ARG(ncols_out <= ld_dx && ncols_out <= 128 && ld_dy >= d && ld_x >= d, "layernorm_bwd: bad strides");
+  const int blocks = min((rows + 3) / 4, 1024);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, ld_dy, x, ld_x, gamma, rows, d,
+                     addend, ld_add, dx, ld_dx, ncols_out, dgamma, dbeta);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_embed_scatter(const float* dz, int ld_dz, const int32_t* ids, int rows, int d, float scale,
+                                   float* d_items, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(dz && ids && d_items && rows >= 1 && d >= 1 && ld_dz >= d, "embed_scatter: bad arguments");
+  const int blocks = min((rows + 3) / 4, 2048);
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(blocks), dim3(256), 0, stream, dz, ld_dz, ids, rows, d, scale, d_items);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_colsum(const float* x, int ld_x, int rows, int cols, const float* rowscale, const int32_t* ids,
+                            int T, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(x && out && rows >= 1 && cols >= 1 && ld_x >= cols && T >= 1, "colsum: bad arguments");
+  CARCA_CHECK_SUPPORTED(cols <= 256, "colsum: cols=%d > 256", cols);
+  const int blocks = T == 1 ? min(rows, 512) : T;
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, x, ld_x, rows, cols, rowscale, ids, T, out);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const float* d_attn, int ld_da,
+                                 const int32_t* ids, float* dqh, float* dkh, float* dvh, int B, int L, int d, int H,
+                                 void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(qh && kh && vh && d_attn && ids && dqh && dkh && dvh && ld_da >= d, "sa_attn_bwd: bad arguments");
+  CARCA_CHECK_ARG(B >= 1 && L >= 1 && d >= 1 && H >= 1 && d % H == 0, "sa_attn_bwd: bad dims");
+  CARCA_CHECK_SUPPORTED(L <= CARCA_MAX_L, "sa_attn_bwd: L=%d > %d", L, CARCA_MAX_L);
+  int dpi, dhp, dpo;
+  if (carca_padded_dims(d, H, &dpi, &dhp, &dpo) != CARCA_OK) return CARCA_ERR_UNSUPPORTED;
+  CARCA_ATT_DISPATCH(launch_sa_attn_bwd, qh, kh, vh, d_attn, ld_da, ids, dqh, dkh, dvh, B, L, d, stream);
+  carca_set_error("sa_attn_bwd: no kernel built for d=%d H=%d", d, H);
+  return CARCA_ERR_UNSUPPORTED;
+}
+
+extern "C" int carca_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids,
+                                    const CarcaCrossBwdGroup* groups, int ngroups, const float* ffn_w_pad, float* dkh,
+                                    float* dvh, float* d_ffn_w_pad, int B, int L, int d, int H, int training,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(kh && vh && p_ids && groups && ffn_w_pad && dkh && dvh && d_ffn_w_pad, "cross_attn_bwd: null pointer");
+  CARCA_CHECK_ARG(ngroups >= 1 && ngroups <= CARCA_MAX_GROUPS && B >= 1 && L >= 1 && d >= 1 && H >= 1 && d % H == 0,
+                  "cross_attn_bwd: bad dims");
+  CARCA_CHECK_SUPPORTED(L <= CARCA_MAX_L, "cross_attn_bwd: L=%d > %d", L, CARCA_MAX_L);
+  int dpi, dhp, dpo;
+  if (carca_padded_dims(d, H, &dpi, &dhp, &dpo) != CARCA_OK) return CARCA_ERR_UNSUPPORTED;
+  CrossBwdGroups gd{};
+  for (int i = 0; i < ngroups; ++i) {
+    const CarcaCrossBwdGroup& g = groups[i];
+    CARCA_CHECK_ARG(g.qh && g.y && g.dy && g.ids && g.dqh && g.N >= 1, "cross_attn_bwd: group %d malformed", i);
+    gd.g[i] = g;
+  }
+  gd.n = ngroups;
+  CARCA_ATT_DISPATCH(launch_cross_attn_bwd, kh, vh, p_ids, gd, ffn_w_pad, dkh, dvh, d_ffn_w_pad, B, L, d, training,
+                     stream);
+  carca_set_error("cross_attn_bwd: no kernel built for d=%d H=%d", d, H);
+  return CARCA_ERR_UNSUPPORTED;
+}

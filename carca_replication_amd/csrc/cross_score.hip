@@ -26,7 +26,7 @@ __global__ __launch_bounds__(512) void cross_score_kernel(const float* __restric
                                                           const int32_t* __restrict__ p_ids,
                                                           float* __restrict__ p_normed, const GroupsDev groups,
                                                           int ldo, int L, int d, int dh, const CarcaCaWeights w,
-                                                          int residual, int training) {
+                                                          int residual, int training, const CarcaCaSave sv) {
   using G = AttGeom<DPI, DHP, NH>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ps = lds;                    // [64][SI]
@@ -66,9 +66,11 @@ __global__ __launch_bounds__(512) void cross_score_kernel(const float* __restric
       const int jj = isv ? job - nk : job;
       const int ft = jj / LT, st = jj - ft * LT;
       if (!isv)
-        proj_tile_feat_major<DPI>(w.wk, w.bk, Ps, G::SI, Ks, G::SO, ft, st, lane);
+        proj_tile_feat_major<DPI>(w.wk, w.bk, Ps, G::SI, Ks, G::SO, ft, st, lane,
+                                  sv.kh ? sv.kh + (size_t)u * L * G::DPO : nullptr, G::DPO, L);
       else
-        proj_tile_slot_major<DPI>(w.wv, w.bv, Ps, G::SI, Vt, ATT_SK, ft, st, lane);
+        proj_tile_slot_major<DPI>(w.wv, w.bv, Ps, G::SI, Vt, ATT_SK, ft, st, lane,
+                                  sv.vh ? sv.vh + (size_t)u * L * G::DPO : nullptr, G::DPO, L);
     }
   }
   __syncthreads();
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(512) void cross_score_kernel(const float* __restric
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       f32x4 oh[G::NFH], p[ATT_LT];
-      attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, nkt, okbits, sqrt_dh, oh, p, lane);
+      attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, nkt, okbits, sqrt_dh, oh, p, lane,
+                                (sv.qh[gi] && in_range) ? sv.qh[gi] + row * G::DPO : nullptr);
 #pragma unroll
       for (int ft = 0; ft < G::NFH; ++ft) {
         const f32x4 wp = glb4(w.ffn_w_pad + h * DHP + 16 * ft + 4 * mq);
@@ -132,7 +135,8 @@ __global__ __launch_bounds__(512) void cross_score_kernel(const float* __restric
 
 template <int DPI, int DHP, int NH>
 int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_normed, const GroupsDev& groups, int ldo,
-                 int B, int L, int d, const CarcaCaWeights& w, int residual, int training, hipStream_t stream) {
+                 int B, int L, int d, const CarcaCaWeights& w, int residual, int training, const CarcaCaSave& sv,
+                 hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
   const size_t lds_bytes = sizeof(float) * (ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK);
   auto kern = cross_score_kernel<DPI, DHP, NH>;
@@ -146,7 +150,7 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L, d,
-                     d / NH, w, residual, training);
+                     d / NH, w, residual, training, sv);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -155,7 +159,8 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
 
 extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t* p_ids, float* p_normed,
                                      const CarcaTargetGroup* groups, int ngroups, int ldo, int B, int L, int d, int H,
-                                     const CarcaCaWeights* w, int residual, int training, void* stream_) {
+                                     const CarcaCaWeights* w, int residual, int training, const CarcaCaSave* save,
+                                     void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(p_raw && p_ids && groups && w, "cross_score_fwd: null pointer");
   CARCA_CHECK_ARG(ngroups >= 1 && ngroups <= CARCA_MAX_GROUPS, "cross_score_fwd: ngroups=%d outside 1..%d", ngroups,
@@ -177,7 +182,9 @@ extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t*
   }
   gd.tile_start[ngroups] = t;
   gd.n = ngroups;
-  CARCA_ATT_DISPATCH(launch_cross, p_raw, ldp, p_ids, p_normed, gd, ldo, B, L, d, *w, residual, training, stream);
+  CarcaCaSave sv{};
+  if (save) sv = *save;
+  CARCA_ATT_DISPATCH(launch_cross, p_raw, ldp, p_ids, p_normed, gd, ldo, B, L, d, *w, residual, training, sv, stream);
   carca_set_error("cross_score_fwd: no kernel built for d=%d H=%d (padded %d / head %d)", d, H, dpi, dhp);
   return CARCA_ERR_UNSUPPORTED;
 }

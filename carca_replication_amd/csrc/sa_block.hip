@@ -16,7 +16,7 @@ template <int DPI, int DHP, int NH>
 __global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__ x, int ldx,
                                                        const int32_t* __restrict__ ids, float* __restrict__ y,
                                                        int ldy, int L, int d, int dh, const CarcaSaWeights w,
-                                                       int residual) {
+                                                       int residual, const CarcaSaSave sv) {
   using G = AttGeom<DPI, DHP, NH>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Xs = lds;                    // [64][SI]  x, later s2 = LayerNorm2(.)
@@ -43,6 +43,11 @@ __global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__
     if (r < L) row_layernorm(v0, v1, lane, d, w.ln1_w, w.ln1_b);
     if (lane < DPI) Qn[r * G::SI + lane] = v0;
     if (lane + 64 < DPI) Qn[r * G::SI + lane + 64] = v1;
+    if (sv.qn && r < L) {
+      float* qr = sv.qn + ((size_t)u * L + r) * DPI;
+      if (lane < DPI) qr[lane] = v0;
+      if (lane + 64 < DPI) qr[lane + 64] = v1;
+    }
   }
   __syncthreads();
 
@@ -54,9 +59,11 @@ __global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__
       const int jj = isv ? job - nk : job;
       const int ft = jj / LT, st = jj - ft * LT;
       if (!isv)
-        proj_tile_feat_major<DPI>(w.wk, w.bk, Xs, G::SI, Ks, G::SO, ft, st, lane);
+        proj_tile_feat_major<DPI>(w.wk, w.bk, Xs, G::SI, Ks, G::SO, ft, st, lane,
+                                  sv.kh ? sv.kh + (size_t)u * L * G::DPO : nullptr, G::DPO, L);
       else
-        proj_tile_slot_major<DPI>(w.wv, w.bv, Xs, G::SI, Vt, ATT_SK, ft, st, lane);
+        proj_tile_slot_major<DPI>(w.wv, w.bv, Xs, G::SI, Vt, ATT_SK, ft, st, lane,
+                                  sv.vh ? sv.vh + (size_t)u * L * G::DPO : nullptr, G::DPO, L);
     }
   }
   __syncthreads();
@@ -87,7 +94,8 @@ __global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       f32x4 oh[G::NFH], p[ATT_LT];
-      attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, nkt, okbits, sqrt_dh, oh, p, lane);
+      attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, nkt, okbits, sqrt_dh, oh, p, lane,
+                                (sv.qh && q < L) ? sv.qh + ((size_t)u * L + q) * G::DPO : nullptr);
 #pragma unroll
       for (int ft = 0; ft < G::NFH; ++ft) o[h * G::NFH + ft] = oh[ft];
     }
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__
         if (j >= 0) v = o[fi][r] + (residual ? Qn[q * G::SI + j] : 0.f);
         o[fi][r] = v;
         part += v;
+        if (sv.r && j >= 0 && q < L) sv.r[((size_t)u * L + q) * DPI + j] = v;  // LayerNorm2 input
       }
     const float inv_d = 1.0f / (float)d;
     const float mean = quad4_sum(part) * inv_d;
@@ -131,7 +140,10 @@ __global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__
 
     f32x4 s2[G::NKG];
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) s2[kg] = lds4(Xs + q * G::SI + 16 * kg + 4 * mq);
+    for (int kg = 0; kg < G::NKG; ++kg) {
+      s2[kg] = lds4(Xs + q * G::SI + 16 * kg + 4 * mq);
+      if (sv.s2 && q < L) *reinterpret_cast<f32x4*>(sv.s2 + ((size_t)u * L + q) * DPI + 16 * kg + 4 * mq) = s2[kg];
+    }
     // ffn_1 + LeakyReLU: H1^T[f][query], kept in registers as the next product's Bt operand
     f32x4 h1[G::NKG];
 #pragma unroll
@@ -144,6 +156,7 @@ __global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.01f * acc[r];
       h1[ft] = acc;
+      if (sv.h1 && q < L) *reinterpret_cast<f32x4*>(sv.h1 + ((size_t)u * L + q) * DPI + 16 * ft + 4 * mq) = acc;
     }
     // ffn_2 + residual with s2, straight to global (pad columns come out as exact zeros)
 #pragma unroll
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__
 
 template <int DPI, int DHP, int NH>
 int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d,
-              const CarcaSaWeights& w, int residual, hipStream_t stream) {
+              const CarcaSaWeights& w, int residual, const CarcaSaSave& sv, hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
   const size_t lds_bytes = sizeof(float) * (2 * ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK);
   auto kern = sa_block_kernel<DPI, DHP, NH>;
@@ -175,7 +188,7 @@ int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, in
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_bytes, stream, x, ldx, ids, y, ldy, L, d, d / NH, w, residual);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_bytes, stream, x, ldx, ids, y, ldy, L, d, d / NH, w, residual, sv);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -183,7 +196,8 @@ int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, in
 }  // namespace
 
 extern "C" int carca_sa_block_fwd(const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d,
-                                  int H, const CarcaSaWeights* w, int residual, void* stream_) {
+                                  int H, const CarcaSaWeights* w, int residual, const CarcaSaSave* save,
+                                  void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(x && ids && y && w, "sa_block_fwd: null pointer");
   CARCA_CHECK_ARG(B >= 1 && L >= 1 && d >= 1 && H >= 1 && d % H == 0, "sa_block_fwd: bad dims B=%d L=%d d=%d H=%d", B,
@@ -193,7 +207,9 @@ extern "C" int carca_sa_block_fwd(const float* x, int ldx, const int32_t* ids, f
   if (carca_padded_dims(d, H, &dpi, &dhp, &dpo) != CARCA_OK) return CARCA_ERR_UNSUPPORTED;
   CARCA_CHECK_ARG(ldx >= d && ldy >= dpi && ldy % 4 == 0, "sa_block_fwd: need ldx >= d, ldy >= %d and ldy %% 4 == 0",
                   dpi);
-  CARCA_ATT_DISPATCH(launch_sa, x, ldx, ids, y, ldy, B, L, d, *w, residual, stream);
+  CarcaSaSave sv{};
+  if (save) sv = *save;
+  CARCA_ATT_DISPATCH(launch_sa, x, ldx, ids, y, ldy, B, L, d, *w, residual, sv, stream);
   carca_set_error("sa_block_fwd: no kernel built for d=%d H=%d (padded %d / head %d)", d, H, dpi, dhp);
   return CARCA_ERR_UNSUPPORTED;
 }

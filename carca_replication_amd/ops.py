@@ -66,6 +66,7 @@ class PackItem:
     dst_cols: int
     row_heads: Tuple[int, int] = (0, 0)  # (dh, dhp) when rows are output features split into heads
     col_heads: Tuple[int, int] = (0, 0)
+    transposed: bool = False  # pack src^T (dst_rows/dst_cols and the head maps refer to the transposed matrix)
 
 
 class PackedWeights:
@@ -87,22 +88,40 @@ class PackedWeights:
         it = self.items[i]
         return self.buf[self.offsets[i]: self.offsets[i] + it.dst_rows * it.dst_cols].view(it.dst_rows, it.dst_cols)
 
-    def pack(self) -> None:
-        lib = _lib.load()
+    def _fill(self, tensors) -> list:
         keep = []
-        for i, it in enumerate(self.items):
-            src = it.src.detach()
+        for i, (it, src) in enumerate(zip(self.items, tensors)):
+            src = src.detach()
             src2 = src.reshape(1, -1) if src.dim() == 1 else src.reshape(src.shape[0], -1)
-            src2 = _f32(src2)
+            if src2.dtype != torch.float32 or src2.stride(1) != 1:
+                raise CarcaHipError("pack: parameters must be fp32 with unit inner stride")
             _need_cuda(src2)
             keep.append(src2)
             d = self._descs[i]
             d.src, d.dst = src2.data_ptr(), self.ptr(i)
-            d.rows, d.cols, d.src_ld = src2.shape[0], src2.shape[1], src2.stride(0)
+            if it.transposed:
+                d.rows, d.cols = src2.shape[1], src2.shape[0]
+            else:
+                d.rows, d.cols = src2.shape[0], src2.shape[1]
+            d.src_ld = src2.stride(0)
             d.dst_rows, d.dst_cols = it.dst_rows, it.dst_cols
             d.row_dh, d.row_dhp = it.row_heads
             d.col_dh, d.col_dhp = it.col_heads
+            d.transposed = int(it.transposed)
+        return keep
+
+    def pack(self) -> None:
+        lib = _lib.load()
+        keep = self._fill([it.src for it in self.items])
         _lib.check(lib.carca_pack_weights(self._descs, len(self.items), _stream()), "pack_weights")
+        del keep
+
+    def unpack_into(self, grads, accumulate: bool = False) -> None:
+        """Inverse map for gradients: grads[i] (real shape of items[i].src) (+)= packed item i of this buffer."""
+        lib = _lib.load()
+        keep = self._fill(grads)
+        _lib.check(lib.carca_unpack_grads(self._descs, len(self.items), int(accumulate), _stream()), "unpack_grads")
+        del keep
 
 
 # --------------------------------------------------------------------------------------------------
@@ -169,26 +188,35 @@ def embed_fwd(segs: Sequence[Tuple[Tensor, Tensor, Tensor, bool]], items_w: Tens
 # --------------------------------------------------------------------------------------------------
 # self-attention block
 # --------------------------------------------------------------------------------------------------
-def sa_block_fwd(x: Tensor, ids: Tensor, w: "_lib.SaWeights", d: int, H: int, residual: bool) -> Tensor:
-    """x [B, L, ldx] (ldx >= d) -> y [B, L, DPI]; `ids` [B, L] (any integer/bool type, 0 = pad)."""
+def sa_block_fwd(x: Tensor, ids: Tensor, w: "_lib.SaWeights", d: int, H: int, residual: bool, save: bool = False):
+    """x [B, L, ldx] (ldx >= d) -> y [B, L, DPI]; `ids` [B, L] (any integer/bool type, 0 = pad).
+
+    save=True also returns the dict of tensors the backward pass needs (CarcaSaSave)."""
     lib = _lib.load()
     _need_cuda(x, ids)
     x = _f32(x)
     B, L, ldx = x.shape
-    dpi, _, _ = padded_dims(d, H)
+    dpi, _, dpo = padded_dims(d, H)
     ids32 = _ids32(ids)
     y = torch.empty(B, L, dpi, dtype=torch.float32, device=x.device)
+    sv, saved = None, None
+    if save:
+        sv = _lib.SaSave()
+        mk = lambda w_: torch.empty(B * L, w_, dtype=torch.float32, device=x.device)  # noqa: E731
+        saved = dict(qn=mk(dpi), qh=mk(dpo), kh=mk(dpo), vh=mk(dpo), r=mk(dpi), s2=mk(dpi), h1=mk(dpi))
+        for k, t in saved.items():
+            setattr(sv, k, t.data_ptr())
     _lib.check(lib.carca_sa_block_fwd(x.data_ptr(), ldx, ids32.data_ptr(), y.data_ptr(), dpi, B, L, d, H, C.byref(w),
-                                      int(bool(residual)), _stream()), "sa_block_fwd")
-    return y
+                                      int(bool(residual)), C.byref(sv) if save else None, _stream()), "sa_block_fwd")
+    return (y, saved) if save else y
 
 
 # --------------------------------------------------------------------------------------------------
 # final norm + grouped cross-attention scoring
 # --------------------------------------------------------------------------------------------------
 def cross_score_fwd(p_raw: Tensor, p_ids: Tensor, groups: Sequence[Tuple[Tensor, Tensor]], w: "_lib.CaWeights", d: int,
-                    H: int, residual: bool, training: bool, want_normed: bool = False):
-    """p_raw [B, L, ldp]; groups: [(o [B,N,ldo], ids [B,N])] -> ([y [B,N]], p_normed or None)."""
+                    H: int, residual: bool, training: bool, want_normed: bool = False, save: bool = False):
+    """p_raw [B, L, ldp]; groups: [(o [B,N,ldo], ids [B,N])] -> ([y [B,N]], p_normed or None[, saved])."""
     lib = _lib.load()
     _need_cuda(p_raw, p_ids)
     p_raw = _f32(p_raw)
@@ -211,16 +239,28 @@ def cross_score_fwd(p_raw: Tensor, p_ids: Tensor, groups: Sequence[Tuple[Tensor,
         keep += [o, ids32]
         ys.append(y)
         arr[i].o, arr[i].ids, arr[i].y, arr[i].N = o.data_ptr(), ids32.data_ptr(), y.data_ptr(), o.shape[1]
-    p_normed = torch.empty_like(p_raw) if want_normed else None
+    p_normed = torch.empty_like(p_raw) if (want_normed or save) else None
+    sv, saved = None, None
+    if save:
+        _, _, dpo = padded_dims(d, H)
+        sv = _lib.CaSave()
+        mk = lambda n: torch.empty(n, dpo, dtype=torch.float32, device=p_raw.device)  # noqa: E731
+        saved = dict(kh=mk(B * L), vh=mk(B * L), qh=[mk(B * o.shape[1]) for (o, _) in groups])
+        sv.kh, sv.vh = saved["kh"].data_ptr(), saved["vh"].data_ptr()
+        for i, t in enumerate(saved["qh"]):
+            sv.qh[i] = t.data_ptr()
     ev = _stage_events.get("cross") if _stage_events else None
     if ev is not None:
         ev[0].record()
     _lib.check(lib.carca_cross_score_fwd(p_raw.data_ptr(), ldp, p_ids32.data_ptr(),
-                                         p_normed.data_ptr() if want_normed else None, arr, len(groups), ldo, B, L, d,
-                                         H, C.byref(w), int(bool(residual)), int(bool(training)), _stream()),
+                                         p_normed.data_ptr() if p_normed is not None else None, arr, len(groups),
+                                         ldo, B, L, d, H, C.byref(w), int(bool(residual)), int(bool(training)),
+                                         C.byref(sv) if save else None, _stream()),
                "cross_score_fwd")
     if ev is not None:
         ev[1].record()
+    if save:
+        return ys, p_normed, saved
     return ys, p_normed
 
 
@@ -371,3 +411,82 @@ def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, ma
     D.ld_dy, D.ld_x, D.N, D.K = ld_dy, ld_x, N, K
     D.dw, D.ldw, D.db, D.mask_rows = dw.data_ptr(), dw.stride(0), _ptr(db), int(mask_rows)
     _lib.check(lib.carca_gemm_wgrad(C.byref(D), _stream()), "gemm_wgrad")
+
+
+# --------------------------------------------------------------------------------------------------
+# backward kernels
+# --------------------------------------------------------------------------------------------------
+def _row2d(t: Tensor, name: str) -> Tensor:
+    _need_cuda(t)
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
+        raise CarcaHipError(f"{name} must be a 2-D fp32 view with unit inner stride")
+    return t
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, d: int, out_ld: int, addend: Optional[Tensor] = None,
+                  dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None) -> Tensor:
+    """dx [rows, out_ld] = dLayerNorm(dy; x, gamma) (+ addend); dgamma/dbeta accumulate (atomics)."""
+    lib = _lib.load()
+    dy, x = _row2d(dy, "dy"), _row2d(x, "x")
+    rows = dy.shape[0]
+    dx = torch.empty(rows, out_ld, dtype=torch.float32, device=dy.device)
+    if addend is not None:
+        addend = _row2d(addend, "addend")
+    _lib.check(lib.carca_layernorm_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(), rows, d,
+                                       _ptr(addend), addend.stride(0) if addend is not None else 0, dx.data_ptr(),
+                                       out_ld, out_ld, _ptr(dgamma), _ptr(dbeta), _stream()), "layernorm_bwd")
+    return dx
+
+
+def embed_scatter(dz: Tensor, ids: Tensor, d: int, scale: float, d_items: Tensor) -> None:
+    lib = _lib.load()
+    dz = _row2d(dz, "dz")
+    ids32 = _ids32(ids.reshape(-1))
+    _lib.check(lib.carca_embed_scatter(dz.data_ptr(), dz.stride(0), ids32.data_ptr(), dz.shape[0], d, scale,
+                                       d_items.data_ptr(), _stream()), "embed_scatter")
+
+
+def colsum(x: Tensor, cols: int, out: Tensor, rowscale: Optional[Tensor] = None, ids: Optional[Tensor] = None,
+           T: int = 1) -> None:
+    """out[(row % T)][c] += sum_rows rowscale[row] * (ids[row] != 0) * x[row][c]."""
+    lib = _lib.load()
+    x = _row2d(x, "x")
+    ids32 = _ids32(ids.reshape(-1)) if ids is not None else None
+    rs = _f32(rowscale.reshape(-1)) if rowscale is not None else None
+    _lib.check(lib.carca_colsum(x.data_ptr(), x.stride(0), x.shape[0], cols, _ptr(rs), _ptr(ids32), T, out.data_ptr(),
+                                _stream()), "colsum")
+
+
+def sa_attn_bwd(qh: Tensor, kh: Tensor, vh: Tensor, d_attn: Tensor, ids: Tensor, B: int, L: int, d: int, H: int):
+    lib = _lib.load()
+    d_attn = _row2d(d_attn, "d_attn")
+    ids32 = _ids32(ids.reshape(-1))
+    dqh, dkh, dvh = torch.empty_like(qh), torch.empty_like(kh), torch.empty_like(vh)
+    _lib.check(lib.carca_sa_attn_bwd(qh.data_ptr(), kh.data_ptr(), vh.data_ptr(), d_attn.data_ptr(), d_attn.stride(0),
+                                     ids32.data_ptr(), dqh.data_ptr(), dkh.data_ptr(), dvh.data_ptr(), B, L, d, H,
+                                     _stream()), "sa_attn_bwd")
+    return dqh, dkh, dvh
+
+
+def cross_attn_bwd(kh: Tensor, vh: Tensor, p_ids: Tensor, groups, ffn_w_pad_ptr: int, d_ffn_w_pad: Tensor, B: int,
+                   L: int, d: int, H: int, training: bool):
+    """groups: [(qh [B*N,DPO], y [B,N], dy [B,N], ids [B,N])] -> ([dqh], [dlogit], dkh, dvh)."""
+    lib = _lib.load()
+    arr = (_lib.CrossBwdGroup * len(groups))()
+    keep, dqhs, dls = [], [], []
+    for i, (qh, y, dy, ids) in enumerate(groups):
+        y, dy, ids32 = _f32(y), _f32(dy), _ids32(ids)
+        dqh = torch.empty_like(qh)
+        dl = torch.empty(y.numel(), dtype=torch.float32, device=y.device)
+        keep += [y, dy, ids32]
+        dqhs.append(dqh)
+        dls.append(dl)
+        g = arr[i]
+        g.qh, g.y, g.dy, g.ids, g.dqh, g.dlogit, g.N = (qh.data_ptr(), y.data_ptr(), dy.data_ptr(), ids32.data_ptr(),
+                                                        dqh.data_ptr(), dl.data_ptr(), y.shape[1])
+    p_ids32 = _ids32(p_ids)
+    dkh, dvh = torch.empty_like(kh), torch.empty_like(vh)
+    _lib.check(lib.carca_cross_attn_bwd(kh.data_ptr(), vh.data_ptr(), p_ids32.data_ptr(), arr, len(groups),
+                                        ffn_w_pad_ptr, dkh.data_ptr(), dvh.data_ptr(), d_ffn_w_pad.data_ptr(), B, L, d,
+                                        H, int(bool(training)), _stream()), "cross_attn_bwd")
+    return dqhs, dls, dkh, dvh

@@ -63,6 +63,7 @@ typedef struct CarcaPackDesc {
   int32_t dst_rows, dst_cols;
   int32_t row_dh, row_dhp; /* 0,0 = plain rows */
   int32_t col_dh, col_dhp; /* 0,0 = plain cols */
+  int32_t transposed;      /* 1: logical element (r, c) lives at src[c * src_ld + r] (rows/cols are logical) */
 } CarcaPackDesc;
 int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream);
 
@@ -161,9 +162,17 @@ typedef struct CarcaSaWeights {
   const float *w1, *w2;                       /* [DPI, DPI] */
   const float *b1, *b2;                       /* [DPI] */
 } CarcaSaWeights;
+/* Tensors the backward pass needs (all optional; pass save = NULL in eval): */
+typedef struct CarcaSaSave {
+  float* qn;             /* [B*L, DPI] LayerNorm1(x) */
+  float *qh, *kh, *vh;   /* [B*L, DPO] projections, head-padded columns */
+  float* r;              /* [B*L, DPI] LayerNorm2's input (attention + residual) */
+  float* s2;             /* [B*L, DPI] LayerNorm2's output */
+  float* h1;             /* [B*L, DPI] LeakyReLU(ffn_1(s2)) */
+} CarcaSaSave;
 int carca_sa_block_fwd(const float* x /*[B*L, ldx]*/, int ldx, const int32_t* ids /*[B*L]*/, float* y /*[B*L, ldy]*/,
                        int ldy, int B, int L, int d, int H, const CarcaSaWeights* w /*host struct*/, int residual,
-                       void* stream);
+                       const CarcaSaSave* save /*host struct or NULL*/, void* stream);
 
 /* ---- a5 + a6: final LayerNorm + CrossAttentionBlock.forward, grouped --------------------------
  * Replaces CARCA.forward's final norm (carca.py:421) and, for every target group,
@@ -185,10 +194,52 @@ typedef struct CarcaTargetGroup {
   float* y;           /* [B*N] */
   int32_t N;
 } CarcaTargetGroup;
+typedef struct CarcaCaSave {
+  float *kh, *vh;              /* [B*L, DPO] */
+  float* qh[CARCA_MAX_GROUPS]; /* [B*N_g, DPO] per group */
+} CarcaCaSave;
 int carca_cross_score_fwd(const float* p_raw /*[B*L, ldp] encoder output BEFORE the final norm*/, int ldp,
                           const int32_t* p_ids /*[B*L]*/, float* p_normed /*[B*L, ldp] or NULL*/,
                           const CarcaTargetGroup* groups /*host*/, int ngroups, int ldo, int B, int L, int d, int H,
-                          const CarcaCaWeights* w /*host struct*/, int residual, int training, void* stream);
+                          const CarcaCaWeights* w /*host struct*/, int residual, int training,
+                          const CarcaCaSave* save /*host struct or NULL*/, void* stream);
+
+/* ---- backward kernels (the autograd of the lines cited at each forward entry point) -------------------
+ * LayerNorm backward over `rows` rows of width d: dx = dLN(dy; x, gamma) (+ addend); dgamma/dbeta are
+ * accumulated with atomics (caller zeroes).  Columns d..ncols_out-1 of dx are written as zeros. */
+int carca_layernorm_bwd(const float* dy, int ld_dy, const float* x, int ld_x, const float* gamma, int rows, int d,
+                        const float* addend /*or NULL*/, int ld_add, float* dx, int ld_dx, int ncols_out,
+                        float* dgamma /*or NULL*/, float* dbeta /*or NULL*/, void* stream);
+/* d_items[ids[r]][:] += scale * dz[r][:] for ids[r] != 0 (nn.Embedding(padding_idx=0), carca.py:73,87-88) */
+int carca_embed_scatter(const float* dz, int ld_dz, const int32_t* ids, int rows, int d, float scale,
+                        float* d_items /*[n_items, d]*/, void* stream);
+/* out[(row % T)][c] += sum_rows rowscale[row] * (ids[row] != 0) * x[row][c]; T = 1: plain column sum.
+ * rowscale / ids may be NULL.  cols <= 256.  Caller zeroes out. */
+int carca_colsum(const float* x, int ld_x, int rows, int cols, const float* rowscale, const int32_t* ids, int T,
+                 float* out /*[T, cols]*/, void* stream);
+/* Attention core of SelfAttentionBlock (carca.py:246-260, causal = 0): given d(attention output)
+ * [B*L, ld_da] in plain feature order and the saved projections, recompute P and return dQ, dK, dV
+ * (head-padded, [B*L, DPO]). */
+int carca_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const float* d_attn, int ld_da,
+                      const int32_t* ids, float* dqh, float* dkh, float* dvh, int B, int L, int d, int H, void* stream);
+/* Attention core + sigmoid(ffn(.)) head of CrossAttentionBlock (carca.py:340-347) for every group:
+ * dlogit = dy * y * (1 - y); d(attention output) = dlogit (x) ffn_w_pad; returns dQ per group, dK, dV
+ * (summed over groups) and accumulates d ffn_w_pad[f] += sum dlogit * O[.][f] (caller zeroes it). */
+typedef struct CarcaCrossBwdGroup {
+  const float* qh;    /* [B*N, DPO] saved by the forward */
+  const float* y;     /* [B*N] forward output */
+  const float* dy;    /* [B*N] incoming gradient */
+  const int32_t* ids; /* [B*N] */
+  float* dqh;         /* [B*N, DPO] out */
+  float* dlogit;      /* [B*N] out, or NULL */
+  int32_t N;
+} CarcaCrossBwdGroup;
+int carca_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids, const CarcaCrossBwdGroup* groups,
+                         int ngroups, const float* ffn_w_pad, float* dkh, float* dvh, float* d_ffn_w_pad, int B, int L,
+                         int d, int H, int training, void* stream);
+/* Inverse of carca_pack_weights for gradients: real[r][c] (+)= packed[rp][cp] (same descriptor fields:
+ * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
+int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);
 
 /* ---- a8: BinaryCrossEntropy.forward (carca.py:441-444) -----------------------------------------
  * loss = sum(l * m) / sum(m), l = -(t log(y+eps) + (1-t) log(1-y+eps)), m = (ids != 0).
