@@ -104,6 +104,43 @@ def cpu_baseline(c, model, profile, target, budget_s=15.0):
                       f"oracle/carca_oracle.py on torch-CPU, {cores} threads"}
 
 
+def measure_train(c, model, rank, world, device, steps):
+    """Secondary metric: train users/sec = fwd + bwd + gradient all-reduce + Adam, L pos + L neg
+    targets per user (train.py:84-96 call shape), dropout p = 0, same C2 model and batch size per GPU."""
+    import torch
+    import torch.distributed as dist
+
+    from carca_replication_amd import engine
+    from oracle.carca_oracle import synth_eval_batch
+
+    L = c["L"]
+    profile, pos, _ = synth_eval_batch(c["B"], L, L, c["n_items"], c["n_attrs"], c["n_ctx"], seed=4321 + rank)
+    px = profile[0]
+    o_x = torch.cat([pos[0] * (px != 0), pos[0].flip(1) * (px != 0)], dim=1)
+    o_a = torch.cat([pos[1], pos[1].flip(1)], dim=1)
+    o_c = torch.cat([pos[2], pos[2]], dim=1)
+    y_true = torch.cat([(px != 0).int(), torch.zeros_like(px)], dim=1)
+    batch = tuple(t.to(device) for t in (profile[0], profile[1], profile[2], o_x, o_a, o_c, y_true))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    for _ in range(2):
+        engine.train_step(model, opt, batch, sharded=world > 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = engine.train_step(model, opt, batch, sharded=world > 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    model.eval()
+    return {"users_per_s": world * c["B"] * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "what": "fwd+bwd+Adam (+RCCL grad all-reduce when n_gpus>1), p=0, L pos + L neg targets, B=%d per GPU" % c["B"],
+            "last_loss": float(loss)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +148,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=C2["B"])
+    ap.add_argument("--train-steps", type=int, default=8, help="extra, untimed-by-the-headline train-step measurement")
     args = ap.parse_args()
 
     import torch
@@ -170,6 +208,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    train_info = None
+    if args.train_steps > 0:
+        train_info = measure_train(c, model, rank, world, device, args.train_steps)
+
     feat_ms = sorted(a.elapsed_time(b) for a, b in feat_events)
     ca_ms = sorted(a.elapsed_time(b) for a, b in ca_events)
     feat_avg = sum(feat_ms) / len(feat_ms)
@@ -199,6 +241,8 @@ def main():
                                      "unit": "TFLOP/s", "frac": ca_tflops / PEAK_F32_MFMA_TFLOPS, "avg_ms": ca_avg,
                                      "min_ms": ca_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["ca"] / 1e9},
         }
+        if train_info is not None:
+            out["train"] = train_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, model, profile_cpu, target_cpu)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -179,7 +179,7 @@ SIGNATURES = {
     "carca_cross_attn_bwd": (_i, [_fp, _fp, _fp, C.POINTER(CrossBwdGroup), _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i,
                                   _fp]),
     "carca_unpack_grads": (_i, [C.POINTER(PackDesc), _i, _i, _fp]),
-    "carca_bce_fwd": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp]),
+    "carca_bce_fwd": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp, _fp]),
     "carca_rank_metrics": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),
 }
 

@@ -210,8 +210,8 @@ def carca_forward_with_grad(model, profile, targets) -> List[Tensor]:
 
 class _BceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y_pred, y_true, ids_mask, eps):
-        loss, dy = ops.bce_fwd(y_pred.detach(), y_true, ids_mask, eps, want_grad=True)
+    def forward(ctx, y_pred, y_true, ids_mask, eps, denom):
+        loss, dy = ops.bce_fwd(y_pred.detach(), y_true, ids_mask, eps, want_grad=True, denom=denom)
         ctx.save_for_backward(dy)
         ctx.shape = y_pred.shape
         return loss
@@ -219,11 +219,11 @@ class _BceFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dy,) = ctx.saved_tensors
-        return dy.view(ctx.shape) * g, None, None, None
+        return dy.view(ctx.shape) * g, None, None, None, None
 
 
-def bce_with_grad(y_pred, y_true, mask, eps):
-    return _BceFn.apply(y_pred, y_true, mask != 0, eps)
+def bce_with_grad(y_pred, y_true, mask, eps, denom=None):
+    return _BceFn.apply(y_pred, y_true, mask != 0, eps, denom)
 
 
 def embed_with_grad(module, x, a, c, target):

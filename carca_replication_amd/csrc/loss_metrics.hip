@@ -8,7 +8,7 @@ namespace {
 __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ y, const int32_t* __restrict__ y_true,
                                                    const int32_t* __restrict__ ids, int n, float eps,
                                                    float* __restrict__ scratch, float* __restrict__ loss_out,
-                                                   float* __restrict__ dy) {
+                                                   float* __restrict__ dy, const float* __restrict__ denom) {
   __shared__ float red[2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float sl = 0.f, sm = 0.f;
@@ -34,6 +34,8 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ y, 
     if (lane == 0) {
       scratch[0] = a;
       scratch[1] = b;
+      // denom: the mask count of the WHOLE batch when users are sharded over ranks (dist.py), else sum(mask)
+      if (denom) b = denom[0];
       loss_out[0] = a / b;  // 0/0 = NaN for an all-pad batch, as in the reference
     }
     red[0][0] = b;
@@ -81,10 +83,10 @@ __global__ void rank_kernel(const float* __restrict__ y, int B, int N, int k, in
 }  // namespace
 
 extern "C" int carca_bce_fwd(const float* y, const int32_t* y_true, const int32_t* ids, int n, float eps,
-                             float* scratch, float* loss_out, float* dy, void* stream_) {
+                             float* scratch, float* loss_out, float* dy, const float* denom, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(y && y_true && ids && scratch && loss_out && n >= 1, "bce_fwd: null pointer or n < 1");
-  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, stream, y, y_true, ids, n, eps, scratch, loss_out, dy);
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, stream, y, y_true, ids, n, eps, scratch, loss_out, dy, denom);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

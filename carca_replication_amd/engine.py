@@ -1,0 +1,54 @@
+"""One training step / one evaluation batch of the hot path, single- or multi-GPU.
+
+Mirrors the body of the reference's loops (src/train.py:83-97 and :41-51) without its host syncs:
+nothing here calls .item(); losses and metric sums stay on the device until the caller reads them.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import dist as cdist
+from . import ops
+from .modules import BinaryCrossEntropy, get_mask
+
+_loss_fn = BinaryCrossEntropy()
+
+
+def train_step(model, optim, batch, sharded: bool = False) -> torch.Tensor:
+    """batch = (p_x, p_a, p_c, o_x, o_a, o_c, y_true) as the reference's DataLoader yields (train.py:84).
+
+    With sharded=True the batch holds THIS rank's users; the loss is normalised by the global mask
+    count and gradients are summed over ranks, which reproduces the single-process step exactly.
+    Returns the (device) loss: the global batch loss's local share when sharded.
+    """
+    p_x, p_a, p_c, o_x, o_a, o_c, y_true = batch
+    half = o_x.shape[1] // 2
+    pos = tuple(t[:, :half] for t in (o_x, o_a, o_c))  # train.py:86-88
+    neg = tuple(t[:, half:] for t in (o_x, o_a, o_c))
+    optim.zero_grad(set_to_none=True)
+    y = model(profile=(p_x, p_a, p_c), targets=[pos, neg])
+    denom = cdist.global_mask_count(o_x) if sharded else None
+    loss = _loss_fn(y, y_true, get_mask(o_x), denom=denom)
+    loss.backward()
+    if sharded:
+        cdist.allreduce_gradients(model.parameters())
+    optim.step()
+    return loss.detach()
+
+
+@torch.no_grad()
+def eval_batch(model, batch, k: int = 10, sums: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Scores one (p_x, p_a, p_c, o_x, o_a, o_c, y_true) eval batch (train.py:42-51); accumulates
+    [HR@k sum, NDCG@k sum, ties, loss sum, users] into `sums` (device float[5]) with no host sync."""
+    p_x, p_a, p_c, o_x, o_a, o_c, y_true = batch
+    y = model(profile=(p_x, p_a, p_c), targets=[(o_x, o_a, o_c)])
+    y2 = y.reshape(p_x.shape[0], -1)
+    if sums is None:
+        sums = torch.zeros(5, dtype=torch.float32, device=y.device)
+    ops.rank_metrics(y2, k, sums=sums[:3])
+    loss = _loss_fn(y2, y_true, get_mask(o_x))
+    sums[3] += loss
+    sums[4] += p_x.shape[0]
+    return y, sums

@@ -436,10 +436,12 @@ class CARCA(Model):
 
 
 class BinaryCrossEntropy(nn.Module):
-    def forward(self, y_pred: Tensor, y_true: Tensor, mask: Tensor, eps: float = 1e-8) -> Tensor:
+    def forward(self, y_pred: Tensor, y_true: Tensor, mask: Tensor, eps: float = 1e-8,
+                denom: Optional[Tensor] = None) -> Tensor:
+        """`denom` (extension, device float[1]): the whole batch's mask count when users are sharded (dist.py)."""
         if torch.is_grad_enabled() and y_pred.requires_grad:
             from .autograd import bce_with_grad
 
-            return bce_with_grad(y_pred, y_true, mask, eps)
-        loss, _ = ops.bce_fwd(y_pred, y_true, mask != 0, eps)
+            return bce_with_grad(y_pred, y_true, mask, eps, denom)
+        loss, _ = ops.bce_fwd(y_pred, y_true, mask != 0, eps, denom=denom)
         return loss

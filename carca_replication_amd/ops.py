@@ -267,7 +267,8 @@ def cross_score_fwd(p_raw: Tensor, p_ids: Tensor, groups: Sequence[Tuple[Tensor,
 # --------------------------------------------------------------------------------------------------
 # loss and metrics
 # --------------------------------------------------------------------------------------------------
-def bce_fwd(y: Tensor, y_true: Tensor, ids: Tensor, eps: float = 1e-8, want_grad: bool = False):
+def bce_fwd(y: Tensor, y_true: Tensor, ids: Tensor, eps: float = 1e-8, want_grad: bool = False,
+            denom: Optional[Tensor] = None):
     lib = _lib.load()
     _need_cuda(y, y_true, ids)
     y = _f32(y)
@@ -278,7 +279,8 @@ def bce_fwd(y: Tensor, y_true: Tensor, ids: Tensor, eps: float = 1e-8, want_grad
     loss = torch.empty(1, dtype=torch.float32, device=y.device)
     dy = torch.empty_like(y) if want_grad else None
     _lib.check(lib.carca_bce_fwd(y.data_ptr(), yt.data_ptr(), ids32.data_ptr(), y.numel(), eps, scratch.data_ptr(),
-                                 loss.data_ptr(), dy.data_ptr() if want_grad else None, _stream()), "bce_fwd")
+                                 loss.data_ptr(), dy.data_ptr() if want_grad else None, _ptr(denom), _stream()),
+               "bce_fwd")
     return loss[0], dy
 
 

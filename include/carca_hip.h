@@ -243,9 +243,12 @@ int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* 
 
 /* ---- a8: BinaryCrossEntropy.forward (carca.py:441-444) -----------------------------------------
  * loss = sum(l * m) / sum(m), l = -(t log(y+eps) + (1-t) log(1-y+eps)), m = (ids != 0).
- * scratch: 2 floats, zeroed by the call; loss_out: 1 float.  dy (optional) receives dloss/dy. */
+ * scratch: 2 floats, written by the call as [sum(l*m), sum(m)]; loss_out: 1 float.  dy (optional)
+ * receives dloss/dy.  denom (optional, device float[1]) replaces sum(m) as the normaliser: with users
+ * sharded over ranks it holds the all-reduced mask count, so that summing the ranks' gradients gives
+ * exactly the single-process batch gradient. */
 int carca_bce_fwd(const float* y, const int32_t* y_true, const int32_t* ids, int n, float eps, float* scratch,
-                  float* loss_out, float* dy /*or NULL*/, void* stream);
+                  float* loss_out, float* dy /*or NULL*/, const float* denom /*or NULL*/, void* stream);
 
 /* ---- M: compute_HR / compute_NDCG (train.py:15-32) without the sort ----------------------------
  * rank[u] = #{j > 0 : y[u][j] > y[u][0]}; sums[0] += [rank < k], sums[1] += [rank<k]/log2(rank+2),

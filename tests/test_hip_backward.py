@@ -107,3 +107,23 @@ def test_gradients_vs_oracle_autograd_c2_like():
     lg.backward()
     assert abs(float(lg) - float(loss)) < 2e-6
     _check_grads(model, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()})
+
+
+def test_engine_train_step_and_eval_batch():
+    """engine.train_step == the reference's loop body (train.py:84-96); eval_batch == train.py:42-51."""
+    from carca_replication_amd import engine
+
+    fx = load("g3_adam")
+    model = model_from_fixture(fx).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0, betas=(0.9, 0.98))
+    batch = tuple(fx.ins[k].cuda() for k in ("p_x", "p_a", "p_c", "o_x", "o_a", "o_c", "y_true"))
+    for step in range(3):
+        loss = engine.train_step(model, opt, batch)
+        assert abs(float(loss) - float(fx.outs[f"loss{step}"])) < 5e-6
+    fx8 = load("g8_ranking")
+    m8 = model_from_fixture(fx8).eval()
+    batch = tuple(fx8.ins[k].cuda() for k in ("p_x", "p_a", "p_c", "o_x", "o_a", "o_c", "y_true"))
+    y, sums = engine.eval_batch(m8, batch, k=10)
+    sums = sums.cpu()
+    assert float(sums[0]) == float(fx8.outs["hr10"]) and abs(float(sums[1]) - float(fx8.outs["ndcg10"])) < 1e-4
+    assert float(sums[2]) == 0.0 and float(sums[4]) == 64.0

@@ -1,0 +1,85 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every declared symbol, the
+nn.Module mirror has the reference's state_dict contract, pickles, and refuses to
+compute on the CPU."""
+import io
+import pickle
+
+import pytest
+import torch
+
+from tests.golden_util import load
+from tests.model_util import build_model, model_from_fixture
+
+
+def test_library_exports_every_declared_symbol():
+    from carca_replication_amd import _lib
+
+    lib = _lib.load()
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.SIGNATURES) == declared
+    assert lib.carca_abi_version() == 1
+
+
+def test_padded_dims_host_logic():
+    from carca_replication_amd import ops, CarcaHipError
+
+    assert ops.padded_dims(90, 3) == (96, 32, 96)
+    assert ops.padded_dims(90, 2) == (96, 48, 96)
+    assert ops.padded_dims(128, 4) == (128, 32, 128)
+    assert ops.padded_dims(64, 2) == (64, 32, 64)
+    with pytest.raises(CarcaHipError):
+        ops.padded_dims(90, 4)  # d % H != 0 (carca.py:208)
+    with pytest.raises(CarcaHipError):
+        ops.padded_dims(256, 2)
+
+
+@pytest.mark.parametrize("name", ["g1_d90h3", "g7_learnable", "g7_positional"])
+def test_state_dict_contract_matches_reference(name):
+    fx = load(name)
+    model = model_from_fixture(fx, device="cpu")  # strict load: same keys
+    sd = model.state_dict()
+    assert set(sd) == set(fx.params)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(fx.params[k].shape), k
+        assert torch.equal(v, fx.params[k])
+
+
+def test_head_divisibility_assert():
+    from carca_replication_amd import modules as M
+
+    with pytest.raises(AssertionError):
+        M.MultiHeadAttention(90, 4, 0.0)
+
+
+def test_model_pickles_like_torch_save_of_whole_module():
+    """train.py:124 does torch.save(model): the packed-weight cache must not break pickling."""
+    model = build_model(dict(d=64, H=2, n_blocks=1), 20, 16, 2, 5, 8)
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    assert set(again.state_dict()) == set(model.state_dict())
+
+
+def test_src_namespace_resolves_like_the_reference():
+    """scripts/training.py:13-30 imports these names from src.*"""
+    from src.abstract import Decoder, Embedding, Encoding  # noqa: F401
+    from src.carca import (CARCA, AllEmbedding, CrossAttentionBlock, IdentityEncoding, LearnableEncoding,  # noqa: F401
+                           PositionalEncoding, SelfAttentionBlock)
+    from src.utils import get_mask, to  # noqa: F401
+
+    assert CARCA.__name__ == "CARCA"
+
+
+def test_cpu_tensors_raise():
+    from carca_replication_amd import CarcaHipError
+
+    fx = load("g1_d90h2")
+    model = model_from_fixture(fx, device="cpu").eval()
+    g = lambda k: fx.ins[k]  # noqa: E731
+    with pytest.raises(CarcaHipError):
+        with torch.no_grad():
+            model(profile=(g("p_x"), g("p_a"), g("p_c")), targets=[(g("o_x"), g("o_a"), g("o_c"))])
