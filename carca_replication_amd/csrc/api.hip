@@ -14,6 +14,14 @@ void carca_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static int g_tuning[CARCA_TUNE_COUNT] = {0};
+int carca_tuning(int key) { return (key >= 0 && key < CARCA_TUNE_COUNT) ? g_tuning[key] : 0; }
+extern "C" int carca_set_tuning(int key, int value) {
+  CARCA_CHECK_ARG(key >= 0 && key < CARCA_TUNE_COUNT, "set_tuning: unknown key %d", key);
+  g_tuning[key] = value;
+  return CARCA_OK;
+}
+
 extern "C" int carca_abi_version(void) { return CARCA_ABI_VERSION; }
 extern "C" const char* carca_last_error(void) { return g_err; }
 

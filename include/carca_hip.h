@@ -40,6 +40,8 @@ extern "C" {
 #define CARCA_EMBED_ALL 7
 
 int carca_abi_version(void);
+/* Kernel-variant knobs for tuning runs (tools/): key 0 row GEMM, key 1 attention kernels; 0 = shipped. */
+int carca_set_tuning(int key, int value);
 const char* carca_last_error(void); /* host string, thread-local, valid until the next call */
 
 /* ------------------------------------------------------------------------------------------
