@@ -163,6 +163,7 @@ _i, _f = C.c_int, C.c_float
 SIGNATURES = {
     "carca_abi_version": (_i, []),
     "carca_set_tuning": (_i, [_i, _i]),
+    "carca_set_debug_buffer": (_i, [_fp]),
     "carca_last_error": (C.c_char_p, []),
     "carca_padded_dims": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "carca_pack_weights": (_i, [C.POINTER(PackDesc), _i, _fp]),

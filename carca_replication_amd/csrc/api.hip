@@ -15,6 +15,12 @@ void carca_set_error(const char* fmt, ...) {
 }
 
 static int g_tuning[CARCA_TUNE_COUNT] = {0};
+static unsigned long long* g_debug = nullptr;
+unsigned long long* carca_debug_buffer() { return g_debug; }
+extern "C" int carca_set_debug_buffer(void* p) {
+  g_debug = (unsigned long long*)p;
+  return CARCA_OK;
+}
 int carca_tuning(int key) { return (key >= 0 && key < CARCA_TUNE_COUNT) ? g_tuning[key] : 0; }
 extern "C" int carca_set_tuning(int key, int value) {
   CARCA_CHECK_ARG(key >= 0 && key < CARCA_TUNE_COUNT, "set_tuning: unknown key %d", key);

@@ -56,10 +56,14 @@ __device__ __forceinline__ void proj_tile_feat_major(const float* __restrict__ W
   const int ln = lane & 15, mq = lane >> 4;
   const float* wrow = Wp + (size_t)(16 * ft + ln) * DPI + 4 * mq;
   const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
+  f32x4 wf[DPI / 16];  // all weight fragments first: their latencies overlap instead of chaining
+#pragma unroll
+  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = glb4(wrow + 16 * kg);
+  const f32x4 bias = glb4(bp + 16 * ft + 4 * mq);
   f32x4 acc = zero4();
 #pragma unroll
-  for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(glb4(wrow + 16 * kg), lds4(xrow + 16 * kg), acc);
-  acc = acc + glb4(bp + 16 * ft + 4 * mq);
+  for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(wf[kg], lds4(xrow + 16 * kg), acc);
+  acc = acc + bias;
   *reinterpret_cast<f32x4*>(out + (16 * st + ln) * so + 16 * ft + 4 * mq) = acc;
   if (save && 16 * st + ln < L)  // [slot][head-padded feature], saved for backward
     *reinterpret_cast<f32x4*>(save + (size_t)(16 * st + ln) * dpo + 16 * ft + 4 * mq) = acc;
@@ -75,10 +79,13 @@ __device__ __forceinline__ void proj_tile_slot_major(const float* __restrict__ W
   const int ln = lane & 15, mq = lane >> 4;
   const float* wrow = Wp + (size_t)(16 * ft + ln) * DPI + 4 * mq;
   const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
+  f32x4 wf[DPI / 16];
+#pragma unroll
+  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = glb4(wrow + 16 * kg);
+  const float bias = bp[16 * ft + ln];
   f32x4 acc = zero4();
 #pragma unroll
-  for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(lds4(xrow + 16 * kg), glb4(wrow + 16 * kg), acc);
-  const float bias = bp[16 * ft + ln];
+  for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(lds4(xrow + 16 * kg), wf[kg], acc);
   f32x4 o = {acc[0] + bias, acc[1] + bias, acc[2] + bias, acc[3] + bias};
   *reinterpret_cast<f32x4*>(out + (16 * ft + ln) * sk + 16 * st + 4 * mq) = o;
   if (save) {  // [slot][head-padded feature]
@@ -108,10 +115,14 @@ __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], cons
 #pragma unroll
   for (int ft = 0; ft < G::NFH; ++ft) {
     const float* wrow = wq + (size_t)(h * DHP + 16 * ft + ln) * DPI + 4 * mq;
+    f32x4 wf[G::NKG];
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = glb4(wrow + 16 * kg);
+    const f32x4 bias = glb4(bq + h * DHP + 16 * ft + 4 * mq);
     f32x4 acc = zero4();
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(glb4(wrow + 16 * kg), qfrag[kg], acc);
-    qt[ft] = acc + glb4(bq + h * DHP + 16 * ft + 4 * mq);
+    for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], qfrag[kg], acc);
+    qt[ft] = acc + bias;
     if (qh_row) *reinterpret_cast<f32x4*>(qh_row + h * DHP + 16 * ft + 4 * mq) = qt[ft];  // saved for backward
   }
   // scores^T tiles: rows = keys, cols = queries
@@ -146,7 +157,7 @@ __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], cons
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = (okbits >> (4 * kt + r)) & 1u;
-      const float e = ok ? expf(p[kt][r] - mx) : 0.f;
+      const float e = ok ? __expf(p[kt][r] - mx) : 0.f;
       p[kt][r] = e;
       sum += e;
     }

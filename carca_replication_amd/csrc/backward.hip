@@ -141,7 +141,7 @@ __device__ __forceinline__ void masked_softmax(f32x4 (&p)[ATT_LT], unsigned okbi
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = (okbits >> (4 * kt + r)) & 1u;
-      const float e = ok ? expf(p[kt][r] - mx) : 0.f;
+      const float e = ok ? __expf(p[kt][r] - mx) : 0.f;
       p[kt][r] = e;
       sum += e;
     }
@@ -433,11 +433,7 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
               }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float v = acc[r] * dl;
-              v += __shfl_xor(v, 1, 64);
-              v += __shfl_xor(v, 2, 64);
-              v += __shfl_xor(v, 4, 64);
-              v += __shfl_xor(v, 8, 64);
+              const float v = row16_sum(acc[r] * dl);
               if (ln == 0) atomicAdd(&dwp[h * DHP + 16 * ft + 4 * mq + r], v);
             }
           }

@@ -36,27 +36,39 @@ __device__ __forceinline__ f32x4 mfma16_group(f32x4 a, f32x4 b, f32x4 c) {
   return c;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane reductions without LDS traffic (__shfl_xor compiles to ds_bpermute: ~100+ cycles a hop) ----
+// all-reduce inside each 16-lane row: four DPP row rotations
+#define CARCA_DPP_ROR(v, n) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x120 + (n), 0xf, 0xf, false))
+__device__ __forceinline__ float row16_sum(float v) {
+  v += CARCA_DPP_ROR(v, 8);
+  v += CARCA_DPP_ROR(v, 4);
+  v += CARCA_DPP_ROR(v, 2);
+  v += CARCA_DPP_ROR(v, 1);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, CARCA_DPP_ROR(v, 8));
+  v = fmaxf(v, CARCA_DPP_ROR(v, 4));
+  v = fmaxf(v, CARCA_DPP_ROR(v, 2));
+  v = fmaxf(v, CARCA_DPP_ROR(v, 1));
   return v;
 }
-// reduce over the four lane quads that share l&15 (lanes l, l^16, l^32, l^48)
+// all-reduce over the four lanes that share l&15 (lanes l, l^16, l^32, l^48): gfx950's row / half swaps.
+// v_permlane16_swap(a, a) leaves {rows 0,0,2,2} and {rows 1,1,3,3}; v_permlane32_swap(a, a) {lo,lo} and {hi,hi}.
 __device__ __forceinline__ float quad4_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float quad4_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+__device__ __forceinline__ float wave_sum(float v) { return quad4_sum(row16_sum(v)); }
+__device__ __forceinline__ float wave_max(float v) { return quad4_max(row16_max(v)); }
 
 __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -75,6 +87,7 @@ void carca_set_error(const char* fmt, ...);
 // tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice
 enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_COUNT = 8 };
 int carca_tuning(int key);
+unsigned long long* carca_debug_buffer();  // device buffer for in-kernel phase stamps (diagnostic runs), or null
 #define CARCA_CHECK_ARG(cond, ...)            \
   do {                                        \
     if (!(cond)) {                            \

@@ -1,11 +1,11 @@
 // K3 + K4: final LayerNorm (carca.py:421) + grouped CrossAttentionBlock.forward (carca.py:338-349).
 //
-// One 8-wave workgroup per user:
+// One 16-wave workgroup per user:
 //   phase A  p = LayerNorm(encoder output) -> LDS                                   (one wave per row)
 //   phase B  K [key][head-padded f] and V^T [head-padded f][key] of p, ONCE per user (the reference
 //            recomputes them per target group, carca.py:424-428; same numbers)
-//   phase C  every 16-target tile of every group is one wave job, all in registers:
-//            Q^T -> scores^T -> masked softmax -> O^T -> y = sigmoid(w . (O + o) + b)
+//   phase C  every (16-target tile, head) of every group is one wave job, all in registers:
+//            Q^T -> scores^T -> masked softmax -> O^T -> partial logit; y = sigmoid(sum_h + w.o + b)
 //            The residual never needs materialising: w.(O + o) = w_pad.O (head-padded order) + w.o.
 //   masking  eval: a target attends every real profile slot; train: tril(diagonal=-1), i.e. target
 //            slot i attends real profile slots j < i, so the first slot attends nothing and scores
@@ -21,115 +21,154 @@ struct GroupsDev {
   int n;
 };
 
+// 16 waves per user; phase C is split into (16-target tile, head) wave jobs so that four waves per SIMD
+// overlap each other's weight-fragment latency; per-head partial logits meet in LDS.
+#define CROSS_TPR 16  // target tiles per round (jobs per round = 16 * H >= 16 waves)
 template <int DPI, int DHP, int NH>
-__global__ __launch_bounds__(512) void cross_score_kernel(const float* __restrict__ p_raw, int ldp,
-                                                          const int32_t* __restrict__ p_ids,
-                                                          float* __restrict__ p_normed, const GroupsDev groups,
-                                                          int ldo, int L, int d, int dh, const CarcaCaWeights w,
-                                                          int residual, int training, const CarcaCaSave sv) {
+__global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __restrict__ p_raw, int ldp,
+                                                               const int32_t* __restrict__ p_ids,
+                                                               float* __restrict__ p_normed,
+                                                               const GroupsDev groups, int ldo, int L, int d, int dh,
+                                                               const CarcaCaWeights w, int residual, int training,
+                                                               const CarcaCaSave sv) {
   using G = AttGeom<DPI, DHP, NH>;
+  constexpr int NW = 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Ps = lds;                    // [64][SI]
-  float* Ks = Ps + ATT_LMAX * G::SI;  // [64][SO]
-  float* Vt = Ks + ATT_LMAX * G::SO;  // [DPO][ATT_SK]
+  float* Ps = lds;                     // [64][SI]
+  float* Ks = Ps + ATT_LMAX * G::SI;   // [64][SO]
+  float* Vt = Ks + ATT_LMAX * G::SO;   // [DPO][ATT_SK]
+  float* Yp = Vt + G::DPO * ATT_SK;    // [CROSS_TPR][NH][16] partial logits
 
   const int u = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int LT = (L + 15) >> 4;
   const int32_t* uid = p_ids + (size_t)u * L;
   const unsigned long long pmask = __ballot(lane < L && uid[lane < L ? lane : 0] != 0);
+  const size_t ubase = (size_t)u * L;
+  const int ln = lane & 15, mq = lane >> 4;
 
-  // ---- phase A: final norm -------------------------------------------------------------------------
-  for (int r = wave; r < 16 * LT; r += 8) {
-    float v0 = 0.f, v1 = 0.f;
+  // ---- A0: rows -> LDS; A1: final norm (wave per row) ------------------------------------------------------
+  constexpr int V4 = DPI / 4;
+  const bool vec_ok = (ldp % 4 == 0) && ldp >= DPI;
+  for (int i = tid; i < 16 * LT * V4; i += 1024) {
+    const int r = i / V4, c4 = i - r * V4;
+    f32x4 v = zero4();
     if (r < L) {
-      const float* xr = p_raw + ((size_t)u * L + r) * ldp;
-      v0 = lane < d ? xr[lane] : 0.f;
-      v1 = lane + 64 < d ? xr[lane + 64] : 0.f;
-      if (w.ln_w) row_layernorm(v0, v1, lane, d, w.ln_w, w.ln_b);  // NULL: p is already normed
+      const float* xr = p_raw + (ubase + r) * ldp + 4 * c4;
+      if (vec_ok) {
+        v = glb4(xr);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 4 * c4 + e < d ? xr[e] : 0.f;
+      }
+    }
+    *reinterpret_cast<f32x4*>(Ps + r * G::SI + 4 * c4) = v;
+  }
+  __syncthreads();
+  if (w.ln_w || p_normed) {
+    for (int r = wave; r < L; r += NW) {
+      float v0 = lane < d ? Ps[r * G::SI + lane] : 0.f;
+      float v1 = lane + 64 < d ? Ps[r * G::SI + lane + 64] : 0.f;
+      if (w.ln_w) row_layernorm(v0, v1, lane, d, w.ln_w, w.ln_b);
+      if (lane < DPI) Ps[r * G::SI + lane] = v0;
+      if (lane + 64 < DPI) Ps[r * G::SI + lane + 64] = v1;
       if (p_normed) {
-        float* pr = p_normed + ((size_t)u * L + r) * ldp;
+        float* pr = p_normed + (ubase + r) * ldp;
         if (lane < ldp) pr[lane] = v0;
         if (lane + 64 < ldp) pr[lane + 64] = v1;
       }
     }
-    if (lane < DPI) Ps[r * G::SI + lane] = v0;
-    if (lane + 64 < DPI) Ps[r * G::SI + lane + 64] = v1;
+    __syncthreads();
   }
-  __syncthreads();
-
-  // ---- phase B: K and V^T ----------------------------------------------------------------------------
+  // ---- B: K and V^T ---------------------------------------------------------------------------------------
   {
     const int nk = G::NF * LT;
-    for (int job = wave; job < 2 * nk; job += 8) {
+    for (int job = wave; job < 2 * nk; job += NW) {
       const bool isv = job >= nk;
       const int jj = isv ? job - nk : job;
       const int ft = jj / LT, st = jj - ft * LT;
       if (!isv)
         proj_tile_feat_major<DPI>(w.wk, w.bk, Ps, G::SI, Ks, G::SO, ft, st, lane,
-                                  sv.kh ? sv.kh + (size_t)u * L * G::DPO : nullptr, G::DPO, L);
+                                  sv.kh ? sv.kh + ubase * G::DPO : nullptr, G::DPO, L);
       else
         proj_tile_slot_major<DPI>(w.wv, w.bv, Ps, G::SI, Vt, ATT_SK, ft, st, lane,
-                                  sv.vh ? sv.vh + (size_t)u * L * G::DPO : nullptr, G::DPO, L);
+                                  sv.vh ? sv.vh + ubase * G::DPO : nullptr, G::DPO, L);
     }
   }
   __syncthreads();
 
-  // ---- phase C: one wave per 16-target tile ------------------------------------------------------------
+  // ---- C: rounds of CROSS_TPR target tiles; job = (tile, head) -----------------------------------------------
   const float sqrt_dh = sqrtf((float)dh);
   const float ffn_b = w.ffn_b[0];
-  const int ln = lane & 15, mq = lane >> 4;
   const int ntiles = groups.tile_start[groups.n];
-  for (int job = wave; job < ntiles; job += 8) {
-    int gi = 0;
+  for (int t0 = 0; t0 < ntiles; t0 += CROSS_TPR) {
+    const int nt = min(CROSS_TPR, ntiles - t0);
+    for (int job = wave; job < nt * NH; job += NW) {
+      const int tl = job / NH, h = job - tl * NH;
+      const int tile = t0 + tl;
+      int gi = 0;
 #pragma unroll
-    for (int i = 1; i < CARCA_MAX_GROUPS; ++i)
-      if (i < groups.n && job >= groups.tile_start[i]) gi = i;
-    const CarcaTargetGroup grp = groups.g[gi];
-    const int qt = job - groups.tile_start[gi];
-    const int n = 16 * qt + ln;  // this lane's target slot
-    const bool in_range = n < grp.N;
-    const size_t row = (size_t)u * grp.N + (in_range ? n : grp.N - 1);
-    const float* orow = grp.o + row * ldo + 4 * mq;
-    f32x4 qfrag[G::NKG];
+      for (int i = 1; i < CARCA_MAX_GROUPS; ++i)
+        if (i < groups.n && tile >= groups.tile_start[i]) gi = i;
+      const CarcaTargetGroup grp = groups.g[gi];
+      const int qt = tile - groups.tile_start[gi];
+      const int n = 16 * qt + ln;
+      const bool in_range = n < grp.N;
+      const size_t row = (size_t)u * grp.N + (in_range ? n : grp.N - 1);
+      const float* orow = grp.o + row * ldo + 4 * mq;
+      f32x4 qfrag[G::NKG];
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) qfrag[kg] = glb4(orow + 16 * kg);
-    const bool q_ok = in_range && grp.ids[row] != 0;
-
-    unsigned okbits = 0;
+      for (int kg = 0; kg < G::NKG; ++kg) qfrag[kg] = glb4(orow + 16 * kg);
+      const bool q_ok = in_range && grp.ids[row] != 0;
+      unsigned okbits = 0;
 #pragma unroll
-    for (int kt = 0; kt < ATT_LT; ++kt)
+      for (int kt = 0; kt < ATT_LT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = 16 * kt + 4 * mq + r;
-        const bool ok = q_ok && ((pmask >> key) & 1ull) && (!training || key < n);
-        okbits |= (ok ? 1u : 0u) << (4 * kt + r);
-      }
-    const int nkt = training ? min(LT, qt + 1) : LT;
-
-    float ypart = 0.f;
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * mq + r;
+          const bool ok = q_ok && ((pmask >> key) & 1ull) && (!training || key < n);
+          okbits |= (ok ? 1u : 0u) << (4 * kt + r);
+        }
+      const int nkt = training ? min(LT, qt + 1) : LT;
       f32x4 oh[G::NFH], p[ATT_LT];
       attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, nkt, okbits, sqrt_dh, oh, p, lane,
                                 (sv.qh[gi] && in_range) ? sv.qh[gi] + row * G::DPO : nullptr);
+      float ypart = 0.f;
 #pragma unroll
       for (int ft = 0; ft < G::NFH; ++ft) {
         const f32x4 wp = glb4(w.ffn_w_pad + h * DHP + 16 * ft + 4 * mq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) ypart += wp[r] * oh[ft][r];
       }
+      if (residual && h == 0) {  // w . o, once per target
+#pragma unroll
+        for (int kg = 0; kg < G::NKG; ++kg) {
+          const f32x4 wv = glb4(w.ffn_w + 16 * kg + 4 * mq);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ypart += wv[r] * qfrag[kg][r];
+        }
+      }
+      ypart = quad4_sum(ypart);
+      if (mq == 0) Yp[(tl * NH + h) * 16 + ln] = ypart;
     }
-    if (residual) {
+    __syncthreads();
+    if (tid < nt * 16) {
+      const int tl = tid >> 4, l16 = tid & 15;
+      const int tile = t0 + tl;
+      int gi = 0;
 #pragma unroll
-      for (int kg = 0; kg < G::NKG; ++kg) {
-        const f32x4 wv = glb4(w.ffn_w + 16 * kg + 4 * mq);
+      for (int i = 1; i < CARCA_MAX_GROUPS; ++i)
+        if (i < groups.n && tile >= groups.tile_start[i]) gi = i;
+      const CarcaTargetGroup grp = groups.g[gi];
+      const int n = 16 * (tile - groups.tile_start[gi]) + l16;
+      if (n < grp.N) {
+        float logit = ffn_b;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ypart += wv[r] * qfrag[kg][r];
+        for (int h = 0; h < NH; ++h) logit += Yp[(tl * NH + h) * 16 + l16];
+        grp.y[(size_t)u * grp.N + n] = 1.0f / (1.0f + expf(-logit));
       }
     }
-    const float logit = quad4_sum(ypart) + ffn_b;
-    if (mq == 0 && in_range) grp.y[row] = 1.0f / (1.0f + expf(-logit));
+    __syncthreads();
   }
 }
 
@@ -138,8 +177,8 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
                  int B, int L, int d, const CarcaCaWeights& w, int residual, int training, const CarcaCaSave& sv,
                  hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
-  const size_t lds_bytes = sizeof(float) * (ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK);
-  auto kern = cross_score_kernel<DPI, DHP, NH>;
+  const size_t lds_bytes = sizeof(float) * (ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK + CROSS_TPR * NH * 16);
+  auto kern = cross_score_kernel_w16<DPI, DHP, NH>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -149,7 +188,7 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L, d,
+  hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L, d,
                      d / NH, w, residual, training, sv);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;

@@ -1,10 +1,10 @@
 // K2: SelfAttentionBlock.forward (carca.py:297-318) incl. MultiHeadAttention.forward (carca.py:228-265),
-// causal = 0, eval mode / dropout p = 0.  One 4-wave workgroup per user, the whole block fused:
-//   phase A  x -> LDS; q = LayerNorm1(x) -> LDS                               (one wave per row)
-//   phase B  K = x W_K^T + b_K  [key][head-padded f];  V^T  [head-padded f][key]   (un-normed x, carca.py:299)
-//   phase C  per 16-query tile, one wave, no further workgroup barrier:
-//            Q^T -> scores^T -> masked softmax -> O^T (registers) -> + q (normed residual, carca.py:301-302)
-//            -> LayerNorm2 -> ffn_1 -> LeakyReLU(0.01) -> ffn_2 -> + s (carca.py:304-316) -> y
+// causal = 0, eval mode / dropout p = 0.  One 16-wave workgroup per user, the whole block fused:
+//   A  x -> LDS; q = LayerNorm1(x) -> LDS                                (one wave per row)
+//   B  K = x W_K^T + b_K [key][head-padded f]; V^T [head-padded f][key]   (un-normed x, carca.py:299)
+//   C1 per (16-query tile, head): Q^T -> scores^T -> masked softmax -> O^T in registers, + q (normed
+//      residual, carca.py:301-302) -> LDS
+//   C2 LayerNorm2 rows; C3 ffn_1 + LeakyReLU(0.01); C4 ffn_2 + s (carca.py:304-316) -> y
 // Rows that are padding (ids == 0) are computed like any other: the reference does not re-mask after a
 // block (carca.py:318), they carry LayerNorm(0) = beta forward and are never attended.
 #include "attn_common.h"
@@ -12,16 +12,30 @@
 
 namespace {
 
+// 16 waves per user: the block is split into many short wave jobs so that four waves per SIMD hide the
+// latency of each other's weight-fragment loads (a 4-wave, one-job-per-query-tile version took 1.5x longer)
+//   A0 x -> LDS (16-byte coalesced)      A1 LayerNorm1 rows (wave per row)        | barrier after each
+//   B  K / V^T tiles                      C1 (query tile, head): attention + residual -> R (LDS, plain order)
+//   C2 LayerNorm2 rows in place           C3 (query tile, f tile): ffn_1 + LeakyReLU -> H1 (LDS)
+//   C4 (query tile, f tile): ffn_2 + residual -> y
 template <int DPI, int DHP, int NH>
-__global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__ x, int ldx,
-                                                       const int32_t* __restrict__ ids, float* __restrict__ y,
-                                                       int ldy, int L, int d, int dh, const CarcaSaWeights w,
-                                                       int residual, const CarcaSaSave sv) {
+__global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restrict__ x, int ldx,
+                                                            const int32_t* __restrict__ ids,
+                                                            float* __restrict__ y, int ldy, int L, int d, int dh,
+                                                            const CarcaSaWeights w, int residual,
+                                                            const CarcaSaSave sv, unsigned long long* stamps) {
   using G = AttGeom<DPI, DHP, NH>;
+  static_assert(G::SO >= G::SI, "H1 reuses the K image");
+#define SA_STAMP(i)                                                                       \
+  do {                                                                                    \
+    if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+  SA_STAMP(0);
+  constexpr int NW = 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Xs = lds;                    // [64][SI]  x, later s2 = LayerNorm2(.)
-  float* Qn = Xs + ATT_LMAX * G::SI;  // [64][SI]  LayerNorm1(x)
-  float* Ks = Qn + ATT_LMAX * G::SI;  // [64][SO]
+  float* Xs = lds;                    // [64][SI]  x -> R -> S2
+  float* Qn = Xs + ATT_LMAX * G::SI;  // [64][SI]
+  float* Ks = Qn + ATT_LMAX * G::SI;  // [64][SO]  K -> H1
   float* Vt = Ks + ATT_LMAX * G::SO;  // [DPO][ATT_SK]
 
   const int u = blockIdx.x;
@@ -29,148 +43,154 @@ __global__ __launch_bounds__(256) void sa_block_kernel(const float* __restrict__
   const int LT = (L + 15) >> 4;
   const int32_t* uid = ids + (size_t)u * L;
   const unsigned long long pmask = __ballot(lane < L && uid[lane < L ? lane : 0] != 0);
+  const size_t ubase = (size_t)u * L;
+  const int ln = lane & 15, mq = lane >> 4;
 
-  // ---- phase A -----------------------------------------------------------------------------------
-  for (int r = wave; r < 16 * LT; r += 4) {
-    float v0 = 0.f, v1 = 0.f;
+  // ---- A0 ---------------------------------------------------------------------------------------------
+  constexpr int V4 = DPI / 4;
+  const bool vec_ok = (ldx % 4 == 0) && ldx >= DPI;  // internal buffers: padded rows with zeroed pad columns
+  for (int i = tid; i < 16 * LT * V4; i += 1024) {
+    const int r = i / V4, c4 = i - r * V4;
+    f32x4 v = zero4();
     if (r < L) {
-      const float* xr = x + ((size_t)u * L + r) * ldx;
-      v0 = lane < d ? xr[lane] : 0.f;
-      v1 = lane + 64 < d ? xr[lane + 64] : 0.f;
+      const float* xr = x + (ubase + r) * ldx + 4 * c4;
+      if (vec_ok) {
+        v = glb4(xr);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 4 * c4 + e < d ? xr[e] : 0.f;
+      }
     }
-    if (lane < DPI) Xs[r * G::SI + lane] = v0;
-    if (lane + 64 < DPI) Xs[r * G::SI + lane + 64] = v1;
+    *reinterpret_cast<f32x4*>(Xs + r * G::SI + 4 * c4) = v;
+  }
+  __syncthreads();
+  SA_STAMP(1);
+  // ---- A1 ---------------------------------------------------------------------------------------------
+  for (int r = wave; r < 16 * LT; r += NW) {
+    float v0 = lane < DPI ? Xs[r * G::SI + lane] : 0.f;
+    float v1 = lane + 64 < DPI ? Xs[r * G::SI + lane + 64] : 0.f;
+    if (lane >= d) v0 = 0.f;
+    if (lane + 64 >= d) v1 = 0.f;
     if (r < L) row_layernorm(v0, v1, lane, d, w.ln1_w, w.ln1_b);
     if (lane < DPI) Qn[r * G::SI + lane] = v0;
     if (lane + 64 < DPI) Qn[r * G::SI + lane + 64] = v1;
     if (sv.qn && r < L) {
-      float* qr = sv.qn + ((size_t)u * L + r) * DPI;
+      float* qr = sv.qn + (ubase + r) * DPI;
       if (lane < DPI) qr[lane] = v0;
       if (lane + 64 < DPI) qr[lane + 64] = v1;
     }
   }
-  __syncthreads();
-
-  // ---- phase B: K and V^T tiles, round-robin over the 4 waves ---------------------------------------
+  SA_STAMP(2);
+  // ---- B (reads Xs only, so no barrier is needed between A1 and B) ---------------------------------------
   {
     const int nk = G::NF * LT;
-    for (int job = wave; job < 2 * nk; job += 4) {
+    for (int job = wave; job < 2 * nk; job += NW) {
       const bool isv = job >= nk;
       const int jj = isv ? job - nk : job;
       const int ft = jj / LT, st = jj - ft * LT;
       if (!isv)
         proj_tile_feat_major<DPI>(w.wk, w.bk, Xs, G::SI, Ks, G::SO, ft, st, lane,
-                                  sv.kh ? sv.kh + (size_t)u * L * G::DPO : nullptr, G::DPO, L);
+                                  sv.kh ? sv.kh + ubase * G::DPO : nullptr, G::DPO, L);
       else
         proj_tile_slot_major<DPI>(w.wv, w.bv, Xs, G::SI, Vt, ATT_SK, ft, st, lane,
-                                  sv.vh ? sv.vh + (size_t)u * L * G::DPO : nullptr, G::DPO, L);
+                                  sv.vh ? sv.vh + ubase * G::DPO : nullptr, G::DPO, L);
     }
   }
   __syncthreads();
+  SA_STAMP(3);
 
-  // ---- phase C ------------------------------------------------------------------------------------
+  // ---- C1: attention per (query tile, head) -----------------------------------------------------------------
   const float sqrt_dh = sqrtf((float)dh);
-  const int ln = lane & 15, mq = lane >> 4;
-  for (int qt = wave; qt < LT; qt += 4) {
-    const int q = 16 * qt + ln;  // this lane's query slot
+  for (int job = wave; job < LT * NH; job += NW) {
+    const int qt = job / NH, h = job - qt * NH;
+    const int q = 16 * qt + ln;
     const bool q_ok = (pmask >> q) & 1ull;
     f32x4 qfrag[G::NKG];
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) qfrag[kg] = lds4(Qn + q * G::SI + 16 * kg + 4 * mq);
-
-    // key 16kt+4mq+r may be attended iff both slots are real items and key <= query (tril, diagonal 0)
     unsigned okbits = 0;
 #pragma unroll
     for (int kt = 0; kt < ATT_LT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * kt + 4 * mq + r;
-        const bool ok = q_ok && key <= q && ((pmask >> key) & 1ull);
-        okbits |= (ok ? 1u : 0u) << (4 * kt + r);
+        okbits |= ((q_ok && key <= q && ((pmask >> key) & 1ull)) ? 1u : 0u) << (4 * kt + r);
       }
-    const int nkt = qt + 1;  // key tiles that can hold a key <= query
-
-    f32x4 o[G::NF];
+    f32x4 oh[G::NFH], p[ATT_LT];
+    attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, qt + 1, okbits, sqrt_dh, oh, p, lane,
+                              (sv.qh && q < L) ? sv.qh + (ubase + q) * G::DPO : nullptr);
+    // r = attention (+ q): plain feature order, into the dead x image (pad columns stay 0)
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      f32x4 oh[G::NFH], p[ATT_LT];
-      attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, nkt, okbits, sqrt_dh, oh, p, lane,
-                                (sv.qh && q < L) ? sv.qh + ((size_t)u * L + q) * G::DPO : nullptr);
-#pragma unroll
-      for (int ft = 0; ft < G::NFH; ++ft) o[h * G::NFH + ft] = oh[ft];
-    }
-
-    // s = attention + q (normed residual); LayerNorm2 over the d real features of the row
-    float part = 0.f;
-#pragma unroll
-    for (int fi = 0; fi < G::NF; ++fi)
+    for (int ft = 0; ft < G::NFH; ++ft)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = unpad_feature(16 * fi + 4 * mq + r, dh, DHP);
-        float v = 0.f;
-        if (j >= 0) v = o[fi][r] + (residual ? Qn[q * G::SI + j] : 0.f);
-        o[fi][r] = v;
-        part += v;
-        if (sv.r && j >= 0 && q < L) sv.r[((size_t)u * L + q) * DPI + j] = v;  // LayerNorm2 input
+        const int fr = 16 * ft + 4 * mq + r;
+        if (fr < dh) {
+          const int j = h * dh + fr;
+          const float v = oh[ft][r] + (residual ? Qn[q * G::SI + j] : 0.f);
+          Xs[q * G::SI + j] = v;
+          if (sv.r && q < L) sv.r[(ubase + q) * DPI + j] = v;
+        }
       }
-    const float inv_d = 1.0f / (float)d;
-    const float mean = quad4_sum(part) * inv_d;
-    part = 0.f;
-#pragma unroll
-    for (int fi = 0; fi < G::NF; ++fi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = unpad_feature(16 * fi + 4 * mq + r, dh, DHP);
-        const float dv = j >= 0 ? o[fi][r] - mean : 0.f;
-        o[fi][r] = dv;
-        part += dv * dv;
-      }
-    const float rstd = 1.0f / sqrtf(quad4_sum(part) * inv_d + 1e-5f);
-    // s2 -> LDS rows of this wave (Xs is dead after phase B; its pad columns are already 0)
-#pragma unroll
-    for (int fi = 0; fi < G::NF; ++fi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = unpad_feature(16 * fi + 4 * mq + r, dh, DHP);
-        if (j >= 0) Xs[q * G::SI + j] = o[fi][r] * rstd * w.ln2_w[j] + w.ln2_b[j];
-      }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    f32x4 s2[G::NKG];
-#pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) {
-      s2[kg] = lds4(Xs + q * G::SI + 16 * kg + 4 * mq);
-      if (sv.s2 && q < L) *reinterpret_cast<f32x4*>(sv.s2 + ((size_t)u * L + q) * DPI + 16 * kg + 4 * mq) = s2[kg];
-    }
-    // ffn_1 + LeakyReLU: H1^T[f][query], kept in registers as the next product's Bt operand
-    f32x4 h1[G::NKG];
-#pragma unroll
-    for (int ft = 0; ft < G::NKG; ++ft) {
-      const float* wrow = w.w1 + (size_t)(16 * ft + ln) * DPI + 4 * mq;
-      f32x4 acc = zero4();
-#pragma unroll
-      for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(glb4(wrow + 16 * kg), s2[kg], acc);
-      acc = acc + glb4(w.b1 + 16 * ft + 4 * mq);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.01f * acc[r];
-      h1[ft] = acc;
-      if (sv.h1 && q < L) *reinterpret_cast<f32x4*>(sv.h1 + ((size_t)u * L + q) * DPI + 16 * ft + 4 * mq) = acc;
-    }
-    // ffn_2 + residual with s2, straight to global (pad columns come out as exact zeros)
-#pragma unroll
-    for (int ft = 0; ft < G::NKG; ++ft) {
-      const float* wrow = w.w2 + (size_t)(16 * ft + ln) * DPI + 4 * mq;
-      f32x4 acc = zero4();
-#pragma unroll
-      for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(glb4(wrow + 16 * kg), h1[kg], acc);
-      acc = acc + glb4(w.b2 + 16 * ft + 4 * mq);
-      if (residual) acc = acc + s2[ft];
-      if (q < L && 16 * ft + 4 * mq < ldy)
-        *reinterpret_cast<f32x4*>(y + ((size_t)u * L + q) * ldy + 16 * ft + 4 * mq) = acc;
+  }
+  __syncthreads();
+  SA_STAMP(4);
+  // ---- C2: LayerNorm2 rows, in place -------------------------------------------------------------------------
+  for (int r = wave; r < 16 * LT; r += NW) {
+    float v0 = lane < d ? Xs[r * G::SI + lane] : 0.f;
+    float v1 = lane + 64 < d ? Xs[r * G::SI + lane + 64] : 0.f;
+    row_layernorm(v0, v1, lane, d, w.ln2_w, w.ln2_b);
+    if (lane < DPI) Xs[r * G::SI + lane] = v0;
+    if (lane + 64 < DPI) Xs[r * G::SI + lane + 64] = v1;
+    if (sv.s2 && r < L) {
+      float* sr = sv.s2 + (ubase + r) * DPI;
+      if (lane < DPI) sr[lane] = v0;
+      if (lane + 64 < DPI) sr[lane + 64] = v1;
     }
   }
+  __syncthreads();
+  SA_STAMP(5);
+  // ---- C3: ffn_1 + LeakyReLU per (query tile, f tile) -> H1 (over the dead K image) ---------------------------
+  float* H1 = Ks;
+  for (int job = wave; job < LT * G::NKG; job += NW) {
+    const int qt = job / G::NKG, ft = job - qt * G::NKG;
+    const int q = 16 * qt + ln;
+    const float* wrow = w.w1 + (size_t)(16 * ft + ln) * DPI + 4 * mq;
+    const float* srow = Xs + q * G::SI + 4 * mq;
+    f32x4 wf[G::NKG];
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = glb4(wrow + 16 * kg);
+    const f32x4 bias = glb4(w.b1 + 16 * ft + 4 * mq);
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], lds4(srow + 16 * kg), acc);
+    acc = acc + bias;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.01f * acc[r];
+    *reinterpret_cast<f32x4*>(H1 + q * G::SI + 16 * ft + 4 * mq) = acc;
+    if (sv.h1 && q < L) *reinterpret_cast<f32x4*>(sv.h1 + (ubase + q) * DPI + 16 * ft + 4 * mq) = acc;
+  }
+  __syncthreads();
+  SA_STAMP(6);
+  // ---- C4: ffn_2 + residual per (query tile, f tile) -> y ------------------------------------------------------
+  for (int job = wave; job < LT * G::NKG; job += NW) {
+    const int qt = job / G::NKG, ft = job - qt * G::NKG;
+    const int q = 16 * qt + ln;
+    const float* wrow = w.w2 + (size_t)(16 * ft + ln) * DPI + 4 * mq;
+    const float* hrow = H1 + q * G::SI + 4 * mq;
+    f32x4 wf[G::NKG];
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = glb4(wrow + 16 * kg);
+    const f32x4 bias = glb4(w.b2 + 16 * ft + 4 * mq);
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], lds4(hrow + 16 * kg), acc);
+    acc = acc + bias;
+    if (residual) acc = acc + lds4(Xs + q * G::SI + 16 * ft + 4 * mq);
+    if (q < L && 16 * ft + 4 * mq < ldy) *reinterpret_cast<f32x4*>(y + (ubase + q) * ldy + 16 * ft + 4 * mq) = acc;
+  }
+  SA_STAMP(7);
+#undef SA_STAMP
 }
 
 template <int DPI, int DHP, int NH>
@@ -178,17 +198,18 @@ int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, in
               const CarcaSaWeights& w, int residual, const CarcaSaSave& sv, hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
   const size_t lds_bytes = sizeof(float) * (2 * ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK);
-  auto kern = sa_block_kernel<DPI, DHP, NH>;
+  const void* kern = (const void*)sa_block_kernel_w16<DPI, DHP, NH>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       carca_set_error("sa_block_fwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_bytes, stream, x, ldx, ids, y, ldy, L, d, d / NH, w, residual, sv);
+  hipLaunchKernelGGL((sa_block_kernel_w16<DPI, DHP, NH>), dim3(B), dim3(1024), lds_bytes, stream, x, ldx, ids, y, ldy, L,
+                     d, d / NH, w, residual, sv, carca_debug_buffer());
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

@@ -42,6 +42,9 @@ extern "C" {
 int carca_abi_version(void);
 /* Kernel-variant knobs for tuning runs (tools/): key 0 row GEMM, key 1 attention kernels; 0 = shipped. */
 int carca_set_tuning(int key, int value);
+/* Diagnostic runs only: device buffer (>= 16 x #workgroups uint64) that the attention kernels fill with
+ * s_memtime stamps at their phase boundaries; NULL (default) disables stamping. */
+int carca_set_debug_buffer(void* device_ptr);
 const char* carca_last_error(void); /* host string, thread-local, valid until the next call */
 
 /* ------------------------------------------------------------------------------------------
