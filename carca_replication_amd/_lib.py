@@ -107,12 +107,13 @@ class PackDesc(C.Structure):
 
 class RowSeg(C.Structure):
     _fields_ = [("ids", _fp), ("attrs", _fp), ("ctx", _fp), ("e_out", _fp), ("rows", C.c_int32), ("T", C.c_int32),
-                ("add_pos", C.c_int32)]
+                ("add_pos", C.c_int32), ("attrs_bstride", C.c_int64), ("ctx_bstride", C.c_int64)]
 
 
 class GemmSeg(C.Structure):
     _fields_ = [("a0", _fp), ("a1", _fp), ("c", _fp), ("ids", _fp), ("add", _fp), ("gate", _fp), ("rowscale", _fp),
-                ("rows", C.c_int32), ("T", C.c_int32), ("add_pos", C.c_int32)]
+                ("rows", C.c_int32), ("T", C.c_int32), ("add_pos", C.c_int32), ("a0_bstride", C.c_int64),
+                ("a1_bstride", C.c_int64)]
 
 
 class GemmDesc(C.Structure):
@@ -124,13 +125,14 @@ class GemmDesc(C.Structure):
 
 
 class WgradSeg(C.Structure):
-    _fields_ = [("dy", _fp), ("x", _fp), ("ids", _fp), ("rows", C.c_int32)]
+    _fields_ = [("dy", _fp), ("x", _fp), ("x1", _fp), ("ids", _fp), ("rows", C.c_int32), ("T", C.c_int32),
+                ("x_bstride", C.c_int64), ("x1_bstride", C.c_int64)]
 
 
 class WgradDesc(C.Structure):
     _fields_ = [("seg", WgradSeg * MAX_SEGS), ("nseg", C.c_int32), ("ld_dy", C.c_int32), ("ld_x", C.c_int32),
-                ("N", C.c_int32), ("K", C.c_int32), ("dw", _fp), ("ldw", C.c_int32), ("db", _fp),
-                ("mask_rows", C.c_int32)]
+                ("ld_x1", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("K1", C.c_int32), ("dw", _fp),
+                ("ldw", C.c_int32), ("db", _fp), ("mask_rows", C.c_int32)]
 
 
 class SaSave(C.Structure):

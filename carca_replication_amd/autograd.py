@@ -59,8 +59,10 @@ class _CarcaFn(torch.autograd.Function):
         d, H = emb.d, dec.attn.H
         dpi, dhp, dpo = ops.padded_dims(d, H)
         B, L = p_x.shape
-        c_ = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731  (train.py:86-88 passes split views)
-        segs = [(c_(p_x), c_(p_a), c_(p_c), False)] + [(c_(o_x), c_(o_a), c_(o_c), True) for (o_x, o_a, o_c) in targets]
+        # train.py:86-88 passes torch.split views: ids are copied (tiny), the dense attrs/ctx views are walked
+        # in place by the kernels (CarcaRowSeg.attrs_bstride / CarcaWgradSeg.x_bstride)
+        c_ = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
+        segs = [(c_(p_x), p_a, p_c, False)] + [(c_(o_x), o_a, o_c, True) for (o_x, o_a, o_c) in targets]
         p_x = segs[0][0]
         es, zq = emb.embed_segments(segs, ld_e=dpi)
         x = es[0]
@@ -191,12 +193,10 @@ class _CarcaFn(torch.autograd.Function):
         for i in range(nseg):
             ops.embed_scatter(dzq[i], ids_seg[i], d, float(d) ** 0.5, g_items)
         g_feats_w, g_feats_b = gbp[id(emb.feats_embed.weight)], gbp[id(emb.feats_embed.bias)]
-        ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x=st["segs"][i][1].view(-1, n_attrs)) for i in range(nseg)], g_feats,
-                       n_attrs, g_feats_w[:, :n_attrs], g_feats_b)
         n_ctx = st["segs"][0][2].shape[-1]
-        if n_ctx > 0:
-            ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x=st["segs"][i][2].view(-1, n_ctx)) for i in range(nseg)], g_feats,
-                           n_ctx, g_feats_w[:, n_attrs:], None)
+        # d feats_embed.weight = dq^T [attrs | ctx]: one launch, the ctx columns ride along as a second X source
+        ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x=st["segs"][i][1], x1=st["segs"][i][2] if n_ctx else None)
+                        for i in range(nseg)], g_feats, n_attrs, g_feats_w, g_feats_b, K1=n_ctx)
         ctx.st = None
         return (None, None, None) + tuple(grads)
 

@@ -525,7 +525,7 @@ extern "C" int carca_layernorm_bwd(const float* dy, int ld_dy, const float* x, i
   CARCA_CHECK_SUPPORTED(d <= 128, "layernorm_bwd: d=%d > 128", d);
   CARCA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
   CARCA_CHECK_ARG(ncols_out <= ld_dx && ncols_out <= 128 && ld_dy >= d && ld_x >= d, "layernorm_bwd: bad strides");
-  const int blocks = min((rows + 3) / 4, 1024);
+  const int blocks = min((rows + 31) / 32, 256);  // >= 8 rows per wave: few blocks contend on dgamma/dbeta
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, ld_dy, x, ld_x, gamma, rows, d,
                      addend, ld_add, dx, ld_dx, ncols_out, dgamma, dbeta);
   CARCA_LAUNCH_CHECK();

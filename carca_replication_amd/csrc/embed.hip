@@ -64,6 +64,7 @@ extern "C" int carca_embed_fwd(const CarcaRowSeg* segs, int nseg, int n_attrs, i
     CarcaGemmSeg& f = fa.seg[s];
     f.a0 = sg.attrs; f.a1 = sg.ctx; f.c = zq + (size_t)row_start * ldz + d; f.ids = sg.ids;
     f.rows = sg.rows; f.T = sg.T; f.add_pos = 0;
+    f.a0_bstride = sg.attrs_bstride; f.a1_bstride = sg.ctx_bstride;
     CarcaGemmSeg& j = ja.seg[s];
     j.a0 = zq + (size_t)row_start * ldz; j.a1 = nullptr; j.c = sg.e_out; j.ids = sg.ids;
     j.rows = sg.rows; j.T = sg.T; j.add_pos = sg.add_pos;

@@ -60,6 +60,16 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
   const int ntiles = nt0 + nt1;
 
   f32x4 ra[A_PER], rbv[B_PER];
+  // element offsets of this thread's A rows inside each k-source (loop invariant; handles [B, T, K] views)
+  size_t aoff0[A_PER], aoff1[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int slot = tid + i * NT;
+    const int gr = min(row0 + slot / C4, sg.rows - 1);
+    const int ub = gr / sg.T, ut = gr - ub * sg.T;
+    aoff0[i] = sg.a0_bstride ? (size_t)ub * sg.a0_bstride + (size_t)ut * D.lda0 : (size_t)gr * D.lda0;
+    aoff1[i] = sg.a1_bstride ? (size_t)ub * sg.a1_bstride + (size_t)ut * D.lda1 : (size_t)gr * D.lda1;
+  }
 
   auto load4 = [](const float* p, bool full, int kk, int klen) -> f32x4 {
     if (full) return *reinterpret_cast<const f32x4_u*>(p);
@@ -75,7 +85,6 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
     const int k0 = (src1 ? t - nt0 : t) * BK;
     const int klen = src1 ? D.K1 : D.K0;
     const float* abase = src1 ? sg.a1 : sg.a0;
-    const int lda = src1 ? D.lda1 : D.lda0;
     const float* bbase = src1 ? D.bt1 : D.bt0;
     const int ldb = src1 ? D.ldb1 : D.ldb0;
     const bool full = k0 + BK <= klen;  // block-uniform
@@ -83,9 +92,8 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
     for (int i = 0; i < A_PER; ++i) {
       const int slot = tid + i * NT;
       if (A_SLOTS % NT != 0 && slot >= A_SLOTS) break;
-      const int r = slot / C4, c4 = slot - r * C4;
-      const int gr = min(row0 + r, sg.rows - 1);
-      ra[i] = load4(abase + (size_t)gr * lda + k0 + c4 * 4, full, k0 + c4 * 4, klen);
+      const int c4 = slot % C4;
+      ra[i] = load4(abase + (src1 ? aoff1[i] : aoff0[i]) + k0 + c4 * 4, full, k0 + c4 * 4, klen);
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
@@ -176,7 +184,7 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
 struct WgradDev {
   CarcaWgradDesc d;
   int chunk_start[CARCA_MAX_SEGS + 1];  // 32-row chunks per segment, prefix sums
-  int nnb, nkb, nsplit, chunks_per_split;
+  int nnb, nkb, nkb0, nsplit, chunks_per_split;
 };
 
 template <int BNO, int BKO, int BR>
@@ -193,10 +201,13 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
   b /= args.nkb;
   const int nb = b % args.nnb;
   const int split = b / args.nnb;
-  const int n0 = nb * BNO, k0 = kb * BKO;
+  const bool src1 = kb >= args.nkb0;  // this block's dW columns come from the second X source
+  const int n0 = nb * BNO, k0 = (src1 ? kb - args.nkb0 : kb) * BKO;
+  const int klen = src1 ? D.K1 : D.K;
+  const int ldx = src1 ? D.ld_x1 : D.ld_x;
   const int c_begin = split * args.chunks_per_split;
   const int c_end = min(c_begin + args.chunks_per_split, args.chunk_start[D.nseg]);
-  const bool n_full = n0 + BNO <= D.N, k_full = k0 + BKO <= D.K;
+  const bool n_full = n0 + BNO <= D.N, k_full = k0 + BKO <= klen;
 
   constexpr int Y4 = BNO / 4, X4 = BKO / 4;                            // float4 per tile row
   constexpr int Y_PER = BR * Y4 / NT, X_PER = BR * X4 / NT;            // 3, 4
@@ -238,15 +249,17 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
       const int row = r0 + r;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < sg.rows) {
-        const float* p = sg.x + (size_t)row * D.ld_x + k0 + c4 * 4;
+        const int64_t bs = src1 ? sg.x1_bstride : sg.x_bstride;
+        const size_t roff = bs ? (size_t)(row / sg.T) * bs + (size_t)(row % sg.T) * ldx : (size_t)row * ldx;
+        const float* p = (src1 ? sg.x1 : sg.x) + roff + k0 + c4 * 4;
         if (k_full) {
           v = *reinterpret_cast<const f32x4_u*>(p);
         } else {
           const int kk = k0 + c4 * 4;
-          v[0] = kk + 0 < D.K ? p[0] : 0.f;
-          v[1] = kk + 1 < D.K ? p[1] : 0.f;
-          v[2] = kk + 2 < D.K ? p[2] : 0.f;
-          v[3] = kk + 3 < D.K ? p[3] : 0.f;
+          v[0] = kk + 0 < klen ? p[0] : 0.f;
+          v[1] = kk + 1 < klen ? p[1] : 0.f;
+          v[2] = kk + 2 < klen ? p[2] : 0.f;
+          v[3] = kk + 3 < klen ? p[3] : 0.f;
         }
       }
       rx[i] = v;
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
   for (int c = c_begin; c < c_end; ++c) {
     if (c + 1 < c_end) load_chunk(c + 1);
     // D[m = n index][n = k index] = sum_r Ys[r][m] * Xs[r][n]:  A lane (i, kk) = Ys[2s + kk][i]
-#pragma unroll
+#pragma unroll 4
     for (int st = 0; st < BR / 2; ++st) {
       const int r = 2 * st + lh;
       const float xb = Xs[r * BKO + wave * 32 + lr];
@@ -304,13 +317,14 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
 
   // D row (= n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (= k) = lane&31
   const int k = k0 + wave * 32 + lr;
-  if (k < D.K) {
+  if (k < klen) {
+    const int kcol = (src1 ? D.K : 0) + k;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < D.N) atomicAdd(&D.dw[(size_t)n * D.ldw + k], acc[t][r]);
+        if (n < D.N) atomicAdd(&D.dw[(size_t)n * D.ldw + kcol], acc[t][r]);
       }
   }
   if (D.db && kb == 0 && tid < BNO && n0 + tid < D.N) atomicAdd(&D.db[n0 + tid], bsum);
@@ -334,6 +348,9 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   for (int s = 0; s < desc->nseg; ++s) {
     const CarcaGemmSeg& sg = desc->seg[s];
     CARCA_CHECK_ARG(sg.rows >= 1 && sg.a0 && sg.c && (desc->K1 == 0 || sg.a1), "gemm_rows: segment %d malformed", s);
+    CARCA_CHECK_ARG(sg.T >= 1 || (!sg.a0_bstride && !sg.a1_bstride && !sg.add_pos), "gemm_rows: segment %d needs T >= 1",
+                    s);
+    if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
     CARCA_CHECK_ARG(!(sg.add_pos && (!desc->pos || sg.T < 1 || !sg.ids)) && !(desc->mask_rows && !sg.ids) &&
                         !(sg.rowscale && !desc->colvec),
                     "gemm_rows: segment %d epilogue needs a pointer that is NULL", s);
@@ -352,8 +369,8 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
 extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(desc && desc->nseg >= 1 && desc->nseg <= CARCA_MAX_SEGS, "gemm_wgrad: bad segment count");
-  CARCA_CHECK_ARG(desc->dw && desc->N >= 1 && desc->K >= 1 && desc->ldw >= desc->K && desc->ld_dy >= desc->N &&
-                      desc->ld_x >= desc->K,
+  CARCA_CHECK_ARG(desc->dw && desc->N >= 1 && desc->K >= 1 && desc->K1 >= 0 && desc->ldw >= desc->K + desc->K1 &&
+                      desc->ld_dy >= desc->N && desc->ld_x >= desc->K && (desc->K1 == 0 || desc->ld_x1 >= desc->K1),
                   "gemm_wgrad: bad geometry");
   constexpr int BNO = 96, BKO = 128, BR = 32;
   WgradDev g{};
@@ -361,17 +378,21 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   int chunks = 0;
   for (int s = 0; s < desc->nseg; ++s) {
     const CarcaWgradSeg& sg = desc->seg[s];
-    CARCA_CHECK_ARG(sg.rows >= 1 && sg.dy && sg.x && !(desc->mask_rows && !sg.ids), "gemm_wgrad: segment %d malformed",
-                    s);
+    CARCA_CHECK_ARG(sg.rows >= 1 && sg.dy && sg.x && !(desc->mask_rows && !sg.ids) && (desc->K1 == 0 || sg.x1),
+                    "gemm_wgrad: segment %d malformed", s);
+    CARCA_CHECK_ARG(sg.T >= 1 || (!sg.x_bstride && !sg.x1_bstride), "gemm_wgrad: segment %d needs T >= 1", s);
+    if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
     g.chunk_start[s] = chunks;
     chunks += (sg.rows + BR - 1) / BR;
   }
   g.chunk_start[desc->nseg] = chunks;
   g.nnb = (desc->N + BNO - 1) / BNO;
-  g.nkb = (desc->K + BKO - 1) / BKO;
-  // enough row splits for ~3 blocks per CU, but at least 4 chunks (128 rows) per split
+  g.nkb0 = (desc->K + BKO - 1) / BKO;
+  g.nkb = g.nkb0 + (desc->K1 + BKO - 1) / BKO;
+  // row splits: fill the chip's 2 x 256 resident slots in ONE round (the kernel holds 2 blocks per CU),
+  // but keep at least 4 chunks (128 rows) per split
   const int tiles = g.nnb * g.nkb;
-  int nsplit = (768 + tiles - 1) / tiles;
+  int nsplit = tiles >= 512 ? 1 : 512 / tiles;
   nsplit = max(1, min(nsplit, (chunks + 3) / 4));
   g.chunks_per_split = (chunks + nsplit - 1) / nsplit;
   g.nsplit = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;

@@ -49,6 +49,20 @@ def _ids32(t: Tensor) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _btk_view(t: Tensor) -> Tuple[Tensor, int]:
+    """[B, T, K] fp32 tensor -> (tensor the kernels can walk, user stride in elements or 0 when dense).
+
+    A view whose rows are dense (stride(2) == 1, stride(1) == K) but whose users are further apart -- e.g.
+    o_a[:, :L] of train.py:86-88 -- is passed through without a copy; anything else is made contiguous."""
+    if t.dtype != torch.float32:
+        raise CarcaHipError(f"expected float32, got {t.dtype}")
+    B, T, K = t.shape
+    if K > 0 and t.stride(2) == 1 and t.stride(1) == K and (B == 1 or t.stride(0) >= T * K):
+        bs = t.stride(0) if B > 1 else T * K
+        return t, (0 if bs == T * K else bs)
+    return t.contiguous(), 0
+
+
 def padded_dims(d: int, H: int) -> Tuple[int, int, int]:
     lib = _lib.load()
     a, b, c = C.c_int(), C.c_int(), C.c_int()
@@ -150,15 +164,18 @@ def embed_fwd(segs: Sequence[Tuple[Tensor, Tensor, Tensor, bool]], items_w: Tens
     for i, (ids, attrs, ctx, add_pos) in enumerate(segs):
         _need_cuda(ids, attrs, ctx)
         B, T = ids.shape
-        ids32, attrs, ctx = _ids32(ids), _f32(attrs), _f32(ctx)
         if attrs.shape != (B, T, n_attrs) or ctx.shape != (B, T, n_ctx):
             raise CarcaHipError("embed_fwd: attrs/ctx shapes do not match ids")
+        ids32 = _ids32(ids)
+        attrs, a_bs = _btk_view(attrs)
+        ctx, c_bs = _btk_view(ctx) if n_ctx > 0 else (ctx, 0)
         e = torch.empty(B, T, ld_e, dtype=torch.float32, device=dev)
         keep += [ids32, attrs, ctx]
         outs.append(e)
         a = arr[i]
         a.ids, a.attrs, a.ctx, a.e_out = ids32.data_ptr(), attrs.data_ptr(), ctx.data_ptr(), e.data_ptr()
         a.rows, a.T, a.add_pos = B * T, T, int(bool(add_pos))
+        a.attrs_bstride, a.ctx_bstride = a_bs, c_bs
         total += B * T
     zq = torch.empty(total, d + g, dtype=torch.float32, device=dev)
     pos_ptr = None
@@ -379,30 +396,50 @@ def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[
     return outs
 
 
-def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, mask_rows: bool = False) -> None:
+def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, mask_rows: bool = False,
+               K1: int = 0) -> None:
     """dw[n][k] += sum_r dy[r][n] x[r][k] (and db[n] += sum_r dy[r][n]) over all segments' rows.
 
-    segs: list of dicts with dy [rows, >=N], x [rows, >=K], optional ids.  dw is a 2-D fp32 view (unit inner stride).
+    segs: list of dicts with dy [rows, >=N]; x either [rows, >=K] (2-D) or a [B, T, K] view (3-D, users may be
+    strided); optional x1 likewise for dw[:, K:K+K1]; optional ids.  dw is a 2-D fp32 view (unit inner stride).
     """
     lib = _lib.load()
     D = _lib.WgradDesc()
     D.nseg = len(segs)
     keep = []
-    ld_dy = ld_x = None
+    ld_dy = ld_x = ld_x1 = None
+
+    def xinfo(x, name):
+        _need_cuda(x)
+        if x.dim() == 3:
+            x, bs = _btk_view(x)
+            keep.append(x)
+            return x.data_ptr(), x.shape[2], x.shape[0] * x.shape[1], x.shape[1], bs
+        if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32:
+            raise CarcaHipError(f"gemm_wgrad: {name} must be a 2-D fp32 view with unit inner stride or a [B,T,K] tensor")
+        return x.data_ptr(), x.stride(0), x.shape[0], 1, 0
+
     for i, sg in enumerate(segs):
-        dy, x = sg["dy"], sg["x"]
-        for t in (dy, x):
-            _need_cuda(t)
-            if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
-                raise CarcaHipError("gemm_wgrad: dy/x must be 2-D fp32 views with unit inner stride")
-        if dy.shape[0] != x.shape[0]:
+        dy = sg["dy"]
+        _need_cuda(dy)
+        if dy.dim() != 2 or dy.stride(1) != 1 or dy.dtype != torch.float32:
+            raise CarcaHipError("gemm_wgrad: dy must be a 2-D fp32 view with unit inner stride")
+        xp, lx, xrows, xT, xbs = xinfo(sg["x"], "x")
+        if dy.shape[0] != xrows:
             raise CarcaHipError("gemm_wgrad: dy and x row counts differ")
         ld_dy = dy.stride(0) if ld_dy is None else ld_dy
-        ld_x = x.stride(0) if ld_x is None else ld_x
-        if dy.stride(0) != ld_dy or x.stride(0) != ld_x:
+        ld_x = lx if ld_x is None else ld_x
+        if dy.stride(0) != ld_dy or lx != ld_x:
             raise CarcaHipError("gemm_wgrad: all segments must share row strides")
         S = D.seg[i]
-        S.dy, S.x, S.rows = dy.data_ptr(), x.data_ptr(), dy.shape[0]
+        S.dy, S.x, S.rows, S.T, S.x_bstride = dy.data_ptr(), xp, dy.shape[0], xT, xbs
+        if K1:
+            x1p, lx1, x1rows, x1T, x1bs = xinfo(sg["x1"], "x1")
+            if x1rows != xrows or (xbs and x1bs and x1T != xT):
+                raise CarcaHipError("gemm_wgrad: x1 does not match x")
+            ld_x1 = lx1 if ld_x1 is None else ld_x1
+            S.x1, S.x1_bstride = x1p, x1bs
+            S.T = max(xT, x1T)
         ids = sg.get("ids")
         if ids is not None:
             ids = _ids32(ids.reshape(-1))
@@ -410,7 +447,7 @@ def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, ma
             S.ids = ids.data_ptr()
     if dw.dim() != 2 or dw.stride(1) != 1 or dw.dtype != torch.float32:
         raise CarcaHipError("gemm_wgrad: dw must be a 2-D fp32 view with unit inner stride")
-    D.ld_dy, D.ld_x, D.N, D.K = ld_dy, ld_x, N, K
+    D.ld_dy, D.ld_x, D.ld_x1, D.N, D.K, D.K1 = ld_dy, ld_x, ld_x1 or 0, N, K, K1
     D.dw, D.ldw, D.db, D.mask_rows = dw.data_ptr(), dw.stride(0), _ptr(db), int(mask_rows)
     _lib.check(lib.carca_gemm_wgrad(C.byref(D), _stream()), "gemm_wgrad")
 

@@ -91,6 +91,9 @@ typedef struct CarcaGemmSeg {
   const float* gate;     /* [rows, ld_gate] or NULL */
   const float* rowscale; /* [rows] or NULL */
   int32_t rows, T, add_pos;
+  /* Rows of a0 / a1 may belong to a [B, T, K] VIEW whose users are a0_bstride / a1_bstride elements apart
+   * (e.g. o_a[:, :L] of train.py:86-88): row r then starts at (r / T) * bstride + (r % T) * lda.  0 = dense. */
+  int64_t a0_bstride, a1_bstride;
 } CarcaGemmSeg;
 typedef struct CarcaGemmDesc {
   CarcaGemmSeg seg[CARCA_MAX_SEGS];
@@ -116,15 +119,18 @@ int carca_gemm_rows(const CarcaGemmDesc* desc /*host*/, void* stream);
  * are skipped when mask_rows (the e * mask of carca.py:94 seen from the backward side). */
 typedef struct CarcaWgradSeg {
   const float* dy;    /* [rows, ld_dy] */
-  const float* x;     /* [rows, ld_x] */
+  const float* x;     /* [rows, ld_x]  -> dW[:, 0:K] */
+  const float* x1;    /* [rows, ld_x1] -> dW[:, K:K+K1], or NULL when K1 == 0 */
   const int32_t* ids; /* [rows] or NULL */
   int32_t rows;
+  int32_t T;                     /* rows per user, used with the strides below */
+  int64_t x_bstride, x1_bstride; /* users of a [B, T, K] view are this many elements apart; 0 = dense */
 } CarcaWgradSeg;
 typedef struct CarcaWgradDesc {
   CarcaWgradSeg seg[CARCA_MAX_SEGS];
   int32_t nseg;
-  int32_t ld_dy, ld_x;
-  int32_t N, K; /* dW is [N, K] */
+  int32_t ld_dy, ld_x, ld_x1;
+  int32_t N, K, K1; /* dW is [N, K + K1] */
   float* dw;
   int32_t ldw;
   float* db; /* [N] or NULL */
@@ -149,6 +155,7 @@ typedef struct CarcaRowSeg {
   int32_t rows;       /* B * T */
   int32_t T;          /* slots per user (position index = row % T) */
   int32_t add_pos;    /* 1: add pos[row % T] (profile side, carca.py:91-92) */
+  int64_t attrs_bstride, ctx_bstride; /* elements between users when attrs/ctx are [B, T, .] views; 0 = dense */
 } CarcaRowSeg;
 int carca_embed_fwd(const CarcaRowSeg* segs /*host*/, int nseg, int n_attrs, int n_ctx, int d, int g,
                     const float* items_w /*[n_items,d]*/, const float* feats_w /*[g,n_attrs+n_ctx]*/,
