@@ -85,7 +85,7 @@ __device__ __forceinline__ int unpad_feature(int fp, int dh, int dhp) {
 
 void carca_set_error(const char* fmt, ...);
 // tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice
-enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_COUNT = 8 };
+enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_COUNT = 8 };
 int carca_tuning(int key);
 unsigned long long* carca_debug_buffer();  // device buffer for in-kernel phase stamps (diagnostic runs), or null
 #define CARCA_CHECK_ARG(cond, ...)            \

@@ -389,10 +389,11 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   g.nnb = (desc->N + BNO - 1) / BNO;
   g.nkb0 = (desc->K + BKO - 1) / BKO;
   g.nkb = g.nkb0 + (desc->K1 + BKO - 1) / BKO;
-  // row splits: fill the chip's 2 x 256 resident slots in ONE round (the kernel holds 2 blocks per CU),
-  // but keep at least 4 chunks (128 rows) per split
+  // row splits: fill the chip's 4 x 256 resident slots in ONE round (119 registers -> 4 blocks per CU;
+  // measured at C2: 512 slots 1017 us, 768 972, 1024 809, 1536 865), but keep >= 4 chunks (128 rows) per split
   const int tiles = g.nnb * g.nkb;
-  int nsplit = tiles >= 512 ? 1 : 512 / tiles;
+  const int slots = carca_tuning(CARCA_TUNE_WGRAD_SLOTS) > 0 ? carca_tuning(CARCA_TUNE_WGRAD_SLOTS) : 1024;
+  int nsplit = tiles >= slots ? 1 : slots / tiles;
   nsplit = max(1, min(nsplit, (chunks + 3) / 4));
   g.chunks_per_split = (chunks + nsplit - 1) / nsplit;
   g.nsplit = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;
