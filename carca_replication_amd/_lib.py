@@ -121,7 +121,8 @@ class GemmDesc(C.Structure):
                 ("K0", C.c_int32), ("K1", C.c_int32), ("bt0", _fp), ("bt1", _fp), ("ldb0", C.c_int32),
                 ("ldb1", C.c_int32), ("N", C.c_int32), ("ldc", C.c_int32), ("ncols_out", C.c_int32), ("bias", _fp),
                 ("pos", _fp), ("colvec", _fp), ("ld_add", C.c_int32), ("ld_gate", C.c_int32),
-                ("gate_slope", C.c_float), ("mask_rows", C.c_int32)]
+                ("gate_slope", C.c_float), ("mask_rows", C.c_int32), ("gate_scale", C.c_float),
+                ("gate_zero_drops", C.c_int32)]
 
 
 class WgradSeg(C.Structure):
@@ -135,16 +136,21 @@ class WgradDesc(C.Structure):
                 ("ldw", C.c_int32), ("db", _fp), ("mask_rows", C.c_int32)]
 
 
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("site", C.c_uint32)]
+
+
 class SaSave(C.Structure):
-    _fields_ = [(n, _fp) for n in ("qn", "qh", "kh", "vh", "r", "s2", "h1")]
+    _fields_ = [(n, _fp) for n in ("qn", "qh", "kh", "vh", "r", "s2", "h1", "m_attn", "m_ffn1", "m_ffn2")]
 
 
 class CaSave(C.Structure):
-    _fields_ = [("kh", _fp), ("vh", _fp), ("qh", _fp * MAX_GROUPS)]
+    _fields_ = [("kh", _fp), ("vh", _fp), ("qh", _fp * MAX_GROUPS), ("m_attn", _fp * MAX_GROUPS)]
 
 
 class CrossBwdGroup(C.Structure):
-    _fields_ = [("qh", _fp), ("y", _fp), ("dy", _fp), ("ids", _fp), ("dqh", _fp), ("dlogit", _fp), ("N", C.c_int32)]
+    _fields_ = [("qh", _fp), ("y", _fp), ("dy", _fp), ("ids", _fp), ("dqh", _fp), ("dlogit", _fp), ("m_attn", _fp),
+                ("N", C.c_int32)]
 
 
 class SaWeights(C.Structure):
@@ -173,15 +179,17 @@ SIGNATURES = {
     "carca_gemm_rows": (_i, [C.POINTER(GemmDesc), _fp]),
     "carca_gemm_wgrad": (_i, [C.POINTER(WgradDesc), _fp]),
     "carca_sa_block_fwd": (_i, [_fp, _i, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SaWeights), _i, C.POINTER(SaSave),
-                                _fp]),
+                                C.POINTER(Dropout), _fp]),
     "carca_cross_score_fwd": (_i, [_fp, _i, _fp, _fp, C.POINTER(TargetGroup), _i, _i, _i, _i, _i, _i,
-                                   C.POINTER(CaWeights), _i, _i, C.POINTER(CaSave), _fp]),
+                                   C.POINTER(CaWeights), _i, _i, C.POINTER(CaSave), C.POINTER(Dropout), _fp]),
+    "carca_dropout_fwd": (_i, [_fp, _i, _i, _i, C.POINTER(Dropout), _fp, _fp]),
+    "carca_mask_mul": (_i, [_fp, _i, _fp, _i, _f, _fp, _i, _i, _i, _i, _fp]),
     "carca_layernorm_bwd": (_i, [_fp, _i, _fp, _i, _fp, _i, _i, _fp, _i, _fp, _i, _i, _fp, _fp, _fp]),
     "carca_embed_scatter": (_i, [_fp, _i, _fp, _i, _i, _f, _fp, _fp]),
     "carca_colsum": (_i, [_fp, _i, _i, _i, _fp, _fp, _i, _fp, _fp]),
-    "carca_sa_attn_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    "carca_sa_attn_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _f, _fp]),
     "carca_cross_attn_bwd": (_i, [_fp, _fp, _fp, C.POINTER(CrossBwdGroup), _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i,
-                                  _fp]),
+                                  _f, _fp]),
     "carca_unpack_grads": (_i, [C.POINTER(PackDesc), _i, _i, _fp]),
     "carca_bce_fwd": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp, _fp]),
     "carca_rank_metrics": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),

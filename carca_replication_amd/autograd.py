@@ -66,21 +66,34 @@ class _CarcaFn(torch.autograd.Function):
         p_x = segs[0][0]
         es, zq = emb.embed_segments(segs, ld_e=dpi)
         x = es[0]
+        # one seed per forward; every dropout site hashes (seed, site id, element index)  (include/carca_hip.h)
+        seed = ops.new_dropout_seed() if model.training else 0
+        p_emb = float(model.dropout.p) if model.training else 0.0
+        m_embed = ops.dropout_fwd(x, d, p_emb, seed, 1000) if p_emb > 0 else None  # carca.py:416
         blocks = []
-        for blk in model.encoder:
+        for i, blk in enumerate(model.encoder):
             blk._check_mode()
-            y, saved = ops.sa_block_fwd(x, p_x, blk.weights_struct(x.device), d, blk.attn.H, blk.residual, save=True)
+            bp = blk.drop_p()
+            y, saved = ops.sa_block_fwd(x, p_x, blk.weights_struct(x.device), d, blk.attn.H, blk.residual, save=True,
+                                        drop=(bp, seed, 4 * i) if bp > 0 else None)
             saved["x_in"] = x
+            saved["p"] = bp
             blocks.append(saved)
             x = y
         dec._check_mode()
         groups = [(es[gi + 1], segs[gi + 1][0]) for gi in range(len(targets))]
         cw = dec.weights_struct(x.device, model.norm)
-        ys, p_normed, csave = ops.cross_score_fwd(x, p_x, groups, cw, d, H, dec.residual, model.training, save=True)
+        dp_ = dec.drop_p()
+        ys, p_normed, csave = ops.cross_score_fwd(x, p_x, groups, cw, d, H, dec.residual, model.training, save=True,
+                                                  drop=(dp_, seed, 2000) if dp_ > 0 else None)
+        csave["p"] = dp_
+        if getattr(model, "_keep_dropout_masks", False):  # test hook: lets a test replay the reference with these masks
+            model._last_dropout_masks = dict(embed=m_embed, blocks=[{k: v for k, v in b.items() if k.startswith("m_")}
+                                                                    for b in blocks], cross=csave.get("m_attn"))
         ctx.model = model
         ctx.params = params
         ctx.st = dict(p_x=p_x, segs=segs, es=es, zq=zq, blocks=blocks, enc_out=x, p_normed=p_normed, csave=csave,
-                      training=model.training, cw=cw, B=B, L=L, ngroups=len(ys))
+                      training=model.training, cw=cw, B=B, L=L, ngroups=len(ys), m_embed=m_embed, p_emb=p_emb)
         ctx.save_for_backward(*ys)
         return tuple(ys)
 
@@ -109,8 +122,11 @@ class _CarcaFn(torch.autograd.Function):
             dy = dys[gi] if dys[gi] is not None else torch.zeros_like(ys[gi])
             bgroups.append((st["csave"]["qh"][gi], ys[gi], dy.contiguous(), st["segs"][gi + 1][0]))
         ffn_w_pad_ptr = st["cw"].ffn_w_pad
+        cpd = st["csave"]["p"]
         dqhs, dls, dkh, dvh = ops.cross_attn_bwd(st["csave"]["kh"], st["csave"]["vh"], p_x, bgroups, ffn_w_pad_ptr,
-                                                 d_wpad, B, L, d, H, st["training"])
+                                                 d_wpad, B, L, d, H, st["training"],
+                                                 masks=st["csave"].get("m_attn") if cpd > 0 else None,
+                                                 drop_scale=1.0 / (1.0 - cpd) if cpd > 0 else 1.0)
         g_ffn_w, g_ffn_b = gbp[id(dec.ffn.weight)], gbp[id(dec.ffn.bias)]
         o_rows = [st["es"][gi + 1].view(-1, dpi) for gi in range(ngroups)]
         o_ids = [st["segs"][gi + 1][0] for gi in range(ngroups)]
@@ -147,9 +163,13 @@ class _CarcaFn(torch.autograd.Function):
             w1_t, w2_t = bp.wT.view(3), bp.wT.view(4)
             x_in = sv["x_in"].view(-1, dpi)
             dy = dx
-            # f = ffn_2(lrelu(ffn_1(s))) (+ s)
-            (dh1pre,) = ops.gemm_rows([dict(a0=dy, gate=sv["h1"])], w2_t, d, d, dpi, gate_slope=0.01)
-            ops.gemm_wgrad([dict(dy=dy, x=sv["h1"])], d, d, gbp[id(blk.ffn_2.weight)].view(d, d),
+            bp_ = sv["p"]
+            bscale = 1.0 / (1.0 - bp_) if bp_ > 0 else 1.0
+            # f = dropout2(ffn_2(dropout1(lrelu(ffn_1(s))))) (+ s): the f branch sees dy * mask2 / (1-p)
+            dyf = ops.mask_mul(dy, sv["m_ffn2"], bscale, d, dpi) if bp_ > 0 else dy
+            (dh1pre,) = ops.gemm_rows([dict(a0=dyf, gate=sv["h1"])], w2_t, d, d, dpi, gate_slope=0.01,
+                                      gate_scale=bscale, gate_zero_drops=bp_ > 0)
+            ops.gemm_wgrad([dict(dy=dyf, x=sv["h1"])], d, d, gbp[id(blk.ffn_2.weight)].view(d, d),
                            gbp[id(blk.ffn_2.bias)])
             (ds,) = ops.gemm_rows([dict(a0=dh1pre, add=dy if blk.residual else None)], w1_t, d, d, dpi)
             ops.gemm_wgrad([dict(dy=dh1pre, x=sv["s2"])], d, d, gbp[id(blk.ffn_1.weight)].view(d, d),
@@ -157,7 +177,8 @@ class _CarcaFn(torch.autograd.Function):
             # s = LayerNorm2(r), r = attention (+ q)
             dr = ops.layernorm_bwd(ds, sv["r"], blk.norm2.weight.detach(), d, dpi, dgamma=gbp[id(blk.norm2.weight)],
                                    dbeta=gbp[id(blk.norm2.bias)])
-            dqh, dkh_b, dvh_b = ops.sa_attn_bwd(sv["qh"], sv["kh"], sv["vh"], dr, p_x, B, L, d, blk.attn.H)
+            dqh, dkh_b, dvh_b = ops.sa_attn_bwd(sv["qh"], sv["kh"], sv["vh"], dr, p_x, B, L, d, blk.attn.H,
+                                                m_attn=sv.get("m_attn") if bp_ > 0 else None, drop_scale=bscale)
             bq_t, bk_t, bv_t = bp.wT.view(0), bp.wT.view(1), bp.wT.view(2)
             (dqn,) = ops.gemm_rows([dict(a0=dqh, add=dr if blk.residual else None)], bq_t, d, dpo, dpi)
             (dx_kv,) = ops.gemm_rows([dict(a0=dkh_b, a1=dvh_b)], bk_t, d, dpo, dpi, bt1=bv_t, K1=dpo)
@@ -170,6 +191,8 @@ class _CarcaFn(torch.autograd.Function):
                                    dgamma=gbp[id(blk.norm1.weight)], dbeta=gbp[id(blk.norm1.bias)])
 
         # ---------------- embedding (carca.py:85-95) ---------------------------------------------------
+        if st["p_emb"] > 0:  # CARCA.dropout on the profile embedding (carca.py:416)
+            dx = ops.mask_mul(dx, st["m_embed"], 1.0 / (1.0 - st["p_emb"]), d, dpi)
         des = [dx] + des_t                      # d e per segment, [rows, dpi]; profile rows still unmasked
         ids_seg = [s[0] for s in st["segs"]]
         nseg = len(des)

@@ -10,6 +10,7 @@
 //   - K is kept [key][head-padded feature], V transposed [head-padded feature][key].
 #pragma once
 #include "carca_common.h"
+#include "../../include/carca_hip.h"
 
 #define ATT_LMAX 64
 #define ATT_LT 4      // 16-slot tiles in ATT_LMAX
@@ -24,6 +25,35 @@ struct AttGeom {
   static constexpr int NFH = DHP / 16;  // feature tiles per head
   static constexpr int NF = DPO / 16;
 };
+
+// counter-based dropout: keep element `idx` of `site` iff a 24-bit hash of (seed, site, idx) >= p * 2^24
+struct DropCfg {
+  unsigned thresh;  // 0 = dropout off
+  unsigned s0, s1;  // seed halves
+  float scale;      // 1 / (1 - p)
+};
+__host__ inline DropCfg make_drop(const CarcaDropout* d) {
+  DropCfg c{0u, 0u, 0u, 1.0f};
+  if (d && d->p > 0.f) {
+    double t = (double)d->p * 16777216.0;
+    c.thresh = t >= 16777215.0 ? 16777215u : (unsigned)t;
+    if (c.thresh == 0) c.thresh = 1;
+    c.s0 = (unsigned)d->seed;
+    c.s1 = (unsigned)(d->seed >> 32);
+    c.scale = (float)(1.0 / (1.0 - (double)d->p));
+  }
+  return c;
+}
+__device__ __forceinline__ bool drop_keep(const DropCfg& c, unsigned site, unsigned idx) {
+  unsigned x = idx * 0x9E3779B1u + c.s0;
+  x ^= (site + 1u) * 0x85EBCA77u + c.s1;
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return (x >> 8) >= c.thresh;
+}
 
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 glb4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -107,7 +137,9 @@ __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], cons
                                             const float* __restrict__ bq, const float* Ks, const float* Vt, int h,
                                             int nkt, unsigned okbits, float sqrt_dh,
                                             f32x4 (&o)[DHP / 16], f32x4 (&p)[ATT_LT], int lane,
-                                            float* __restrict__ qh_row = nullptr) {
+                                            float* __restrict__ qh_row = nullptr, const DropCfg* dc = nullptr,
+                                            unsigned site = 0, unsigned midx = 0, uint8_t* mrow = nullptr,
+                                            int nkeys = 0) {
   using G = AttGeom<DPI, DHP, NH>;
   const int ln = lane & 15, mq = lane >> 4;
   // Q^T tiles of this head
@@ -165,6 +197,18 @@ __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], cons
   const float inv = sum > 0.f ? 1.0f / sum : 0.f;
 #pragma unroll
   for (int kt = 0; kt < ATT_LT; ++kt) p[kt] = p[kt] * inv;
+  // dropout on the attention weights (carca.py:258): element (user, head, query, key) = midx + key
+  if (dc && dc->thresh) {
+#pragma unroll
+    for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * mq + r;
+        const bool keep = drop_keep(*dc, site, midx + (unsigned)key);
+        p[kt][r] = keep ? p[kt][r] * dc->scale : 0.f;
+        if (mrow && key < nkeys) mrow[key] = keep ? 1 : 0;
+      }
+  }
   // O^T tiles: rows = head features, cols = queries, contracting over keys
 #pragma unroll
   for (int ft = 0; ft < G::NFH; ++ft) {

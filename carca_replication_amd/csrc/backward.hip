@@ -117,6 +117,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// in-place dropout of a [rows, cols] matrix + its keep-mask (CARCA.dropout on the profile embedding)
+__global__ void dropout_fwd_kernel(float* __restrict__ x, int rows, int cols, int ld, const DropCfg dc, unsigned site,
+                                   uint8_t* __restrict__ mask) {
+  const int total = rows * cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / cols, c = i - r * cols;
+    const bool keep = drop_keep(dc, site, (unsigned)i);
+    float* p = x + (size_t)r * ld + c;
+    *p = keep ? *p * dc.scale : 0.f;
+    if (mask) mask[i] = keep ? 1 : 0;
+  }
+}
+// out = x * mask * scale (dropout backward); pad columns [cols, ncols_out) are zeroed
+__global__ void mask_mul_kernel(const float* __restrict__ x, int ld_x, const uint8_t* __restrict__ mask, int ld_m,
+                                float scale, float* __restrict__ out, int ld_out, int rows, int cols, int ncols_out) {
+  const int total = rows * ncols_out;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / ncols_out, c = i - r * ncols_out;
+    float v = 0.f;
+    if (c < cols) v = mask[(size_t)r * ld_m + c] ? x[(size_t)r * ld_x + c] * scale : 0.f;
+    out[(size_t)r * ld_out + c] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // attention backward
 // ---------------------------------------------------------------------------------------------------
@@ -158,7 +182,8 @@ template <int DHP, int SO, typename DoFrag>
 __device__ __forceinline__ void attn_bwd_phase1(const float* Qs, const float* Ks, const float* __restrict__ vh_user,
                                                 int L, int dpo, int h, int qrow, int qcol, int nkt, unsigned okbits,
                                                 float sqrt_dh, DoFrag dofrag, float* PT, float* DST,
-                                                float* __restrict__ dq_row, f32x4 (&p)[ATT_LT], int lane) {
+                                                float* __restrict__ dq_row, f32x4 (&p)[ATT_LT], int lane,
+                                                const uint8_t* __restrict__ mrow = nullptr, float dscale = 1.f) {
   constexpr int NFH = DHP / 16;
   const int ln = lane & 15, mq = lane >> 4;
   f32x4 qf[NFH], dof[NFH];
@@ -187,6 +212,17 @@ __device__ __forceinline__ void attn_bwd_phase1(const float* Qs, const float* Ks
     }
   }
   masked_softmax(p, okbits, sqrt_dh);
+  // attention-weight dropout: O = (P * M) V, so dP = (dO V^T) * M and dV uses P * M   (M = keep / (1 - p))
+  if (mrow) {
+#pragma unroll
+    for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * mq + r;
+        const float m = (key < L && mrow[key]) ? dscale : 0.f;
+        dp[kt][r] *= m;
+      }
+  }
   float dot = 0.f;
 #pragma unroll
   for (int kt = 0; kt < ATT_LT; ++kt)
@@ -198,6 +234,15 @@ __device__ __forceinline__ void attn_bwd_phase1(const float* Qs, const float* Ks
   for (int kt = 0; kt < ATT_LT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ds[kt][r] = p[kt][r] * (dp[kt][r] - dot) / sqrt_dh;
+  if (mrow) {  // from here on p means P * M (what multiplied V in the forward)
+#pragma unroll
+    for (int kt = 0; kt < ATT_LT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * mq + r;
+        p[kt][r] *= (key < L && mrow[key]) ? dscale : 0.f;
+      }
+  }
   // dQ^T[f][q] = sum_key K[key][f] dS^T[key][q]   (A read transposed: one ds_read_b32 per step)
 #pragma unroll
   for (int ft = 0; ft < NFH; ++ft) {
@@ -242,7 +287,8 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
                                                           const float* __restrict__ d_attn /*[B*L, ld] plain*/,
                                                           int ld_da, const int32_t* __restrict__ ids,
                                                           float* __restrict__ dqh, float* __restrict__ dkh,
-                                                          float* __restrict__ dvh, int L, int dh) {
+                                                          float* __restrict__ dvh, int L, int dh,
+                                                          const uint8_t* __restrict__ m_attn, float dscale) {
   using G = AttGeom<DPI, DHP, NH>;
   constexpr int SO = G::SO, DPO = G::DPO, NW = 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -300,8 +346,9 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
       f32x4 p[ATT_LT];
       auto dofrag = [&](int ft) { return lds4(Os + q * SO + h * DHP + 16 * ft + 4 * mq); };
       float* dq_row = q < L ? dqh + (ubase + q) * DPO : nullptr;
+      const uint8_t* mrow = m_attn ? m_attn + (((size_t)u * NH + h) * L + (q < L ? q : 0)) * L : nullptr;
       attn_bwd_phase1<DHP, SO>(Qs, Ks, vh_user, L, DPO, h, q, q, qt + 1, okbits, sqrt_dh, dofrag, PT, DST, dq_row, p,
-                               lane);
+                               lane, mrow, dscale);
     }
     __syncthreads();
     // dK / dV tiles: job = (which, kt, ft); queries that can see key tile kt are tiles qt >= kt
@@ -338,7 +385,7 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
                                                              const float* __restrict__ ffn_w_pad,
                                                              float* __restrict__ dkh, float* __restrict__ dvh,
                                                              float* __restrict__ d_ffn_w_pad, int L, int dh,
-                                                             int training) {
+                                                             int training, float dscale) {
   using G = AttGeom<DPI, DHP, NH>;
   constexpr int SO = G::SO, DPO = G::DPO, NW = 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -416,8 +463,10 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
           f32x4 p[ATT_LT];
           auto dofrag = [&](int ft) { return lds4(wps + h * DHP + 16 * ft + 4 * mq) * dl; };  // dO = dl (x) w_pad
           float* dq_row = in_range ? grp.dqh + (gbase + qloc) * DPO : nullptr;
+          const uint8_t* mrow =
+              grp.m_attn ? grp.m_attn + (((size_t)u * NH + h) * grp.N + (in_range ? nslot : 0)) * L : nullptr;
           attn_bwd_phase1<DHP, SO>(Qs, Ks, vh_user, L, DPO, h, qloc, qloc, nkt, okbits, sqrt_dh, dofrag, PT, DST,
-                                   dq_row, p, lane);
+                                   dq_row, p, lane, mrow, dscale);
           // d w_pad[f] += sum_q dl[q] * O[q][f],  O^T[f][q] = sum_key V[key][f] P^T[key][q]
 #pragma unroll
           for (int ft = 0; ft < G::NFH; ++ft) {
@@ -475,7 +524,7 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
 template <int DPI, int DHP, int NH>
 int launch_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const float* d_attn, int ld_da,
                        const int32_t* ids, float* dqh, float* dkh, float* dvh, int B, int L, int d,
-                       hipStream_t stream) {
+                       const uint8_t* m_attn, float dscale, hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
   const size_t lds_bytes = sizeof(float) * (3 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP);
   auto kern = sa_attn_bwd_kernel<DPI, DHP, NH>;
@@ -488,7 +537,8 @@ int launch_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const 
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds_bytes, stream, qh, kh, vh, d_attn, ld_da, ids, dqh, dkh, dvh, L, d / NH);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds_bytes, stream, qh, kh, vh, d_attn, ld_da, ids, dqh, dkh, dvh, L, d / NH,
+                     m_attn, dscale);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -496,7 +546,7 @@ int launch_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const 
 template <int DPI, int DHP, int NH>
 int launch_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids, const CrossBwdGroups& groups,
                           const float* ffn_w_pad, float* dkh, float* dvh, float* d_ffn_w_pad, int B, int L, int d,
-                          int training, hipStream_t stream) {
+                          int training, float dscale, hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
   const size_t lds_bytes = sizeof(float) * (2 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP + 64 + 2 * G::DPO);
   auto kern = cross_attn_bwd_kernel<DPI, DHP, NH>;
@@ -510,7 +560,7 @@ int launch_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds_bytes, stream, kh, vh, p_ids, groups, ffn_w_pad, dkh, dvh,
-                     d_ffn_w_pad, L, d / NH, training);
+                     d_ffn_w_pad, L, d / NH, training, dscale);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -542,6 +592,32 @@ extern "C" int carca_embed_scatter(const float* dz, int ld_dz, const int32_t* id
   return CARCA_OK;
 }
 
+extern "C" int carca_dropout_fwd(float* x, int rows, int cols, int ld, const CarcaDropout* drop, uint8_t* mask,
+                                 void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(x && drop && rows >= 1 && cols >= 1 && ld >= cols && drop->p >= 0.f && drop->p < 1.f,
+                  "dropout_fwd: bad arguments");
+  const DropCfg dc = make_drop(drop);
+  if (!dc.thresh) return CARCA_OK;
+  const int blocks = min((rows * cols + 255) / 256, 2048);
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, dc, drop->site, mask);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_mask_mul(const float* x, int ld_x, const uint8_t* mask, int ld_m, float scale, float* out,
+                              int ld_out, int rows, int cols, int ncols_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(x && mask && out && rows >= 1 && cols >= 1 && ld_x >= cols && ld_m >= cols && ncols_out >= cols &&
+                      ld_out >= ncols_out,
+                  "mask_mul: bad arguments");
+  const int blocks = min((rows * ncols_out + 255) / 256, 2048);
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(blocks), dim3(256), 0, stream, x, ld_x, mask, ld_m, scale, out, ld_out, rows,
+                     cols, ncols_out);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
 extern "C" int carca_colsum(const float* x, int ld_x, int rows, int cols, const float* rowscale, const int32_t* ids,
                             int T, float* out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -555,14 +631,15 @@ extern "C" int carca_colsum(const float* x, int ld_x, int rows, int cols, const 
 
 extern "C" int carca_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const float* d_attn, int ld_da,
                                  const int32_t* ids, float* dqh, float* dkh, float* dvh, int B, int L, int d, int H,
-                                 void* stream_) {
+                                 const uint8_t* m_attn, float drop_scale, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(qh && kh && vh && d_attn && ids && dqh && dkh && dvh && ld_da >= d, "sa_attn_bwd: bad arguments");
   CARCA_CHECK_ARG(B >= 1 && L >= 1 && d >= 1 && H >= 1 && d % H == 0, "sa_attn_bwd: bad dims");
   CARCA_CHECK_SUPPORTED(L <= CARCA_MAX_L, "sa_attn_bwd: L=%d > %d", L, CARCA_MAX_L);
   int dpi, dhp, dpo;
   if (carca_padded_dims(d, H, &dpi, &dhp, &dpo) != CARCA_OK) return CARCA_ERR_UNSUPPORTED;
-  CARCA_ATT_DISPATCH(launch_sa_attn_bwd, qh, kh, vh, d_attn, ld_da, ids, dqh, dkh, dvh, B, L, d, stream);
+  CARCA_ATT_DISPATCH(launch_sa_attn_bwd, qh, kh, vh, d_attn, ld_da, ids, dqh, dkh, dvh, B, L, d, m_attn, drop_scale,
+                     stream);
   carca_set_error("sa_attn_bwd: no kernel built for d=%d H=%d", d, H);
   return CARCA_ERR_UNSUPPORTED;
 }
@@ -570,7 +647,7 @@ extern "C" int carca_sa_attn_bwd(const float* qh, const float* kh, const float* 
 extern "C" int carca_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids,
                                     const CarcaCrossBwdGroup* groups, int ngroups, const float* ffn_w_pad, float* dkh,
                                     float* dvh, float* d_ffn_w_pad, int B, int L, int d, int H, int training,
-                                    void* stream_) {
+                                    float drop_scale, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(kh && vh && p_ids && groups && ffn_w_pad && dkh && dvh && d_ffn_w_pad, "cross_attn_bwd: null pointer");
   CARCA_CHECK_ARG(ngroups >= 1 && ngroups <= CARCA_MAX_GROUPS && B >= 1 && L >= 1 && d >= 1 && H >= 1 && d % H == 0,
@@ -586,7 +663,7 @@ extern "C" int carca_cross_attn_bwd(const float* kh, const float* vh, const int3
   }
   gd.n = ngroups;
   CARCA_ATT_DISPATCH(launch_cross_attn_bwd, kh, vh, p_ids, gd, ffn_w_pad, dkh, dvh, d_ffn_w_pad, B, L, d, training,
-                     stream);
+                     drop_scale, stream);
   carca_set_error("cross_attn_bwd: no kernel built for d=%d H=%d", d, H);
   return CARCA_ERR_UNSUPPORTED;
 }

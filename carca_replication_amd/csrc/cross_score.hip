@@ -30,7 +30,8 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
                                                                float* __restrict__ p_normed,
                                                                const GroupsDev groups, int ldo, int L, int d, int dh,
                                                                const CarcaCaWeights w, int residual, int training,
-                                                               const CarcaCaSave sv) {
+                                                               const CarcaCaSave sv, const DropCfg dc,
+                                                               unsigned site) {
   using G = AttGeom<DPI, DHP, NH>;
   constexpr int NW = 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -131,8 +132,10 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
         }
       const int nkt = training ? min(LT, qt + 1) : LT;
       f32x4 oh[G::NFH], p[ATT_LT];
+      const unsigned midx = (unsigned)((((size_t)u * NH + h) * grp.N + (in_range ? n : 0)) * L);
       attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, nkt, okbits, sqrt_dh, oh, p, lane,
-                                (sv.qh[gi] && in_range) ? sv.qh[gi] + row * G::DPO : nullptr);
+                                (sv.qh[gi] && in_range) ? sv.qh[gi] + row * G::DPO : nullptr, &dc, site + gi, midx,
+                                (sv.m_attn[gi] && in_range) ? sv.m_attn[gi] + midx : nullptr, L);
       float ypart = 0.f;
 #pragma unroll
       for (int ft = 0; ft < G::NFH; ++ft) {
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
 template <int DPI, int DHP, int NH>
 int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_normed, const GroupsDev& groups, int ldo,
                  int B, int L, int d, const CarcaCaWeights& w, int residual, int training, const CarcaCaSave& sv,
-                 hipStream_t stream) {
+                 const DropCfg& dc, unsigned site, hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
   const size_t lds_bytes = sizeof(float) * (ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK + CROSS_TPR * NH * 16);
   auto kern = cross_score_kernel_w16<DPI, DHP, NH>;
@@ -189,7 +192,7 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L, d,
-                     d / NH, w, residual, training, sv);
+                     d / NH, w, residual, training, sv, dc, site);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -199,7 +202,7 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
 extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t* p_ids, float* p_normed,
                                      const CarcaTargetGroup* groups, int ngroups, int ldo, int B, int L, int d, int H,
                                      const CarcaCaWeights* w, int residual, int training, const CarcaCaSave* save,
-                                     void* stream_) {
+                                     const CarcaDropout* drop, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(p_raw && p_ids && groups && w, "cross_score_fwd: null pointer");
   CARCA_CHECK_ARG(ngroups >= 1 && ngroups <= CARCA_MAX_GROUPS, "cross_score_fwd: ngroups=%d outside 1..%d", ngroups,
@@ -223,7 +226,10 @@ extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t*
   gd.n = ngroups;
   CarcaCaSave sv{};
   if (save) sv = *save;
-  CARCA_ATT_DISPATCH(launch_cross, p_raw, ldp, p_ids, p_normed, gd, ldo, B, L, d, *w, residual, training, sv, stream);
+  const DropCfg dc = make_drop(drop);
+  CARCA_CHECK_ARG(!(drop && drop->p >= 1.0f), "cross_score_fwd: dropout p must be < 1");
+  CARCA_ATT_DISPATCH(launch_cross, p_raw, ldp, p_ids, p_normed, gd, ldo, B, L, d, *w, residual, training, sv, dc,
+                     drop ? drop->site : 0u, stream);
   carca_set_error("cross_score_fwd: no kernel built for d=%d H=%d (padded %d / head %d)", d, H, dpi, dhp);
   return CARCA_ERR_UNSUPPORTED;
 }

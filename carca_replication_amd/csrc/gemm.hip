@@ -172,7 +172,11 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
         if (sg.add_pos) v += D.pos[(size_t)(row % sg.T) * D.N + n];
         if (sg.add) v += sg.add[(size_t)row * D.ld_add + n];
         if (sg.rowscale) v += sg.rowscale[row] * cv;
-        if (sg.gate) v *= sg.gate[(size_t)row * D.ld_gate + n] > 0.f ? 1.0f : D.gate_slope;
+        if (sg.gate) {
+          const float gv = sg.gate[(size_t)row * D.ld_gate + n];
+          const float gs = D.gate_scale != 0.f ? D.gate_scale : 1.0f;
+          v *= gv > 0.f ? gs : ((gv < 0.f || !D.gate_zero_drops) ? D.gate_slope * gs : 0.f);
+        }
         if (D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;  // e * mask (carca.py:94): exact zeros
       }
       sg.c[(size_t)row * D.ldc + n] = v;

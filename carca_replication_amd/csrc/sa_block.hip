@@ -23,7 +23,8 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
                                                             const int32_t* __restrict__ ids,
                                                             float* __restrict__ y, int ldy, int L, int d, int dh,
                                                             const CarcaSaWeights w, int residual,
-                                                            const CarcaSaSave sv, unsigned long long* stamps) {
+                                                            const CarcaSaSave sv, const DropCfg dc, unsigned site,
+                                                            unsigned long long* stamps) {
   using G = AttGeom<DPI, DHP, NH>;
   static_assert(G::SO >= G::SI, "H1 reuses the K image");
 #define SA_STAMP(i)                                                                       \
@@ -117,8 +118,10 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
         okbits |= ((q_ok && key <= q && ((pmask >> key) & 1ull)) ? 1u : 0u) << (4 * kt + r);
       }
     f32x4 oh[G::NFH], p[ATT_LT];
+    const unsigned midx = (unsigned)((((size_t)u * NH + h) * L + (q < L ? q : 0)) * L);
     attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, qt + 1, okbits, sqrt_dh, oh, p, lane,
-                              (sv.qh && q < L) ? sv.qh + (ubase + q) * G::DPO : nullptr);
+                              (sv.qh && q < L) ? sv.qh + (ubase + q) * G::DPO : nullptr, &dc, site, midx,
+                              (sv.m_attn && q < L) ? sv.m_attn + midx : nullptr, L);
     // r = attention (+ q): plain feature order, into the dead x image (pad columns stay 0)
 #pragma unroll
     for (int ft = 0; ft < G::NFH; ++ft)
@@ -167,6 +170,15 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
     acc = acc + bias;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.01f * acc[r];
+    if (dc.thresh) {  // dropout1 (carca.py:309)
+      const unsigned e0 = (unsigned)((ubase + (q < L ? q : 0)) * DPI + 16 * ft + 4 * mq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool keep = drop_keep(dc, site + 1, e0 + r);
+        acc[r] = keep ? acc[r] * dc.scale : 0.f;
+        if (sv.m_ffn1 && q < L) sv.m_ffn1[e0 + r] = keep ? 1 : 0;
+      }
+    }
     *reinterpret_cast<f32x4*>(H1 + q * G::SI + 16 * ft + 4 * mq) = acc;
     if (sv.h1 && q < L) *reinterpret_cast<f32x4*>(sv.h1 + (ubase + q) * DPI + 16 * ft + 4 * mq) = acc;
   }
@@ -186,6 +198,15 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], lds4(hrow + 16 * kg), acc);
     acc = acc + bias;
+    if (dc.thresh) {  // dropout2 (carca.py:312), before the residual
+      const unsigned e0 = (unsigned)((ubase + (q < L ? q : 0)) * DPI + 16 * ft + 4 * mq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool keep = drop_keep(dc, site + 2, e0 + r);
+        acc[r] = keep ? acc[r] * dc.scale : 0.f;
+        if (sv.m_ffn2 && q < L) sv.m_ffn2[e0 + r] = keep ? 1 : 0;
+      }
+    }
     if (residual) acc = acc + lds4(Xs + q * G::SI + 16 * ft + 4 * mq);
     if (q < L && 16 * ft + 4 * mq < ldy) *reinterpret_cast<f32x4*>(y + (ubase + q) * ldy + 16 * ft + 4 * mq) = acc;
   }
@@ -195,7 +216,8 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
 
 template <int DPI, int DHP, int NH>
 int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d,
-              const CarcaSaWeights& w, int residual, const CarcaSaSave& sv, hipStream_t stream) {
+              const CarcaSaWeights& w, int residual, const CarcaSaSave& sv, const DropCfg& dc, unsigned site,
+              hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
   const size_t lds_bytes = sizeof(float) * (2 * ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK);
   const void* kern = (const void*)sa_block_kernel_w16<DPI, DHP, NH>;
@@ -209,7 +231,7 @@ int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, in
     attr_set = true;
   }
   hipLaunchKernelGGL((sa_block_kernel_w16<DPI, DHP, NH>), dim3(B), dim3(1024), lds_bytes, stream, x, ldx, ids, y, ldy, L,
-                     d, d / NH, w, residual, sv, carca_debug_buffer());
+                     d, d / NH, w, residual, sv, dc, site, carca_debug_buffer());
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -218,7 +240,7 @@ int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, in
 
 extern "C" int carca_sa_block_fwd(const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d,
                                   int H, const CarcaSaWeights* w, int residual, const CarcaSaSave* save,
-                                  void* stream_) {
+                                  const CarcaDropout* drop, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(x && ids && y && w, "sa_block_fwd: null pointer");
   CARCA_CHECK_ARG(B >= 1 && L >= 1 && d >= 1 && H >= 1 && d % H == 0, "sa_block_fwd: bad dims B=%d L=%d d=%d H=%d", B,
@@ -230,7 +252,9 @@ extern "C" int carca_sa_block_fwd(const float* x, int ldx, const int32_t* ids, f
                   dpi);
   CarcaSaSave sv{};
   if (save) sv = *save;
-  CARCA_ATT_DISPATCH(launch_sa, x, ldx, ids, y, ldy, B, L, d, *w, residual, sv, stream);
+  const DropCfg dc = make_drop(drop);
+  CARCA_CHECK_ARG(!(drop && drop->p >= 1.0f), "sa_block_fwd: dropout p must be < 1");
+  CARCA_ATT_DISPATCH(launch_sa, x, ldx, ids, y, ldy, B, L, d, *w, residual, sv, dc, drop ? drop->site : 0u, stream);
   carca_set_error("sa_block_fwd: no kernel built for d=%d H=%d (padded %d / head %d)", d, H, dpi, dhp);
   return CARCA_ERR_UNSUPPORTED;
 }

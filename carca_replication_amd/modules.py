@@ -281,8 +281,13 @@ class SelfAttentionBlock(Encoder, _PackedModule):
         return w
 
     def _check_mode(self):
-        if self.training and self.attn.dropout.p > 0:
-            raise CarcaHipError("dropout p > 0 in training mode is not built in the HIP path yet; use p = 0 or eval()")
+        ps = {self.attn.dropout.p, self.dropout1.p, self.dropout2.p}
+        if self.training and len(ps) != 1:
+            raise CarcaHipError("the fused block kernel takes ONE dropout probability for its three sites "
+                                "(the reference constructs them all from the same p, carca.py:280,286,289)")
+
+    def drop_p(self) -> float:
+        return float(self.attn.dropout.p) if self.training else 0.0
 
     def forward(self, x: Tensor, mask: Tensor) -> Tensor:
         """x [B, L, >=d], mask [B, L] (0 = pad) -> [B, L, d] (a view of a padded buffer)."""
@@ -292,7 +297,9 @@ class SelfAttentionBlock(Encoder, _PackedModule):
 
             return sa_block_with_grad(self, x, mask)
         d = self.attn.d
-        y = ops.sa_block_fwd(x, mask != 0, self.weights_struct(x.device), d, self.attn.H, self.residual)
+        p = self.drop_p()
+        y = ops.sa_block_fwd(x, mask != 0, self.weights_struct(x.device), d, self.attn.H, self.residual,
+                             drop=(p, ops.new_dropout_seed(), 0) if p > 0 else None)
         return y[..., :d]
 
 
@@ -339,8 +346,10 @@ class CrossAttentionBlock(Decoder, _PackedModule):
         return w
 
     def _check_mode(self):
-        if self.training and self.attn.dropout.p > 0:
-            raise CarcaHipError("dropout p > 0 in training mode is not built in the HIP path yet; use p = 0 or eval()")
+        pass
+
+    def drop_p(self) -> float:
+        return float(self.attn.dropout.p) if self.training else 0.0
 
     def forward(self, o: Tensor, o_mask: Tensor, p: Tensor, p_mask: Tensor) -> Tensor:
         """Standalone decoder call: p is already final-normed (as in carca.py:421-428)."""
@@ -353,8 +362,14 @@ class CrossAttentionBlock(Decoder, _PackedModule):
         d, H = self.attn.d, self.attn.H
         dpi, _, _ = ops.padded_dims(d, H)
         o_pad = _pad_cols(o, dpi)
-        (y,), _ = ops.cross_score_fwd(p, p_mask != 0, [(o_pad, o_mask != 0)], self.weights_struct(o.device, None), d, H,
-                                      self.residual, self.training)
+        pd = self.drop_p()
+        if pd > 0:  # the keep-masks travel with the saved tensors
+            (y,), _, _ = ops.cross_score_fwd(p, p_mask != 0, [(o_pad, o_mask != 0)], self.weights_struct(o.device, None),
+                                             d, H, self.residual, self.training, save=True,
+                                             drop=(pd, ops.new_dropout_seed(), 0))
+        else:
+            (y,), _ = ops.cross_score_fwd(p, p_mask != 0, [(o_pad, o_mask != 0)], self.weights_struct(o.device, None),
+                                          d, H, self.residual, self.training)
         return y.squeeze()  # bare squeeze, as carca.py:346
 
 
@@ -390,8 +405,6 @@ class CARCA(Model):
             raise CarcaHipError(
                 "only the AllEmbedding + SelfAttentionBlock + CrossAttentionBlock path is built in HIP "
                 "(SURVEY.md section 8: the other embeddings/decoders are ablations outside the hot path)")
-        if self.training and self.dropout.p > 0:
-            raise CarcaHipError("dropout p > 0 in training mode is not built in the HIP path yet; use p = 0 or eval()")
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if needs_grad:
             from .autograd import carca_forward_with_grad
@@ -412,19 +425,30 @@ class CARCA(Model):
         segs = [(p_x, p_a, p_c, False)] + [(o_x, o_a, o_c, True) for (o_x, o_a, o_c) in targets]
         es, _ = self.embeds.embed_segments(segs, ld_e=dpi)
         x = es[0]
+        seed = ops.new_dropout_seed() if self.training else 0
+        if self.training and self.dropout.p > 0:  # carca.py:416
+            ops.dropout_fwd(x, d, float(self.dropout.p), seed, 1000)
         if trace is not None:
             trace["p_embed"] = x[..., :d]
             for gi in range(len(targets)):
                 trace[f"o_embed{gi}"] = es[gi + 1][..., :d]
         for i, blk in enumerate(self.encoder):
             blk._check_mode()
-            x = ops.sa_block_fwd(x, p_x, blk.weights_struct(x.device), d, blk.attn.H, blk.residual)
+            bp = blk.drop_p()
+            x = ops.sa_block_fwd(x, p_x, blk.weights_struct(x.device), d, blk.attn.H, blk.residual,
+                                 drop=(bp, seed, 4 * i) if bp > 0 else None)
             if trace is not None:
                 trace[f"block{i}"] = x[..., :d]
         self.decoder._check_mode()
         groups = [(es[gi + 1], targets[gi][0]) for gi in range(len(targets))]
-        ys, p_normed = ops.cross_score_fwd(x, p_x, groups, self.decoder.weights_struct(x.device, self.norm), d, H,
-                                           self.decoder.residual, self.training, want_normed=trace is not None)
+        dp = self.decoder.drop_p()
+        if dp > 0:
+            ys, p_normed, _ = ops.cross_score_fwd(x, p_x, groups, self.decoder.weights_struct(x.device, self.norm), d, H,
+                                                  self.decoder.residual, self.training, save=True,
+                                                  drop=(dp, seed, 2000))
+        else:
+            ys, p_normed = ops.cross_score_fwd(x, p_x, groups, self.decoder.weights_struct(x.device, self.norm), d, H,
+                                               self.decoder.residual, self.training, want_normed=trace is not None)
         if trace is not None:
             trace["p_final"] = p_normed[..., :d]
         return ys

@@ -71,6 +71,44 @@ def padded_dims(d: int, H: int) -> Tuple[int, int, int]:
 
 
 # --------------------------------------------------------------------------------------------------
+# dropout plumbing
+# --------------------------------------------------------------------------------------------------
+def new_dropout_seed() -> int:
+    """A fresh 62-bit seed from torch's CPU generator (so torch.manual_seed makes training runs repeatable)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def _drop_struct(p: float, seed: int, site: int):
+    if not p:
+        return None
+    d = _lib.Dropout()
+    d.p, d.seed, d.site = float(p), int(seed), int(site)
+    return d
+
+
+def dropout_fwd(x: Tensor, cols: int, p: float, seed: int, site: int) -> Tensor:
+    """In-place dropout of x [..., ld] over its first `cols` columns; returns the uint8 keep-mask [rows, cols]."""
+    lib = _lib.load()
+    _need_cuda(x)
+    x2 = x.view(-1, x.shape[-1])
+    mask = torch.empty(x2.shape[0], cols, dtype=torch.uint8, device=x.device)
+    d = _drop_struct(p, seed, site)
+    _lib.check(lib.carca_dropout_fwd(x2.data_ptr(), x2.shape[0], cols, x2.stride(0), C.byref(d), mask.data_ptr(),
+                                     _stream()), "dropout_fwd")
+    return mask
+
+
+def mask_mul(x: Tensor, mask: Tensor, scale: float, cols: int, out_ld: int) -> Tensor:
+    """out [rows, out_ld] = x[:, :cols] * mask[:, :cols] * scale (pad columns zero)."""
+    lib = _lib.load()
+    x = _row2d(x, "x")
+    out = torch.empty(x.shape[0], out_ld, dtype=torch.float32, device=x.device)
+    _lib.check(lib.carca_mask_mul(x.data_ptr(), x.stride(0), mask.data_ptr(), mask.stride(0), scale, out.data_ptr(),
+                                  out_ld, x.shape[0], cols, out_ld, _stream()), "mask_mul")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
 # weight packing
 # --------------------------------------------------------------------------------------------------
 @dataclass
@@ -205,7 +243,8 @@ def embed_fwd(segs: Sequence[Tuple[Tensor, Tensor, Tensor, bool]], items_w: Tens
 # --------------------------------------------------------------------------------------------------
 # self-attention block
 # --------------------------------------------------------------------------------------------------
-def sa_block_fwd(x: Tensor, ids: Tensor, w: "_lib.SaWeights", d: int, H: int, residual: bool, save: bool = False):
+def sa_block_fwd(x: Tensor, ids: Tensor, w: "_lib.SaWeights", d: int, H: int, residual: bool, save: bool = False,
+                 drop: Optional[Tuple[float, int, int]] = None):
     """x [B, L, ldx] (ldx >= d) -> y [B, L, DPI]; `ids` [B, L] (any integer/bool type, 0 = pad).
 
     save=True also returns the dict of tensors the backward pass needs (CarcaSaSave)."""
@@ -221,10 +260,15 @@ def sa_block_fwd(x: Tensor, ids: Tensor, w: "_lib.SaWeights", d: int, H: int, re
         sv = _lib.SaSave()
         mk = lambda w_: torch.empty(B * L, w_, dtype=torch.float32, device=x.device)  # noqa: E731
         saved = dict(qn=mk(dpi), qh=mk(dpo), kh=mk(dpo), vh=mk(dpo), r=mk(dpi), s2=mk(dpi), h1=mk(dpi))
+        if drop and drop[0] > 0:
+            u8 = lambda *sh: torch.empty(*sh, dtype=torch.uint8, device=x.device)  # noqa: E731
+            saved.update(m_attn=u8(B, H, L, L), m_ffn1=u8(B * L, dpi), m_ffn2=u8(B * L, dpi))
         for k, t in saved.items():
             setattr(sv, k, t.data_ptr())
+    dstruct = _drop_struct(*drop) if drop else None
     _lib.check(lib.carca_sa_block_fwd(x.data_ptr(), ldx, ids32.data_ptr(), y.data_ptr(), dpi, B, L, d, H, C.byref(w),
-                                      int(bool(residual)), C.byref(sv) if save else None, _stream()), "sa_block_fwd")
+                                      int(bool(residual)), C.byref(sv) if save else None,
+                                      C.byref(dstruct) if dstruct is not None else None, _stream()), "sa_block_fwd")
     return (y, saved) if save else y
 
 
@@ -232,7 +276,8 @@ def sa_block_fwd(x: Tensor, ids: Tensor, w: "_lib.SaWeights", d: int, H: int, re
 # final norm + grouped cross-attention scoring
 # --------------------------------------------------------------------------------------------------
 def cross_score_fwd(p_raw: Tensor, p_ids: Tensor, groups: Sequence[Tuple[Tensor, Tensor]], w: "_lib.CaWeights", d: int,
-                    H: int, residual: bool, training: bool, want_normed: bool = False, save: bool = False):
+                    H: int, residual: bool, training: bool, want_normed: bool = False, save: bool = False,
+                    drop: Optional[Tuple[float, int, int]] = None):
     """p_raw [B, L, ldp]; groups: [(o [B,N,ldo], ids [B,N])] -> ([y [B,N]], p_normed or None[, saved])."""
     lib = _lib.load()
     _need_cuda(p_raw, p_ids)
@@ -257,7 +302,7 @@ def cross_score_fwd(p_raw: Tensor, p_ids: Tensor, groups: Sequence[Tuple[Tensor,
         ys.append(y)
         arr[i].o, arr[i].ids, arr[i].y, arr[i].N = o.data_ptr(), ids32.data_ptr(), y.data_ptr(), o.shape[1]
     p_normed = torch.empty_like(p_raw) if (want_normed or save) else None
-    sv, saved = None, None
+    sv, saved, dstruct = None, None, None
     if save:
         _, _, dpo = padded_dims(d, H)
         sv = _lib.CaSave()
@@ -266,13 +311,20 @@ def cross_score_fwd(p_raw: Tensor, p_ids: Tensor, groups: Sequence[Tuple[Tensor,
         sv.kh, sv.vh = saved["kh"].data_ptr(), saved["vh"].data_ptr()
         for i, t in enumerate(saved["qh"]):
             sv.qh[i] = t.data_ptr()
+        if drop and drop[0] > 0:
+            saved["m_attn"] = [torch.empty(B, H, o.shape[1], L, dtype=torch.uint8, device=p_raw.device)
+                               for (o, _) in groups]
+            for i, t in enumerate(saved["m_attn"]):
+                sv.m_attn[i] = t.data_ptr()
+    dstruct = _drop_struct(*drop) if drop else None
     ev = _stage_events.get("cross") if _stage_events else None
     if ev is not None:
         ev[0].record()
     _lib.check(lib.carca_cross_score_fwd(p_raw.data_ptr(), ldp, p_ids32.data_ptr(),
                                          p_normed.data_ptr() if p_normed is not None else None, arr, len(groups),
                                          ldo, B, L, d, H, C.byref(w), int(bool(residual)), int(bool(training)),
-                                         C.byref(sv) if save else None, _stream()),
+                                         C.byref(sv) if save else None,
+                                         C.byref(dstruct) if (save and dstruct is not None) else None, _stream()),
                "cross_score_fwd")
     if ev is not None:
         ev[1].record()
@@ -324,7 +376,8 @@ def _ptr(t: Optional[Tensor]):
 
 def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[Tensor] = None, K1: int = 0,
               bias: Optional[Tensor] = None, pos: Optional[Tensor] = None, colvec: Optional[Tensor] = None,
-              gate_slope: float = 0.01, mask_rows: bool = False, ncols_out: Optional[int] = None) -> List[Tensor]:
+              gate_slope: float = 0.01, mask_rows: bool = False, ncols_out: Optional[int] = None,
+              gate_scale: float = 1.0, gate_zero_drops: bool = False) -> List[Tensor]:
     """C_s[m][n] = sum_k A_s[m][k] Bt[n][k] (+ epilogue) for every row segment s.
 
     segs: list of dicts with keys a0 [rows, lda0] and optionally a1, ids, add, gate, rowscale, T, add_pos, out.
@@ -392,6 +445,7 @@ def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[
     D.N, D.ldc, D.ncols_out = N, out_ld, out_ld if ncols_out is None else ncols_out
     D.bias, D.pos, D.colvec = _ptr(bias), _ptr(pos), _ptr(colvec)
     D.ld_add, D.ld_gate, D.gate_slope, D.mask_rows = ld_add or 0, ld_gate or 0, gate_slope, int(mask_rows)
+    D.gate_scale, D.gate_zero_drops = gate_scale, int(gate_zero_drops)
     _lib.check(lib.carca_gemm_rows(C.byref(D), _stream()), "gemm_rows")
     return outs
 
@@ -496,19 +550,20 @@ def colsum(x: Tensor, cols: int, out: Tensor, rowscale: Optional[Tensor] = None,
                                 _stream()), "colsum")
 
 
-def sa_attn_bwd(qh: Tensor, kh: Tensor, vh: Tensor, d_attn: Tensor, ids: Tensor, B: int, L: int, d: int, H: int):
+def sa_attn_bwd(qh: Tensor, kh: Tensor, vh: Tensor, d_attn: Tensor, ids: Tensor, B: int, L: int, d: int, H: int,
+                m_attn: Optional[Tensor] = None, drop_scale: float = 1.0):
     lib = _lib.load()
     d_attn = _row2d(d_attn, "d_attn")
     ids32 = _ids32(ids.reshape(-1))
     dqh, dkh, dvh = torch.empty_like(qh), torch.empty_like(kh), torch.empty_like(vh)
     _lib.check(lib.carca_sa_attn_bwd(qh.data_ptr(), kh.data_ptr(), vh.data_ptr(), d_attn.data_ptr(), d_attn.stride(0),
                                      ids32.data_ptr(), dqh.data_ptr(), dkh.data_ptr(), dvh.data_ptr(), B, L, d, H,
-                                     _stream()), "sa_attn_bwd")
+                                     _ptr(m_attn), drop_scale, _stream()), "sa_attn_bwd")
     return dqh, dkh, dvh
 
 
 def cross_attn_bwd(kh: Tensor, vh: Tensor, p_ids: Tensor, groups, ffn_w_pad_ptr: int, d_ffn_w_pad: Tensor, B: int,
-                   L: int, d: int, H: int, training: bool):
+                   L: int, d: int, H: int, training: bool, masks=None, drop_scale: float = 1.0):
     """groups: [(qh [B*N,DPO], y [B,N], dy [B,N], ids [B,N])] -> ([dqh], [dlogit], dkh, dvh)."""
     lib = _lib.load()
     arr = (_lib.CrossBwdGroup * len(groups))()
@@ -523,9 +578,10 @@ def cross_attn_bwd(kh: Tensor, vh: Tensor, p_ids: Tensor, groups, ffn_w_pad_ptr:
         g = arr[i]
         g.qh, g.y, g.dy, g.ids, g.dqh, g.dlogit, g.N = (qh.data_ptr(), y.data_ptr(), dy.data_ptr(), ids32.data_ptr(),
                                                         dqh.data_ptr(), dl.data_ptr(), y.shape[1])
+        g.m_attn = masks[i].data_ptr() if masks is not None else None
     p_ids32 = _ids32(p_ids)
     dkh, dvh = torch.empty_like(kh), torch.empty_like(vh)
     _lib.check(lib.carca_cross_attn_bwd(kh.data_ptr(), vh.data_ptr(), p_ids32.data_ptr(), arr, len(groups),
                                         ffn_w_pad_ptr, dkh.data_ptr(), dvh.data_ptr(), d_ffn_w_pad.data_ptr(), B, L, d,
-                                        H, int(bool(training)), _stream()), "cross_attn_bwd")
+                                        H, int(bool(training)), drop_scale, _stream()), "cross_attn_bwd")
     return dqhs, dls, dkh, dvh

@@ -79,7 +79,7 @@ int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream);
  * with its own Bt, so torch.cat((a, c), -1) @ W^T never materialises the concatenation.
  * Epilogue, in this order, each part optional:
  *   v = acc + bias[n] + pos[(row % T)][n] + add[row][n] + rowscale[row] * colvec[n]
- *   v *= (gate[row][n] > 0 ? 1 : gate_slope)            (LeakyReLU', from the saved activation)
+ *   v *= gate_scale * (gate[row][n] > 0 ? 1 : gate_slope) (LeakyReLU' (x dropout1'), from the saved activation)
  *   v  = ids[row] != 0 ? v : 0                          (when mask_rows)
  *   C[row][n] = v for n < N;  C[row][n] = 0 for N <= n < ncols_out                              */
 typedef struct CarcaGemmSeg {
@@ -109,6 +109,8 @@ typedef struct CarcaGemmDesc {
   int32_t ld_add, ld_gate;
   float gate_slope;
   int32_t mask_rows;
+  float gate_scale;        /* extra factor on the gate (1/(1-p) when the saved activation went through dropout); 0 = 1 */
+  int32_t gate_zero_drops; /* 1: an exactly-zero saved activation was DROPPED -> gradient 0 (else LeakyReLU'(0) = slope) */
 } CarcaGemmDesc;
 int carca_gemm_rows(const CarcaGemmDesc* desc /*host*/, void* stream);
 
@@ -174,17 +176,32 @@ typedef struct CarcaSaWeights {
   const float *w1, *w2;                       /* [DPI, DPI] */
   const float *b1, *b2;                       /* [DPI] */
 } CarcaSaWeights;
+/* Training-mode dropout (nn.Dropout sites carca.py:258,309,312,416): element e of a site is kept iff
+ * hash(seed, site, e) >= p * 2^24 (counter-based: no state, any launch order), kept values are scaled by
+ * 1/(1-p).  torch's Philox stream cannot be reproduced inside a kernel, so parity is defined at p = 0 and
+ * through the masks: every site also writes its keep-mask (uint8, 1 = kept) so that tests can replay the
+ * reference arithmetic with the SAME masks.  p = 0 (or a NULL pointer) disables everything. */
+typedef struct CarcaDropout {
+  float p;
+  uint64_t seed;
+  uint32_t site; /* first site id of this call; a kernel with several sites uses site, site+1, ... */
+} CarcaDropout;
+
 /* Tensors the backward pass needs (all optional; pass save = NULL in eval): */
 typedef struct CarcaSaSave {
   float* qn;             /* [B*L, DPI] LayerNorm1(x) */
   float *qh, *kh, *vh;   /* [B*L, DPO] projections, head-padded columns */
   float* r;              /* [B*L, DPI] LayerNorm2's input (attention + residual) */
   float* s2;             /* [B*L, DPI] LayerNorm2's output */
-  float* h1;             /* [B*L, DPI] LeakyReLU(ffn_1(s2)) */
+  float* h1;             /* [B*L, DPI] dropout1(LeakyReLU(ffn_1(s2))) */
+  uint8_t* m_attn;       /* [B, H, L, L] keep-mask of the attention-weight dropout (site+0), or NULL */
+  uint8_t* m_ffn1;       /* [B*L, DPI] keep-mask of dropout1 (site+1), or NULL */
+  uint8_t* m_ffn2;       /* [B*L, DPI] keep-mask of dropout2 (site+2), or NULL */
 } CarcaSaSave;
 int carca_sa_block_fwd(const float* x /*[B*L, ldx]*/, int ldx, const int32_t* ids /*[B*L]*/, float* y /*[B*L, ldy]*/,
                        int ldy, int B, int L, int d, int H, const CarcaSaWeights* w /*host struct*/, int residual,
-                       const CarcaSaSave* save /*host struct or NULL*/, void* stream);
+                       const CarcaSaSave* save /*host struct or NULL*/, const CarcaDropout* drop /*or NULL*/,
+                       void* stream);
 
 /* ---- a5 + a6: final LayerNorm + CrossAttentionBlock.forward, grouped --------------------------
  * Replaces CARCA.forward's final norm (carca.py:421) and, for every target group,
@@ -209,12 +226,14 @@ typedef struct CarcaTargetGroup {
 typedef struct CarcaCaSave {
   float *kh, *vh;              /* [B*L, DPO] */
   float* qh[CARCA_MAX_GROUPS]; /* [B*N_g, DPO] per group */
+  uint8_t* m_attn[CARCA_MAX_GROUPS]; /* [B, H, N_g, L] keep-masks of the attention-weight dropout (site+g), or NULL */
 } CarcaCaSave;
 int carca_cross_score_fwd(const float* p_raw /*[B*L, ldp] encoder output BEFORE the final norm*/, int ldp,
                           const int32_t* p_ids /*[B*L]*/, float* p_normed /*[B*L, ldp] or NULL*/,
                           const CarcaTargetGroup* groups /*host*/, int ngroups, int ldo, int B, int L, int d, int H,
                           const CarcaCaWeights* w /*host struct*/, int residual, int training,
-                          const CarcaCaSave* save /*host struct or NULL*/, void* stream);
+                          const CarcaCaSave* save /*host struct or NULL*/, const CarcaDropout* drop /*or NULL*/,
+                          void* stream);
 
 /* ---- backward kernels (the autograd of the lines cited at each forward entry point) -------------------
  * LayerNorm backward over `rows` rows of width d: dx = dLN(dy; x, gamma) (+ addend); dgamma/dbeta are
@@ -233,7 +252,8 @@ int carca_colsum(const float* x, int ld_x, int rows, int cols, const float* rows
  * [B*L, ld_da] in plain feature order and the saved projections, recompute P and return dQ, dK, dV
  * (head-padded, [B*L, DPO]). */
 int carca_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const float* d_attn, int ld_da,
-                      const int32_t* ids, float* dqh, float* dkh, float* dvh, int B, int L, int d, int H, void* stream);
+                      const int32_t* ids, float* dqh, float* dkh, float* dvh, int B, int L, int d, int H,
+                      const uint8_t* m_attn /*[B,H,L,L] or NULL*/, float drop_scale /*1/(1-p)*/, void* stream);
 /* Attention core + sigmoid(ffn(.)) head of CrossAttentionBlock (carca.py:340-347) for every group:
  * dlogit = dy * y * (1 - y); d(attention output) = dlogit (x) ffn_w_pad; returns dQ per group, dK, dV
  * (summed over groups) and accumulates d ffn_w_pad[f] += sum dlogit * O[.][f] (caller zeroes it). */
@@ -244,11 +264,18 @@ typedef struct CarcaCrossBwdGroup {
   const int32_t* ids; /* [B*N] */
   float* dqh;         /* [B*N, DPO] out */
   float* dlogit;      /* [B*N] out, or NULL */
+  const uint8_t* m_attn; /* [B, H, N, L] keep-mask saved by the forward, or NULL */
   int32_t N;
 } CarcaCrossBwdGroup;
 int carca_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids, const CarcaCrossBwdGroup* groups,
                          int ngroups, const float* ffn_w_pad, float* dkh, float* dvh, float* d_ffn_w_pad, int B, int L,
-                         int d, int H, int training, void* stream);
+                         int d, int H, int training, float drop_scale, void* stream);
+/* In-place dropout of x [rows, cols] (row stride ld): x = keep ? x / (1-p) : 0; mask [rows, cols] uint8.
+ * Used for CARCA.dropout on the profile embedding (carca.py:416). */
+int carca_dropout_fwd(float* x, int rows, int cols, int ld, const CarcaDropout* drop, uint8_t* mask, void* stream);
+/* out[r][c] = x[r][c] * mask[r][c] * scale for c < cols, 0 for cols <= c < ncols_out (dropout backward) */
+int carca_mask_mul(const float* x, int ld_x, const uint8_t* mask, int ld_m, float scale, float* out, int ld_out,
+                   int rows, int cols, int ncols_out, void* stream);
 /* Inverse of carca_pack_weights for gradients: real[r][c] (+)= packed[rp][cp] (same descriptor fields:
  * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
 int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);

@@ -163,17 +163,25 @@ def mha(params: Params, prefix: str, H: int, query: Tensor, key: Tensor, value: 
 # --------------------------------------------------------------------------- #
 # a4: SelfAttentionBlock.forward                            carca.py:297-318  #
 # --------------------------------------------------------------------------- #
-def sa_block(params: Params, cfg: CarcaConfig, i: int, x: Tensor, mask: Tensor) -> Tensor:
+def sa_block(params: Params, cfg: CarcaConfig, i: int, x: Tensor, mask: Tensor, masks: Optional[dict] = None) -> Tensor:
+    """`masks` (optional) injects dropout multipliers (keep / (1-p)) at the block's three nn.Dropout sites:
+    attn{i} [B,H,L,L] (carca.py:258), ffn1_{i} and ffn2_{i} [B,L,d] (carca.py:309,312)."""
     pre = f"encoder.{i}."
+    mk = masks or {}
     q = layer_norm(x, params[pre + "norm1.weight"], params[pre + "norm1.bias"])
-    _, s = mha(params, pre + "attn.", cfg.H, q, x, x, mask, mask, causal=0)  # K,V from un-normed x
+    _, s = mha(params, pre + "attn.", cfg.H, q, x, x, mask, mask, causal=0,
+               drop_mask=mk.get(f"attn{i}"))  # K,V from un-normed x
     if cfg.residual_sa:
         s = s + q  # the NORMED tensor is the residual (carca.py:301-302)
     s = layer_norm(s, params[pre + "norm2.weight"], params[pre + "norm2.bias"])
     W1, b1 = params[pre + "ffn_1.weight"][:, :, 0], params[pre + "ffn_1.bias"]  # Conv1d k=1 == Linear
     W2, b2 = params[pre + "ffn_2.weight"][:, :, 0], params[pre + "ffn_2.bias"]
     f = torch.nn.functional.leaky_relu(s @ W1.T + b1, LRELU_SLOPE)
+    if f"ffn1_{i}" in mk:
+        f = f * mk[f"ffn1_{i}"]
     f = f @ W2.T + b2
+    if f"ffn2_{i}" in mk:
+        f = f * mk[f"ffn2_{i}"]
     if cfg.residual_sa:
         f = f + s
     return f  # no re-masking (carca.py:318)
@@ -183,9 +191,9 @@ def sa_block(params: Params, cfg: CarcaConfig, i: int, x: Tensor, mask: Tensor) 
 # a6: CrossAttentionBlock.forward                           carca.py:338-349  #
 # --------------------------------------------------------------------------- #
 def cross_block(params: Params, cfg: CarcaConfig, o: Tensor, o_mask: Tensor, p: Tensor, p_mask: Tensor,
-                training: bool, return_w: bool = False):
+                training: bool, return_w: bool = False, drop_mask: Optional[Tensor] = None):
     causal = -1 if training else None  # carca.py:339
-    w, s = mha(params, "decoder.attn.", cfg.H, o, p, p, o_mask, p_mask, causal)
+    w, s = mha(params, "decoder.attn.", cfg.H, o, p, p, o_mask, p_mask, causal, drop_mask=drop_mask)
     if cfg.residual_ca:
         s = s + o
     logit = s @ params["decoder.ffn.weight"].T + params["decoder.ffn.bias"]
@@ -200,16 +208,20 @@ def cross_block(params: Params, cfg: CarcaConfig, o: Tensor, o_mask: Tensor, p: 
 # --------------------------------------------------------------------------- #
 def carca_forward(params: Params, cfg: CarcaConfig, profile: Tuple[Tensor, Tensor, Tensor],
                   targets: Sequence[Tuple[Tensor, Tensor, Tensor]], training: bool,
-                  trace: Optional[dict] = None) -> Tensor:
-    """Dropout-free forward (eval mode, or train mode with p=0)."""
+                  trace: Optional[dict] = None, masks: Optional[dict] = None) -> Tensor:
+    """Forward in eval mode, or train mode with the dropout multipliers given in `masks`
+    (keys: embed [B,L,d] (carca.py:416), attn{i}/ffn1_{i}/ffn2_{i} per block, cross{g} [B,H,N,L]); no masks = p 0."""
     p_x, p_a, p_c = profile
     dt = p_a.dtype
     p_mask = get_mask(p_x, dt)
+    mk = masks or {}
     p_e = all_embedding(params, cfg, p_x, p_a, p_c, p_mask, target=False)
     if trace is not None:
         trace["p_mask"], trace["p_embed"] = p_mask, p_e
+    if "embed" in mk:
+        p_e = p_e * mk["embed"]
     for i in range(cfg.n_blocks):
-        p_e = sa_block(params, cfg, i, p_e, p_mask)
+        p_e = sa_block(params, cfg, i, p_e, p_mask, masks)
         if trace is not None:
             trace[f"block{i}"] = p_e
     p_e = layer_norm(p_e, params["norm.weight"], params["norm.bias"])
@@ -219,7 +231,8 @@ def carca_forward(params: Params, cfg: CarcaConfig, profile: Tuple[Tensor, Tenso
     for gi, (o_x, o_a, o_c) in enumerate(targets):
         o_mask = get_mask(o_x, dt)
         o_e = all_embedding(params, cfg, o_x, o_a, o_c, o_mask, target=True)
-        y, w = cross_block(params, cfg, o_e, o_mask, p_e, p_mask, training, return_w=True)
+        y, w = cross_block(params, cfg, o_e, o_mask, p_e, p_mask, training, return_w=True,
+                           drop_mask=mk.get(f"cross{gi}"))
         if trace is not None:
             trace[f"o_embed{gi}"], trace[f"dec_w{gi}"] = o_e, w
         ys.append(y)
