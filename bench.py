@@ -148,12 +148,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=C2["B"])
+    ap.add_argument("--no-table", action="store_true", help="skip the attribute-table (ids-only batch) measurement")
     ap.add_argument("--train-steps", type=int, default=8, help="extra, untimed-by-the-headline train-step measurement")
     args = ap.parse_args()
 
+    # The box exposes every host core but the cgroup grants only a share of them: torch's default intra-op pool
+    # (one thread per visible core, spinning after each CPU op) burns the quota and gets the launching thread
+    # throttled for tens of ms -- seen as random 2x slow bench runs.  Size the pool to the real share.
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
+    os.environ.setdefault("MKL_NUM_THREADS", str(host_cores()))
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", str(host_cores()))
+    os.environ.setdefault("KMP_BLOCKTIME", "0")      # worker threads sleep, not spin, after a parallel region
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     import torch
     import torch.distributed as dist
 
+    torch.set_num_threads(host_cores())
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -174,18 +185,19 @@ def main():
     profile_cpu, target_cpu, profile, target = build_inputs(c, 1234 + rank, device)
     fl = flops_per_user(c)
 
-    feat_events, ca_events = [], []
+
+    # hipEvent_t quadruples recorded INSIDE carca_forward, on the launch stream, around the feature GEMM and the
+    # scoring kernel of every timed step
+    pool = [[ops.HipEvent() for _ in range(4)] for _ in range(args.steps)]
+    used = []
 
     def step(record):
-        ev = None
         if record:
-            ev = {"feat": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)),
-                  "cross": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))}
-            feat_events.append(ev["feat"])
-            ca_events.append(ev["cross"])
-        ops.set_stage_events(ev)
+            evs = pool[len(used)]
+            used.append(evs)
+            ops.set_fused_events([e.handle for e in evs])
         y = model(profile=profile, targets=[target])
-        ops.set_stage_events(None)
+        ops.set_fused_events(None)
         return y
 
     def fence():
@@ -198,22 +210,56 @@ def main():
         for _ in range(args.warmup):
             step(False)
         fence()
+        time.sleep(0.3)  # let the CPU pools used while building the inputs go idle (cgroup CPU quota, see above)
+        for _ in range(3):
+            step(False)
+        fence()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        host_done = []
         t0 = time.perf_counter()
+        g0.record()
         for _ in range(args.steps):
             y = step(True)
+            host_done.append(time.perf_counter())
+        g1.record()
         fence()
         elapsed = time.perf_counter() - t0
+        gpu_span_ms = g0.elapsed_time(g1)
+        host_issue_ms = 1e3 * (host_done[-1] - t0)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    # extension path: attribute table resident in HBM, ids-only batches, gather fused into the GEMM
+    table_info = None
+    if not args.no_table:
+        import numpy as np
+
+        tab = torch.from_numpy(np.random.default_rng(99).random((c["n_items"], c["n_attrs"]), dtype=np.float32))
+        tab[0] = 0
+        model.embeds.register_attr_table(tab.to(device))
+        pf, tg = (profile[0], None, profile[2]), (target[0], None, target[2])
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                model(profile=pf, targets=[tg])
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                model(profile=pf, targets=[tg])
+            fence()
+            dt = time.perf_counter() - t1
+        model.embeds.register_attr_table(None)
+        table_info = {"users_per_s": world * c["B"] * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+                      "what": "same model and ids; attrs gathered by item id from a device-resident [n_items, n_attrs] "
+                              "table inside the feature GEMM (register_attr_table), no dense attrs batch tensor"}
+
     train_info = None
     if args.train_steps > 0:
         train_info = measure_train(c, model, rank, world, device, args.train_steps)
 
-    feat_ms = sorted(a.elapsed_time(b) for a, b in feat_events)
-    ca_ms = sorted(a.elapsed_time(b) for a, b in ca_events)
+    feat_ms = sorted(e[0].elapsed_ms(e[1]) for e in used)
+    ca_ms = sorted(e[2].elapsed_ms(e[3]) for e in used)
     feat_avg = sum(feat_ms) / len(feat_ms)
     ca_avg = sum(ca_ms) / len(ca_ms)
 
@@ -232,6 +278,9 @@ def main():
                                    "n_items=12102, random-init weights" % c["B"],
                        "users_per_gpu_per_step": c["B"], "parallelism": f"users sharded x{world}, no data-path collective"},
             "model_tflops": value * fl["total"] / 1e12,
+            "timeline": {"gpu_span_ms": gpu_span_ms, "host_issue_ms": host_issue_ms,
+                         "note": "GPU time between the first and last launch of the timed region, and host time to "
+                                 "issue them; wall >> gpu_span means the host, not the GPU, set the pace"},
             "roofline": {"kernel": "gemm_rows_kernel<128,96,32,FEAT> (AllEmbedding feats_embed, carca.py:86)",
                          "bound": "mfma", "achieved": feat_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
@@ -243,6 +292,8 @@ def main():
         }
         if train_info is not None:
             out["train"] = train_info
+        if table_info is not None:
+            out["attr_table_path"] = table_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, model, profile_cpu, target_cpu)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -107,13 +107,14 @@ class PackDesc(C.Structure):
 
 class RowSeg(C.Structure):
     _fields_ = [("ids", _fp), ("attrs", _fp), ("ctx", _fp), ("e_out", _fp), ("rows", C.c_int32), ("T", C.c_int32),
-                ("add_pos", C.c_int32), ("attrs_bstride", C.c_int64), ("ctx_bstride", C.c_int64)]
+                ("add_pos", C.c_int32), ("attrs_bstride", C.c_int64), ("ctx_bstride", C.c_int64),
+                ("attrs_table", _fp)]
 
 
 class GemmSeg(C.Structure):
     _fields_ = [("a0", _fp), ("a1", _fp), ("c", _fp), ("ids", _fp), ("add", _fp), ("gate", _fp), ("rowscale", _fp),
                 ("rows", C.c_int32), ("T", C.c_int32), ("add_pos", C.c_int32), ("a0_bstride", C.c_int64),
-                ("a1_bstride", C.c_int64)]
+                ("a1_bstride", C.c_int64), ("a0_gather", C.c_int32)]
 
 
 class GemmDesc(C.Structure):
@@ -127,7 +128,7 @@ class GemmDesc(C.Structure):
 
 class WgradSeg(C.Structure):
     _fields_ = [("dy", _fp), ("x", _fp), ("x1", _fp), ("ids", _fp), ("rows", C.c_int32), ("T", C.c_int32),
-                ("x_bstride", C.c_int64), ("x1_bstride", C.c_int64)]
+                ("x_bstride", C.c_int64), ("x1_bstride", C.c_int64), ("x_gather", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -166,6 +167,19 @@ class TargetGroup(C.Structure):
     _fields_ = [("o", _fp), ("ids", _fp), ("y", _fp), ("N", C.c_int32)]
 
 
+MAX_BLOCKS = 8
+
+
+class ForwardDesc(C.Structure):
+    _fields_ = [("segs", RowSeg * MAX_SEGS), ("ngroups", C.c_int32), ("B", C.c_int32), ("L", C.c_int32),
+                ("d", C.c_int32), ("g", C.c_int32), ("H", C.c_int32), ("n_attrs", C.c_int32), ("n_ctx", C.c_int32),
+                ("n_blocks", C.c_int32), ("ld_e", C.c_int32), ("items_w", _fp), ("feats_w", _fp), ("feats_b", _fp),
+                ("joint_w", _fp), ("joint_b", _fp), ("pos", _fp), ("zq", _fp), ("x_work", _fp * 2),
+                ("sa", SaWeights * MAX_BLOCKS), ("sa_residual", C.c_int32 * MAX_BLOCKS), ("ca", CaWeights),
+                ("ca_residual", C.c_int32), ("training", C.c_int32), ("y", _fp * MAX_GROUPS),
+                ("N", C.c_int32 * MAX_GROUPS), ("p_normed", _fp)]
+
+
 # name -> (restype, argtypes); every symbol include/carca_hip.h declares
 _i, _f = C.c_int, C.c_float
 SIGNATURES = {
@@ -191,6 +205,10 @@ SIGNATURES = {
     "carca_cross_attn_bwd": (_i, [_fp, _fp, _fp, C.POINTER(CrossBwdGroup), _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i,
                                   _f, _fp]),
     "carca_unpack_grads": (_i, [C.POINTER(PackDesc), _i, _i, _fp]),
+    "carca_forward": (_i, [C.POINTER(ForwardDesc), C.POINTER(_fp), _fp]),
+    "carca_event_create": (_i, [C.POINTER(_fp)]),
+    "carca_event_destroy": (_i, [_fp]),
+    "carca_event_elapsed_ms": (_i, [_fp, _fp, C.POINTER(C.c_float)]),
     "carca_bce_fwd": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp, _fp]),
     "carca_rank_metrics": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),
 }

@@ -112,7 +112,8 @@ class _CarcaFn(torch.autograd.Function):
         ys = ctx.saved_tensors
         ngroups = st["ngroups"]
         g_feats = emb.feats_embed.weight.shape[0]
-        n_attrs = st["segs"][0][1].shape[-1]
+        table = emb.attr_table()
+        n_attrs = table.shape[1] if table is not None else st["segs"][0][1].shape[-1]
 
         # ---------------- decoder: sigmoid/ffn head + cross-attention (carca.py:340-347) ----------------
         cp = _Packs(dec.attn, [], dev)
@@ -218,7 +219,11 @@ class _CarcaFn(torch.autograd.Function):
         g_feats_w, g_feats_b = gbp[id(emb.feats_embed.weight)], gbp[id(emb.feats_embed.bias)]
         n_ctx = st["segs"][0][2].shape[-1]
         # d feats_embed.weight = dq^T [attrs | ctx]: one launch, the ctx columns ride along as a second X source
-        ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x=st["segs"][i][1], x1=st["segs"][i][2] if n_ctx else None)
+        def xsrc(i):  # dense attrs batch tensor, or the registered table gathered by id
+            a = st["segs"][i][1]
+            return dict(x=a) if a is not None else dict(x=table, x_gather=True, ids=ids_seg[i])
+
+        ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x1=st["segs"][i][2] if n_ctx else None, **xsrc(i))
                         for i in range(nseg)], g_feats, n_attrs, g_feats_w, g_feats_b, K1=n_ctx)
         ctx.st = None
         return (None, None, None) + tuple(grads)
@@ -226,7 +231,8 @@ class _CarcaFn(torch.autograd.Function):
 
 def carca_forward_with_grad(model, profile, targets) -> List[Tensor]:
     params = [p for p in model.parameters()]
-    if any(t.requires_grad for t in profile) or any(t.requires_grad for grp in targets for t in grp):
+    if any(t is not None and t.requires_grad for t in profile) or \
+            any(t is not None and t.requires_grad for grp in targets for t in grp):
         raise CarcaHipError("gradients with respect to the input tensors (ids/attrs/ctx) are not produced")
     return list(_CarcaFn.apply(model, tuple(profile), [tuple(g) for g in targets], *params))
 

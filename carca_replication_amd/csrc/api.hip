@@ -116,3 +116,72 @@ extern "C" int carca_pack_weights(const CarcaPackDesc* descs, int n, void* strea
   }
   return CARCA_OK;
 }
+
+// ---- whole-forward host entry point + event helpers ---------------------------------------------------------
+extern "C" int carca_event_create(void** ev_out) {
+  CARCA_CHECK_ARG(ev_out, "event_create: null");
+  hipEvent_t e;
+  hipError_t rc = hipEventCreate(&e);
+  if (rc != hipSuccess) {
+    carca_set_error("hipEventCreate: %s", hipGetErrorString(rc));
+    return (int)rc;
+  }
+  *ev_out = (void*)e;
+  return CARCA_OK;
+}
+extern "C" int carca_event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+  return CARCA_OK;
+}
+extern "C" int carca_event_elapsed_ms(void* start, void* stop, float* ms_out) {
+  CARCA_CHECK_ARG(start && stop && ms_out, "event_elapsed_ms: null");
+  hipError_t rc = hipEventElapsedTime(ms_out, (hipEvent_t)start, (hipEvent_t)stop);
+  if (rc != hipSuccess) {
+    carca_set_error("hipEventElapsedTime: %s", hipGetErrorString(rc));
+    return (int)rc;
+  }
+  return CARCA_OK;
+}
+
+extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(D && D->ngroups >= 1 && D->ngroups <= CARCA_MAX_GROUPS && D->n_blocks >= 0 &&
+                      D->n_blocks <= CARCA_MAX_BLOCKS,
+                  "forward: bad group / block count");
+  CARCA_CHECK_ARG(D->x_work[0] && D->x_work[1] && D->zq, "forward: null workspace");
+  const int nseg = D->ngroups + 1;
+  int rc;
+#define CARCA_TRY(call) \
+  do {                  \
+    rc = (call);        \
+    if (rc != CARCA_OK) return rc; \
+  } while (0)
+  CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
+                            D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_GATHER, stream_));
+  if (ev) (void)hipEventRecord((hipEvent_t)ev[0], stream);
+  CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
+                            D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_FEAT, stream_));
+  if (ev) (void)hipEventRecord((hipEvent_t)ev[1], stream);
+  CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
+                            D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_JOINT, stream_));
+  const float* x = D->segs[0].e_out;
+  for (int i = 0; i < D->n_blocks; ++i) {
+    float* y = D->x_work[i & 1];
+    CARCA_TRY(carca_sa_block_fwd(x, D->ld_e, D->segs[0].ids, y, D->ld_e, D->B, D->L, D->d, D->H, &D->sa[i],
+                                 D->sa_residual[i], nullptr, nullptr, stream_));
+    x = y;
+  }
+  CarcaTargetGroup groups[CARCA_MAX_GROUPS];
+  for (int gi = 0; gi < D->ngroups; ++gi) {
+    groups[gi].o = D->segs[gi + 1].e_out;
+    groups[gi].ids = D->segs[gi + 1].ids;
+    groups[gi].y = D->y[gi];
+    groups[gi].N = D->N[gi];
+  }
+  if (ev) (void)hipEventRecord((hipEvent_t)ev[2], stream);
+  CARCA_TRY(carca_cross_score_fwd(x, D->ld_e, D->segs[0].ids, D->p_normed, groups, D->ngroups, D->ld_e, D->B, D->L,
+                                  D->d, D->H, &D->ca, D->ca_residual, D->training, nullptr, nullptr, stream_));
+  if (ev) (void)hipEventRecord((hipEvent_t)ev[3], stream);
+#undef CARCA_TRY
+  return CARCA_OK;
+}

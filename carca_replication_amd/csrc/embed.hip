@@ -56,15 +56,17 @@ extern "C" int carca_embed_fwd(const CarcaRowSeg* segs, int nseg, int n_attrs, i
   int row_start = 0;
   for (int s = 0; s < nseg; ++s) {
     const CarcaRowSeg& sg = segs[s];
-    CARCA_CHECK_ARG(sg.rows >= 1 && sg.T >= 1 && sg.ids && sg.attrs && sg.e_out && (n_ctx == 0 || sg.ctx),
+    CARCA_CHECK_ARG(sg.rows >= 1 && sg.T >= 1 && sg.ids && (sg.attrs || sg.attrs_table) && sg.e_out &&
+                        (n_ctx == 0 || sg.ctx),
                     "embed_fwd: segment %d has null pointers or no rows", s);
     CARCA_CHECK_ARG(!sg.add_pos || pos, "embed_fwd: segment %d wants pos but pos is NULL", s);
     ga.ids[s] = sg.ids;
     ga.row_start[s] = row_start;
     CarcaGemmSeg& f = fa.seg[s];
-    f.a0 = sg.attrs; f.a1 = sg.ctx; f.c = zq + (size_t)row_start * ldz + d; f.ids = sg.ids;
+    f.a0 = sg.attrs_table ? sg.attrs_table : sg.attrs; f.a1 = sg.ctx;
+    f.a0_gather = sg.attrs_table ? 1 : 0; f.c = zq + (size_t)row_start * ldz + d; f.ids = sg.ids;
     f.rows = sg.rows; f.T = sg.T; f.add_pos = 0;
-    f.a0_bstride = sg.attrs_bstride; f.a1_bstride = sg.ctx_bstride;
+    f.a0_bstride = sg.attrs_table ? 0 : sg.attrs_bstride; f.a1_bstride = sg.ctx_bstride;
     CarcaGemmSeg& j = ja.seg[s];
     j.a0 = zq + (size_t)row_start * ldz; j.a1 = nullptr; j.c = sg.e_out; j.ids = sg.ids;
     j.rows = sg.rows; j.T = sg.T; j.add_pos = sg.add_pos;

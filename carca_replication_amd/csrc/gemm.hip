@@ -67,7 +67,9 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
     const int slot = tid + i * NT;
     const int gr = min(row0 + slot / C4, sg.rows - 1);
     const int ub = gr / sg.T, ut = gr - ub * sg.T;
-    aoff0[i] = sg.a0_bstride ? (size_t)ub * sg.a0_bstride + (size_t)ut * D.lda0 : (size_t)gr * D.lda0;
+    aoff0[i] = sg.a0_gather ? (size_t)sg.ids[gr] * D.lda0
+               : sg.a0_bstride ? (size_t)ub * sg.a0_bstride + (size_t)ut * D.lda0
+                               : (size_t)gr * D.lda0;
     aoff1[i] = sg.a1_bstride ? (size_t)ub * sg.a1_bstride + (size_t)ut * D.lda1 : (size_t)gr * D.lda1;
   }
 
@@ -254,7 +256,9 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < sg.rows) {
         const int64_t bs = src1 ? sg.x1_bstride : sg.x_bstride;
-        const size_t roff = bs ? (size_t)(row / sg.T) * bs + (size_t)(row % sg.T) * ldx : (size_t)row * ldx;
+        const size_t roff = (!src1 && sg.x_gather) ? (size_t)sg.ids[row] * ldx
+                            : bs                    ? (size_t)(row / sg.T) * bs + (size_t)(row % sg.T) * ldx
+                                                    : (size_t)row * ldx;
         const float* p = (src1 ? sg.x1 : sg.x) + roff + k0 + c4 * 4;
         if (k_full) {
           v = *reinterpret_cast<const f32x4_u*>(p);
@@ -356,7 +360,7 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
                     s);
     if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
     CARCA_CHECK_ARG(!(sg.add_pos && (!desc->pos || sg.T < 1 || !sg.ids)) && !(desc->mask_rows && !sg.ids) &&
-                        !(sg.rowscale && !desc->colvec),
+                        !(sg.rowscale && !desc->colvec) && !(sg.a0_gather && !sg.ids),
                     "gemm_rows: segment %d epilogue needs a pointer that is NULL", s);
     g.rb_start[s] = rb;
     rb += (sg.rows + BM - 1) / BM;
@@ -385,6 +389,7 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
     CARCA_CHECK_ARG(sg.rows >= 1 && sg.dy && sg.x && !(desc->mask_rows && !sg.ids) && (desc->K1 == 0 || sg.x1),
                     "gemm_wgrad: segment %d malformed", s);
     CARCA_CHECK_ARG(sg.T >= 1 || (!sg.x_bstride && !sg.x1_bstride), "gemm_wgrad: segment %d needs T >= 1", s);
+    CARCA_CHECK_ARG(!(sg.x_gather && !sg.ids), "gemm_wgrad: segment %d gathers without ids", s);
     if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
     g.chunk_start[s] = chunks;
     chunks += (sg.rows + BR - 1) / BR;

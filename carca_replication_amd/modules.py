@@ -152,6 +152,22 @@ class AllEmbedding(Embedding):
         nn.init.zeros_(self.feats_embed.bias)
         nn.init.zeros_(self.joint_embed.bias)
 
+    def register_attr_table(self, attrs: Optional[Tensor]) -> None:
+        """API-compatible extension: keep the item-attribute matrix [n_items, n_attrs] (row 0 = pad,
+        exactly `load_attrs`' output, data.py:28-35) on the device.  Afterwards `a` may be None in forward():
+        the rows are gathered by item id inside the feature GEMM, so no dense [B, T, n_attrs] batch tensor is
+        built, shipped over PCIe or read from HBM.  Valid because the dataset always sets a = attrs[x]
+        (data.py:119-132,167-187).  Pass None to unregister."""
+        if attrs is None:
+            self.__dict__.pop("_attr_table", None)
+            return
+        if attrs.dim() != 2 or attrs.shape[1] > self.feats_embed.in_features:
+            raise CarcaHipError("register_attr_table: expected [n_items, n_attrs] with n_attrs <= feats_embed.in_features")
+        self.__dict__["_attr_table"] = attrs.detach().to(self.items_embed.weight.device, torch.float32).contiguous()
+
+    def attr_table(self) -> Optional[Tensor]:
+        return self.__dict__.get("_attr_table")
+
     def _pos(self, T: int) -> Optional[Tensor]:
         if hasattr(self.enc, "position_table"):
             return self.enc.position_table(T)
@@ -165,7 +181,7 @@ class AllEmbedding(Embedding):
             pos = self._pos(T)
         call = [(x, a, c, (not tgt) and pos is not None) for (x, a, c, tgt) in segs]
         return ops.embed_fwd(call, self.items_embed.weight, self.feats_embed.weight, self.feats_embed.bias,
-                             self.joint_embed.weight, self.joint_embed.bias, pos, ld_e)
+                             self.joint_embed.weight, self.joint_embed.bias, pos, ld_e, attrs_table=self.attr_table())
 
     def forward(self, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
         """`mask` must be get_mask(x) (it always is in the reference, carca.py:413-426); the kernel uses x != 0."""
@@ -235,6 +251,7 @@ class _PackedModule:
         state = dict(self.__dict__)
         state.pop("_pack_cache", None)
         state.pop("_final_norm_params", None)
+        state.pop("_plan", None)
         return state
 
 
@@ -388,6 +405,11 @@ def _pad_cols(t: Tensor, width: int) -> Tensor:
 
 
 class CARCA(Model):
+    def __getstate__(self):  # the cached inference plan holds ctypes structs
+        state = dict(self.__dict__)
+        state.pop("_plan", None)
+        return state
+
     def __init__(self, d: int, p: float, emb: Embedding, enc: Iterable[Encoder], dec: Decoder):
         super().__init__()
         self.embeds = emb
@@ -415,10 +437,99 @@ class CARCA(Model):
         # each group's scores are squeezed the way CrossAttentionBlock does (carca.py:346), then joined (carca.py:431)
         return torch.cat([y.squeeze() for y in ys], dim=-1)
 
+    # ---- inference: one host call per forward (include/carca_hip.h: carca_forward) -----------------------------
+    def _fused_ok(self, trace) -> bool:
+        if trace is not None or len(self.encoder) > _lib.MAX_BLOCKS:
+            return False
+        if self.training and (self.dropout.p > 0 or self.decoder.drop_p() > 0 or
+                              any(b.drop_p() > 0 for b in self.encoder)):
+            return False
+        return True
+
+    def _forward_fused(self, profile, targets, events=None) -> List[Tensor]:
+        import ctypes as C
+
+        p_x, p_a, p_c = profile
+        emb, dec = self.embeds, self.decoder
+        d, H = emb.d, dec.attn.H
+        dev = p_x.device
+        ops._need_cuda(p_x)
+        dpi, _, _ = ops.padded_dims(d, H)
+        B, L = p_x.shape
+        g = emb.feats_embed.out_features
+        table = emb.attr_table()
+        n_ctx = p_c.shape[-1]
+        n_attrs = table.shape[1] if table is not None else p_a.shape[-1]
+        Ns = tuple(int(t[0].shape[1]) for t in targets)
+        key = (str(dev), B, L, Ns, n_attrs, n_ctx, table is not None)
+        plan = self.__dict__.get("_plan")
+        if plan is None or plan["key"] != key:
+            rows = B * (L + sum(Ns))
+            f32 = dict(dtype=torch.float32, device=dev)
+            plan = dict(key=key, D=_lib.ForwardDesc(), zq=torch.empty(rows, d + g, **f32),
+                        es=[torch.empty(B, T, dpi, **f32) for T in (L,) + Ns],
+                        xw=[torch.empty(B, L, dpi, **f32) for _ in range(2)])
+            self.__dict__["_plan"] = plan
+        D = plan["D"]
+        segs = [(p_x, p_a, p_c)] + [tuple(t) for t in targets]
+        keep = []
+        pos = emb._pos(L)
+        for i, (x, a, c) in enumerate(segs):
+            ops._need_cuda(x, a, c)
+            T = x.shape[1]
+            if x.shape[0] != B or c.shape != (B, T, n_ctx) or (a is not None and a.shape != (B, T, n_attrs)):
+                raise CarcaHipError("forward: ids / attrs / ctx shapes do not match")
+            if a is None and table is None:
+                raise CarcaHipError("forward: attrs is None and no attribute table is registered")
+            x32 = ops._ids32(x)
+            S = D.segs[i]
+            S.ids, S.e_out, S.rows, S.T = x32.data_ptr(), plan["es"][i].data_ptr(), B * T, T
+            S.add_pos = int(i == 0 and pos is not None)
+            if a is not None:
+                a, a_bs = ops._btk_view(a)
+                S.attrs, S.attrs_bstride, S.attrs_table = a.data_ptr(), a_bs, None
+            else:
+                S.attrs, S.attrs_bstride, S.attrs_table = None, 0, table.data_ptr()
+            if n_ctx > 0:
+                c, c_bs = ops._btk_view(c)
+                S.ctx, S.ctx_bstride = c.data_ptr(), c_bs
+            keep += [x32, a, c]
+        D.ngroups, D.B, D.L, D.d, D.g, D.H = len(targets), B, L, d, g, H
+        D.n_attrs, D.n_ctx, D.n_blocks, D.ld_e = n_attrs, n_ctx, len(self.encoder), dpi
+        prm = [emb.items_embed.weight, emb.feats_embed.weight, emb.feats_embed.bias, emb.joint_embed.weight,
+               emb.joint_embed.bias]
+        for t in prm:
+            ops._need_cuda(t)
+        D.items_w, D.feats_w, D.feats_b, D.joint_w, D.joint_b = [t.data_ptr() for t in prm]
+        if pos is not None:
+            pos = pos.detach().contiguous()
+            keep.append(pos)
+        D.pos = pos.data_ptr() if pos is not None else None
+        D.zq = plan["zq"].data_ptr()
+        D.x_work[0], D.x_work[1] = plan["xw"][0].data_ptr(), plan["xw"][1].data_ptr()
+        for i, blk in enumerate(self.encoder):
+            blk._check_mode()
+            D.sa[i] = blk.weights_struct(dev)
+            keep.append(blk.__dict__["_pack_cache"])
+            D.sa_residual[i] = int(bool(blk.residual))
+        D.ca = dec.weights_struct(dev, self.norm)
+        D.ca_residual, D.training = int(bool(dec.residual)), int(bool(self.training))
+        ys = []
+        for gi, N in enumerate(Ns):
+            y = torch.empty(B, N, dtype=torch.float32, device=dev)
+            ys.append(y)
+            D.y[gi], D.N[gi] = y.data_ptr(), N
+        D.p_normed = None
+        ev = (C.c_void_p * 4)(*events) if events is not None else None
+        _lib.check(_lib.load().carca_forward(C.byref(D), ev, ops._stream()), "forward")
+        return ys
+
     def forward_nograd(self, profile, targets, trace: Optional[dict] = None) -> List[Tensor]:
         p_x, p_a, p_c = profile
         if len(targets) > _lib.MAX_GROUPS:
             raise CarcaHipError(f"at most {_lib.MAX_GROUPS} target groups per call")
+        if self._fused_ok(trace):
+            return self._forward_fused(profile, targets, events=ops.fused_events())
         d = self.embeds.d
         H = self.decoder.attn.H
         dpi, _, _ = ops.padded_dims(d, H)

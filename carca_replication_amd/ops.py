@@ -26,6 +26,39 @@ def set_stage_events(ev) -> None:
     _stage_events = ev
 
 
+# raw hipEvent_t handles [feat0, feat1, cross0, cross1] for the one-call forward (bench.py), or None
+_fused_events = None
+
+
+def set_fused_events(handles) -> None:
+    global _fused_events
+    _fused_events = handles
+
+
+def fused_events():
+    return _fused_events
+
+
+class HipEvent:
+    """A hipEvent_t owned through the C ABI (no torch.cuda.Event: those cannot be handed to carca_forward)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _lib.check(_lib.load().carca_event_create(C.byref(h)), "event_create")
+        self.handle = h.value
+
+    def elapsed_ms(self, stop: "HipEvent") -> float:
+        ms = C.c_float()
+        _lib.check(_lib.load().carca_event_elapsed_ms(self.handle, stop.handle, C.byref(ms)), "event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.load().carca_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -180,16 +213,21 @@ class PackedWeights:
 # embed
 # --------------------------------------------------------------------------------------------------
 def embed_fwd(segs: Sequence[Tuple[Tensor, Tensor, Tensor, bool]], items_w: Tensor, feats_w: Tensor, feats_b: Tensor,
-              joint_w: Tensor, joint_b: Tensor, pos: Optional[Tensor], ld_e: int) -> Tuple[List[Tensor], Tensor]:
+              joint_w: Tensor, joint_b: Tensor, pos: Optional[Tensor], ld_e: int,
+              attrs_table: Optional[Tensor] = None) -> Tuple[List[Tensor], Tensor]:
     """AllEmbedding over several (ids [B,T], attrs [B,T,A], ctx [B,T,Cx], add_pos) segments in one call.
 
-    Returns ([e_s [B,T,ld_e]], zq [sum B*T, d+g]); e_s[..., d:] is zero.
+    A segment's attrs may be None when `attrs_table` [n_items, A] is given: its rows are then gathered by item id
+    inside the GEMM's operand load.  Returns ([e_s [B,T,ld_e]], zq [sum B*T, d+g]); e_s[..., d:] is zero.
     """
     lib = _lib.load()
     if not 1 <= len(segs) <= _lib.MAX_SEGS:
         raise CarcaHipError(f"embed_fwd takes 1..{_lib.MAX_SEGS} segments, got {len(segs)}")
     d, g = items_w.shape[1], feats_w.shape[0]
-    n_attrs = segs[0][1].shape[-1]
+    if attrs_table is not None:
+        attrs_table = _f32(attrs_table)
+        _need_cuda(attrs_table)
+    n_attrs = attrs_table.shape[1] if attrs_table is not None else segs[0][1].shape[-1]
     n_ctx = segs[0][2].shape[-1] if segs[0][2] is not None else 0
     if feats_w.shape[1] != n_attrs + n_ctx or joint_w.shape != (d, d + g):
         raise CarcaHipError("embed_fwd: weight shapes do not match the inputs")
@@ -202,16 +240,22 @@ def embed_fwd(segs: Sequence[Tuple[Tensor, Tensor, Tensor, bool]], items_w: Tens
     for i, (ids, attrs, ctx, add_pos) in enumerate(segs):
         _need_cuda(ids, attrs, ctx)
         B, T = ids.shape
-        if attrs.shape != (B, T, n_attrs) or ctx.shape != (B, T, n_ctx):
+        if attrs is None and attrs_table is None:
+            raise CarcaHipError("embed_fwd: attrs is None and no attribute table is registered")
+        if (attrs is not None and attrs.shape != (B, T, n_attrs)) or ctx.shape != (B, T, n_ctx):
             raise CarcaHipError("embed_fwd: attrs/ctx shapes do not match ids")
         ids32 = _ids32(ids)
-        attrs, a_bs = _btk_view(attrs)
+        attrs, a_bs = _btk_view(attrs) if attrs is not None else (None, 0)
         ctx, c_bs = _btk_view(ctx) if n_ctx > 0 else (ctx, 0)
         e = torch.empty(B, T, ld_e, dtype=torch.float32, device=dev)
         keep += [ids32, attrs, ctx]
         outs.append(e)
         a = arr[i]
-        a.ids, a.attrs, a.ctx, a.e_out = ids32.data_ptr(), attrs.data_ptr(), ctx.data_ptr(), e.data_ptr()
+        a.ids, a.ctx, a.e_out = ids32.data_ptr(), ctx.data_ptr(), e.data_ptr()
+        if attrs is not None:
+            a.attrs = attrs.data_ptr()
+        else:
+            a.attrs_table = attrs_table.data_ptr()
         a.rows, a.T, a.add_pos = B * T, T, int(bool(add_pos))
         a.attrs_bstride, a.ctx_bstride = a_bs, c_bs
         total += B * T
@@ -479,6 +523,8 @@ def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, ma
         if dy.dim() != 2 or dy.stride(1) != 1 or dy.dtype != torch.float32:
             raise CarcaHipError("gemm_wgrad: dy must be a 2-D fp32 view with unit inner stride")
         xp, lx, xrows, xT, xbs = xinfo(sg["x"], "x")
+        if sg.get("x_gather"):
+            xrows = dy.shape[0]  # x is a table indexed by ids
         if dy.shape[0] != xrows:
             raise CarcaHipError("gemm_wgrad: dy and x row counts differ")
         ld_dy = dy.stride(0) if ld_dy is None else ld_dy
@@ -487,9 +533,10 @@ def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, ma
             raise CarcaHipError("gemm_wgrad: all segments must share row strides")
         S = D.seg[i]
         S.dy, S.x, S.rows, S.T, S.x_bstride = dy.data_ptr(), xp, dy.shape[0], xT, xbs
+        S.x_gather = int(bool(sg.get("x_gather", False)))
         if K1:
             x1p, lx1, x1rows, x1T, x1bs = xinfo(sg["x1"], "x1")
-            if x1rows != xrows or (xbs and x1bs and x1T != xT):
+            if x1rows != dy.shape[0] or (xbs and x1bs and x1T != xT):
                 raise CarcaHipError("gemm_wgrad: x1 does not match x")
             ld_x1 = lx1 if ld_x1 is None else ld_x1
             S.x1, S.x1_bstride = x1p, x1bs

@@ -94,6 +94,9 @@ typedef struct CarcaGemmSeg {
   /* Rows of a0 / a1 may belong to a [B, T, K] VIEW whose users are a0_bstride / a1_bstride elements apart
    * (e.g. o_a[:, :L] of train.py:86-88): row r then starts at (r / T) * bstride + (r % T) * lda.  0 = dense. */
   int64_t a0_bstride, a1_bstride;
+  /* 1: a0 is a TABLE [n_items, lda0] and row r reads a0[ids[r]] (attribute rows gathered by item id inside the
+   * GEMM's operand load -- no dense [B, T, n_attrs] tensor exists; data.py:119-132 always sets p_a = attrs[p_x]) */
+  int32_t a0_gather;
 } CarcaGemmSeg;
 typedef struct CarcaGemmDesc {
   CarcaGemmSeg seg[CARCA_MAX_SEGS];
@@ -127,6 +130,7 @@ typedef struct CarcaWgradSeg {
   int32_t rows;
   int32_t T;                     /* rows per user, used with the strides below */
   int64_t x_bstride, x1_bstride; /* users of a [B, T, K] view are this many elements apart; 0 = dense */
+  int32_t x_gather;              /* 1: x is a table [n_items, ld_x], row r reads x[ids[r]] */
 } CarcaWgradSeg;
 typedef struct CarcaWgradDesc {
   CarcaWgradSeg seg[CARCA_MAX_SEGS];
@@ -158,6 +162,7 @@ typedef struct CarcaRowSeg {
   int32_t T;          /* slots per user (position index = row % T) */
   int32_t add_pos;    /* 1: add pos[row % T] (profile side, carca.py:91-92) */
   int64_t attrs_bstride, ctx_bstride; /* elements between users when attrs/ctx are [B, T, .] views; 0 = dense */
+  const float* attrs_table; /* optional [n_items, n_attrs]: when set, `attrs` is ignored and row r uses attrs_table[ids[r]] */
 } CarcaRowSeg;
 int carca_embed_fwd(const CarcaRowSeg* segs /*host*/, int nseg, int n_attrs, int n_ctx, int d, int g,
                     const float* items_w /*[n_items,d]*/, const float* feats_w /*[g,n_attrs+n_ctx]*/,
@@ -279,6 +284,38 @@ int carca_mask_mul(const float* x, int ld_x, const uint8_t* mask, int ld_m, floa
 /* Inverse of carca_pack_weights for gradients: real[r][c] (+)= packed[rp][cp] (same descriptor fields:
  * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
 int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);
+
+/* ---- a7: CARCA.forward (carca.py:411-431), inference path, as ONE host call -----------------------------
+ * Issues the whole launch sequence -- gather, feature GEMM, joint GEMM, every SelfAttentionBlock, final norm +
+ * grouped cross-attention scoring -- on `stream` without returning to the caller in between, so that a slow
+ * host thread cannot starve the GPU (the Python layer needs ~25 interpreter-level calls per forward otherwise).
+ * No tensors are saved for a backward pass and no dropout is applied: eval mode, or train mode without grad
+ * at p = 0.  All buffers are caller-allocated:
+ *   segs[0] = profile, segs[1..ngroups] = target groups (their e_out feed the scoring kernel),
+ *   x_work[2] = two [B*L, ld_e] ping-pong buffers for the blocks' outputs.
+ * ev (optional, host array of 4 hipEvent_t): recorded before/after the feature GEMM and before/after the
+ * scoring kernel, on `stream`, so a benchmark can time exactly those kernels inside its timed region. */
+#define CARCA_MAX_BLOCKS 8
+typedef struct CarcaForwardDesc {
+  CarcaRowSeg segs[CARCA_MAX_SEGS];
+  int32_t ngroups;
+  int32_t B, L, d, g, H, n_attrs, n_ctx, n_blocks, ld_e;
+  const float *items_w, *feats_w, *feats_b, *joint_w, *joint_b, *pos;
+  float* zq;
+  float* x_work[2];
+  CarcaSaWeights sa[CARCA_MAX_BLOCKS];
+  int32_t sa_residual[CARCA_MAX_BLOCKS];
+  CarcaCaWeights ca;
+  int32_t ca_residual, training;
+  float* y[CARCA_MAX_GROUPS];   /* [B, N_g] outputs */
+  int32_t N[CARCA_MAX_GROUPS];
+  float* p_normed;              /* optional [B*L, ld_e] */
+} CarcaForwardDesc;
+int carca_forward(const CarcaForwardDesc* desc /*host*/, void* const* ev /*4 hipEvent_t or NULL*/, void* stream);
+/* Event helpers so that a host language without a HIP binding can time kernels on the launch stream. */
+int carca_event_create(void** ev_out);
+int carca_event_destroy(void* ev);
+int carca_event_elapsed_ms(void* start, void* stop, float* ms_out); /* both must have completed */
 
 /* ---- a8: BinaryCrossEntropy.forward (carca.py:441-444) -----------------------------------------
  * loss = sum(l * m) / sum(m), l = -(t log(y+eps) + (1-t) log(1-y+eps)), m = (ids != 0).

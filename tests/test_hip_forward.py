@@ -201,3 +201,43 @@ def test_unsupported_shape_is_an_error_not_a_fallback():
     with pytest.raises(CarcaHipError):
         with torch.no_grad():
             model(profile=dev(profile), targets=[dev(target)])
+
+
+def test_attr_table_gather_equals_dense_batch():
+    """register_attr_table: ids-only batches (a = None) give the same scores and gradients as dense attrs."""
+    from carca_replication_amd import modules as M
+
+    cfg = O.CarcaConfig(d=90, H=3, n_blocks=1)
+    n_items, n_attrs, n_ctx, g, L, N, B = 300, 72, 5, 130, 50, 101, 6
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    profile, target, table = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=9)
+    model = model_from_params(P, cfg).eval()
+    with torch.no_grad():
+        dense = model(profile=dev(profile), targets=[dev(target)])
+    model.embeds.register_attr_table(table.cuda())
+    with torch.no_grad():
+        gathered = model(profile=(profile[0].cuda(), None, profile[2].cuda()),
+                         targets=[(target[0].cuda(), None, target[2].cuda())])
+    assert torch.equal(dense, gathered)  # same kernel, same rows, same order of operations
+    # training step through the gathered path
+    pos = (target[0][:, :L].contiguous(), None, target[2][:, :L].contiguous())
+    neg = (target[0][:, L:2 * L].contiguous(), None, target[2][:, L:2 * L].contiguous())
+    y_true = torch.cat([torch.ones(B, L), torch.zeros(B, L)], 1).int().cuda()
+    o_x = torch.cat([pos[0], neg[0]], 1).cuda()
+    model.train()
+    grads = []
+    for use_table in (True, False):
+        model.zero_grad()
+        if use_table:
+            tg = [(pos[0].cuda(), None, pos[2].cuda()), (neg[0].cuda(), None, neg[2].cuda())]
+            pf = (profile[0].cuda(), None, profile[2].cuda())
+        else:
+            model.embeds.register_attr_table(None)
+            tg = [(pos[0].cuda(), table[pos[0]].cuda(), pos[2].cuda()), (neg[0].cuda(), table[neg[0]].cuda(), neg[2].cuda())]
+            pf = dev(profile)
+        y = model(profile=pf, targets=tg)
+        M.BinaryCrossEntropy()(y, y_true, M.get_mask(o_x)).backward()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters()})
+    for n in grads[0]:
+        ref = grads[1][n]
+        assert float((grads[0][n] - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, n
