@@ -210,7 +210,7 @@ SIGNATURES = {
     "carca_event_destroy": (_i, [_fp]),
     "carca_event_elapsed_ms": (_i, [_fp, _fp, C.POINTER(C.c_float)]),
     "carca_bce_fwd": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp, _fp]),
-    "carca_rank_metrics": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),
+    "carca_rank_metrics": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
 }
 
 

@@ -54,15 +54,17 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ y, 
 }
 
 // one wave per user: rank of candidate 0 = number of strictly larger scores among candidates 1..N-1
-__global__ void rank_kernel(const float* __restrict__ y, int B, int N, int k, int32_t* __restrict__ rank,
-                            float* __restrict__ sums) {
+__global__ void rank_kernel(const float* __restrict__ y, int B, int N, int k, const int32_t* __restrict__ pos,
+                            int32_t* __restrict__ rank, float* __restrict__ sums) {
   const int lane = threadIdx.x & 63;
   const int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (u >= B) return;
   const float* yr = y + (size_t)u * N;
-  const float y0 = yr[0];
+  const int pc = pos ? pos[u] : 0;  // column of the positive (0 in the reference's datasets, data.py:165,190)
+  const float y0 = yr[pc];
   float gt = 0.f, eq = 0.f;
-  for (int j = 1 + lane; j < N; j += 64) {
+  for (int j = lane; j < N; j += 64) {
+    if (j == pc) continue;
     const float v = yr[j];
     gt += v > y0 ? 1.f : 0.f;
     eq += v == y0 ? 1.f : 0.f;
@@ -91,11 +93,12 @@ extern "C" int carca_bce_fwd(const float* y, const int32_t* y_true, const int32_
   return CARCA_OK;
 }
 
-extern "C" int carca_rank_metrics(const float* y, int B, int N, int k, int32_t* rank, float* sums, void* stream_) {
+extern "C" int carca_rank_metrics(const float* y, int B, int N, int k, const int32_t* pos, int32_t* rank, float* sums,
+                                  void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(y && sums && B >= 1 && N >= 1 && k >= 1, "rank_metrics: null pointer or bad dims");
   const int blocks = (B + 3) / 4;
-  hipLaunchKernelGGL(rank_kernel, dim3(blocks), dim3(256), 0, stream, y, B, N, k, rank, sums);
+  hipLaunchKernelGGL(rank_kernel, dim3(blocks), dim3(256), 0, stream, y, B, N, k, pos, rank, sums);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

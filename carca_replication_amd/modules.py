@@ -194,6 +194,96 @@ class AllEmbedding(Embedding):
 
 
 # ------------------------------------------------------------------------------------------------
+# ablation variants (carca.py:98-198, 352-395; knn.py) -- OUTSIDE the hot path.
+# They construct with the reference's signatures and state_dict so that scripts/training.py:66-100 imports and
+# builds them, but no HIP kernel is written for their forward: calling one raises, it never falls back to ATen.
+# ------------------------------------------------------------------------------------------------
+def _not_built(name: str):
+    raise CarcaHipError(f"{name} is an ablation variant outside the accelerated CARCA path (AllEmbedding + "
+                        f"SelfAttentionBlock + CrossAttentionBlock: run scripts/training.py with "
+                        f"--embedding all --decoder ca); no HIP kernel is built for it and there is no CPU fallback")
+
+
+class AttrCtxEmbedding(Embedding):
+    def __init__(self, d: int, g: int, n_ctx: int, n_attrs: int, enc: Encoding):
+        super().__init__()
+        self.d, self.enc = d, enc
+        self.feats_embed = nn.Linear(in_features=n_ctx + n_attrs, out_features=g)
+        self.joint_embed = nn.Linear(in_features=g, out_features=d)
+        for m in (self.feats_embed, self.joint_embed):
+            nn.init.xavier_uniform_(m.weight)
+        for m in (self.feats_embed, self.joint_embed):
+            nn.init.zeros_(m.bias)
+
+    def forward(self, x, a, c, mask, target):
+        _not_built("AttrCtxEmbedding")
+
+
+class AttrEmbedding(Embedding):
+    def __init__(self, d: int, g: int, n_attrs: int, enc: Encoding):
+        super().__init__()
+        self.d, self.enc = d, enc
+        self.feats_embed = nn.Linear(in_features=n_attrs, out_features=g)
+        self.joint_embed = nn.Linear(in_features=g, out_features=d)
+        for m in (self.feats_embed, self.joint_embed):
+            nn.init.xavier_uniform_(m.weight)
+        for m in (self.feats_embed, self.joint_embed):
+            nn.init.zeros_(m.bias)
+
+    def forward(self, x, a, c, mask, target):
+        _not_built("AttrEmbedding")
+
+
+class IdEmbedding(Embedding):
+    def __init__(self, n_items: int, d: int, enc: Encoding):
+        super().__init__()
+        self.d, self.enc = d, enc
+        self.items_embed = nn.Embedding(num_embeddings=n_items, embedding_dim=d, padding_idx=0)
+        nn.init.xavier_uniform_(self.items_embed.weight)
+        with torch.no_grad():
+            self.items_embed.weight[0].zero_()
+
+    def forward(self, x, a, c, mask, target):
+        _not_built("IdEmbedding")
+
+
+class MLPIdEmbedding(Embedding):
+    def __init__(self, n_items: int, d: int, g: int, enc: Encoding):
+        super().__init__()
+        self.d, self.enc = d, enc
+        self.items_embed = nn.Embedding(num_embeddings=n_items, embedding_dim=g, padding_idx=0)
+        self.feats_embed = nn.Linear(in_features=g, out_features=d)
+        nn.init.xavier_uniform_(self.items_embed.weight)
+        nn.init.xavier_uniform_(self.feats_embed.weight)
+        nn.init.zeros_(self.feats_embed.bias)
+        with torch.no_grad():
+            self.items_embed.weight[0].zero_()
+
+    def forward(self, x, a, c, mask, target):
+        _not_built("MLPIdEmbedding")
+
+
+class DotProduct(Decoder):
+    def __init__(self) -> None:
+        super().__init__()
+        self.sig = nn.Sigmoid()
+
+    def forward(self, o, o_mask, p, p_mask):
+        _not_built("DotProduct")
+
+
+class WeightedDotProduct(Decoder):
+    def __init__(self, gamma: float, seq_len: int, normalize: bool, device: str):
+        super().__init__()
+        self.norm = normalize
+        self.W = (gamma ** torch.arange(0, seq_len, device=device).unsqueeze(0).repeat(seq_len, 1)).tril().unsqueeze(-1)
+        self.sig = nn.Sigmoid()
+
+    def forward(self, o, o_mask, p, p_mask):
+        _not_built("WeightedDotProduct")
+
+
+# ------------------------------------------------------------------------------------------------
 # attention (carca.py:204-349)
 # ------------------------------------------------------------------------------------------------
 
@@ -247,15 +337,14 @@ class _PackedModule:
         self.__dict__["_pack_cache"] = (key, pw)
         return pw
 
-    def __getstate__(self):  # torch.save(model) pickles whole modules (train.py:124): drop the ctypes cache
-        state = dict(self.__dict__)
-        state.pop("_pack_cache", None)
-        state.pop("_final_norm_params", None)
-        state.pop("_plan", None)
+    def __getstate__(self):  # torch.save(model) pickles whole modules (train.py:124): drop the ctypes caches
+        state = dict(super().__getstate__())
+        for k in ("_pack_cache", "_final_norm_params", "_plan"):
+            state.pop(k, None)
         return state
 
 
-class SelfAttentionBlock(Encoder, _PackedModule):
+class SelfAttentionBlock(_PackedModule, Encoder):
     def __init__(self, d: int, H: int, p: float, residual: bool):
         super().__init__()
         self.residual = residual
@@ -320,7 +409,7 @@ class SelfAttentionBlock(Encoder, _PackedModule):
         return y[..., :d]
 
 
-class CrossAttentionBlock(Decoder, _PackedModule):
+class CrossAttentionBlock(_PackedModule, Decoder):
     def __init__(self, d: int, H: int, p: float, residual: bool):
         super().__init__()
         self.residual = residual
@@ -404,12 +493,7 @@ def _pad_cols(t: Tensor, width: int) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 
 
-class CARCA(Model):
-    def __getstate__(self):  # the cached inference plan holds ctypes structs
-        state = dict(self.__dict__)
-        state.pop("_plan", None)
-        return state
-
+class CARCA(_PackedModule, Model):
     def __init__(self, d: int, p: float, emb: Embedding, enc: Iterable[Encoder], dec: Decoder):
         super().__init__()
         self.embeds = emb

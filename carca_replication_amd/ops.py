@@ -397,8 +397,10 @@ def bce_fwd(y: Tensor, y_true: Tensor, ids: Tensor, eps: float = 1e-8, want_grad
     return loss[0], dy
 
 
-def rank_metrics(y: Tensor, k: int, sums: Optional[Tensor] = None, want_rank: bool = False):
-    """Accumulates [HR@k sum, NDCG@k sum, ties] into `sums` (device float[3]) for y [B, N], positive in column 0."""
+def rank_metrics(y: Tensor, k: int, sums: Optional[Tensor] = None, want_rank: bool = False,
+                 pos: Optional[Tensor] = None):
+    """Accumulates [HR@k sum, NDCG@k sum, ties] into `sums` (device float[3]) for y [B, N]; the positive sits in
+    column pos[u] (default: column 0)."""
     lib = _lib.load()
     _need_cuda(y)
     y = _f32(y)
@@ -406,8 +408,9 @@ def rank_metrics(y: Tensor, k: int, sums: Optional[Tensor] = None, want_rank: bo
     if sums is None:
         sums = torch.zeros(3, dtype=torch.float32, device=y.device)
     rank = torch.empty(B, dtype=torch.int32, device=y.device) if want_rank else None
-    _lib.check(lib.carca_rank_metrics(y.data_ptr(), B, N, k, rank.data_ptr() if want_rank else None, sums.data_ptr(),
-                                      _stream()), "rank_metrics")
+    pos32 = _ids32(pos.reshape(-1)) if pos is not None else None
+    _lib.check(lib.carca_rank_metrics(y.data_ptr(), B, N, k, _ptr(pos32), rank.data_ptr() if want_rank else None,
+                                      sums.data_ptr(), _stream()), "rank_metrics")
     return sums, rank
 
 

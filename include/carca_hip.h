@@ -327,11 +327,12 @@ int carca_bce_fwd(const float* y, const int32_t* y_true, const int32_t* ids, int
                   float* loss_out, float* dy /*or NULL*/, const float* denom /*or NULL*/, void* stream);
 
 /* ---- M: compute_HR / compute_NDCG (train.py:15-32) without the sort ----------------------------
- * rank[u] = #{j > 0 : y[u][j] > y[u][0]}; sums[0] += [rank < k], sums[1] += [rank<k]/log2(rank+2),
- * sums[2] += #{j > 0 : y[u][j] == y[u][0]} (ties: the reference's unstable sort is undefined there).
+ * With p = pos[u] (the positive's column; NULL = column 0 as in data.py:165,190):
+ * rank[u] = #{j != p : y[u][j] > y[u][p]}; sums[0] += [rank < k], sums[1] += [rank<k]/log2(rank+2),
+ * sums[2] += #{j != p : y[u][j] == y[u][p]} (ties: the reference's unstable sort is undefined there).
  * sums is accumulated into (caller zeroes it once per evaluation). */
-int carca_rank_metrics(const float* y /*[B,N]*/, int B, int N, int k, int32_t* rank /*[B] or NULL*/,
-                       float* sums /*[3]*/, void* stream);
+int carca_rank_metrics(const float* y /*[B,N]*/, int B, int N, int k, const int32_t* pos /*[B] or NULL*/,
+                       int32_t* rank /*[B] or NULL*/, float* sums /*[3]*/, void* stream);
 
 #ifdef __cplusplus
 }

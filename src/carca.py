@@ -6,11 +6,17 @@ the encodings) are the HIP-backed mirrors in carca_replication_amd.modules.
 from carca_replication_amd.modules import (  # noqa: F401
     CARCA,
     AllEmbedding,
+    AttrCtxEmbedding,
+    AttrEmbedding,
     BinaryCrossEntropy,
     CrossAttentionBlock,
+    DotProduct,
+    IdEmbedding,
     IdentityEncoding,
     LearnableEncoding,
+    MLPIdEmbedding,
     MultiHeadAttention,
     PositionalEncoding,
     SelfAttentionBlock,
+    WeightedDotProduct,
 )

@@ -1,0 +1,96 @@
+"""The wiring of the reference's scripts/training.py:103-186, reproduced with the names it imports from src.*:
+data files -> load_* -> three CARCADatasets -> DataLoaders -> CARCA -> Adam -> train().  Runs on the GPU."""
+import os
+import pickle
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_dataset(tmp, n_users=40, n_items=60, n_attrs=12, n_ctx=3, seed=0):
+    rng = np.random.default_rng(seed)
+    attrs = rng.random((n_items - 1, n_attrs)).astype(np.float32)  # load_attrs prepends the pad row
+    profiles, ctx, lines = {}, {}, []
+    for u in range(1, n_users + 1):
+        items = [int(v) for v in rng.choice(np.arange(1, n_items), size=int(rng.integers(4, 12)), replace=False)]
+        profiles[u] = items
+        for it in items:
+            ctx[(u, it)] = [float(v) for v in rng.random(n_ctx)]
+            lines.append(f"{u} {it}")
+    with open(os.path.join(tmp, "attrs.dat"), "wb") as fh:
+        pickle.dump(attrs, fh)
+    with open(os.path.join(tmp, "ctx.dat"), "wb") as fh:
+        pickle.dump(ctx, fh)
+    with open(os.path.join(tmp, "profiles.txt"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+def test_training_script_wiring_end_to_end(tmp_path, monkeypatch):
+    import torch.nn as nn
+    from torch.optim import Adam
+    from torch.utils.data import DataLoader
+
+    from src.carca import CARCA, AllEmbedding, CrossAttentionBlock, IdentityEncoding, SelfAttentionBlock
+    from src.data import CARCADataset, load_attrs, load_ctx, load_profiles, set_datapath
+    from src.train import evaluate, train
+
+    _write_dataset(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    set_datapath(str(tmp_path))
+    attrs, ctx = load_attrs("attrs.dat"), load_ctx("ctx.dat")
+    user_ids, item_ids, profiles = load_profiles("profiles.txt")
+    n_items, n_ctx, n_attrs = attrs.shape[0], next(iter(ctx.values())).shape[0], attrs.shape[1]
+    random.seed(0)
+    torch.manual_seed(0)
+    mk = lambda mode: CARCADataset(user_ids=user_ids, item_ids=item_ids, profiles=profiles, attrs=attrs, ctx=ctx,  # noqa: E731
+                                   profile_seq_len=8, target_seq_len=20, mode=mode, test=True)
+    train_loader = DataLoader(mk("train"), batch_size=16, shuffle=True, num_workers=0)
+    val_loader = DataLoader(mk("val"), batch_size=16, shuffle=False, num_workers=0)
+    test_loader = DataLoader(mk("test"), batch_size=16, shuffle=False, num_workers=0)
+    d, g, H, p = 64, 48, 2, 0.2
+    emb = AllEmbedding(n_items, d, g, n_ctx, n_attrs, IdentityEncoding())
+    enc = nn.ModuleList([SelfAttentionBlock(d, H, p, True) for _ in range(2)])
+    model = CARCA(d=d, p=p, emb=emb, enc=enc, dec=CrossAttentionBlock(d, H, p, True)).to("cuda")
+    optim = Adam(model.parameters(), lr=1e-3, weight_decay=0.0, betas=(0.9, 0.98))
+    hr0, ndcg0, loss0 = evaluate(model, val_loader, "cuda", 10)
+    model = train(model=model, train_loader=train_loader, val_loader=val_loader, test_loader=test_loader, device="cuda",
+                  optim=optim, epochs=3, early_stop=20, datadir="results_run", verbose=1)
+    hr1, ndcg1, loss1 = evaluate(model, val_loader, "cuda", 10)
+    assert 0.0 <= hr1 <= 1.0 and 0.0 <= ndcg1 <= 1.0 and np.isfinite(loss1)
+    logs = [f for f in os.listdir("results_run") if f.endswith(".csv")]
+    assert len(logs) == 1
+    rows = [ln.strip().split(";") for ln in open(os.path.join("results_run", logs[0]))]
+    assert [r[2] for r in rows].count("train") == 3 and [r[2] for r in rows].count("val") == 3 and rows[-1][2] == "test"
+    assert any(f.endswith(".pth") for f in os.listdir("results_run"))
+
+
+def test_compute_hr_ndcg_match_reference_fixture():
+    from src.train import compute_HR, compute_NDCG
+    from tests.golden_util import load
+
+    fx = load("g4_metrics")
+    scores, y_true = fx.ins["scores"].cuda(), fx.ins["y_true"].cuda()
+    for k in (1, 5, 10, 20):
+        assert compute_HR(scores, y_true, k) == float(fx.outs[f"hr{k}"])
+        assert abs(compute_NDCG(scores, y_true, k) - float(fx.outs[f"ndcg{k}"])) < 1e-4
+    # positive in another column than 0
+    perm = torch.randperm(scores.shape[1], device="cuda")
+    assert compute_HR(scores[:, perm], y_true[:, perm], 10) == float(fx.outs["hr10"])
+
+
+def test_ablation_variants_construct_but_refuse_to_run():
+    from carca_replication_amd import CarcaHipError
+    from src.carca import AttrCtxEmbedding, DotProduct, IdEmbedding, IdentityEncoding, MLPIdEmbedding
+
+    e = IdEmbedding(10, 8, IdentityEncoding())
+    assert tuple(e.state_dict()["items_embed.weight"].shape) == (10, 8)
+    assert set(AttrCtxEmbedding(8, 4, 2, 3, IdentityEncoding()).state_dict()) == {
+        "feats_embed.weight", "feats_embed.bias", "joint_embed.weight", "joint_embed.bias"}
+    assert set(MLPIdEmbedding(10, 8, 4, IdentityEncoding()).state_dict()) == {
+        "items_embed.weight", "feats_embed.weight", "feats_embed.bias"}
+    with pytest.raises(CarcaHipError):
+        DotProduct()(None, None, None, None)
