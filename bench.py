@@ -263,6 +263,12 @@ def main():
     feat_avg = sum(feat_ms) / len(feat_ms)
     ca_avg = sum(ca_ms) / len(ca_ms)
 
+    traffic = None  # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/README.md)
+    tpath = os.path.join(ROOT, "profiles", "r01_c_feat_gemm_traffic.json")
+    if c["B"] == C2["B"] and os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic = json.load(fh)["hbm_bytes_per_launch"]
+
     if rank == 0:
         users = world * c["B"] * args.steps
         value = users / elapsed
@@ -281,11 +287,14 @@ def main():
             "timeline": {"gpu_span_ms": gpu_span_ms, "host_issue_ms": host_issue_ms,
                          "note": "GPU time between the first and last launch of the timed region, and host time to "
                                  "issue them; wall >> gpu_span means the host, not the GPU, set the pace"},
-            "roofline": {"kernel": "gemm_rows_kernel<128,96,32,FEAT> (AllEmbedding feats_embed, carca.py:86)",
+            "roofline": {"kernel": "gemm_rows_kernel<128,96,32>, feature GEMM launch (AllEmbedding feats_embed, carca.py:86)",
                          "bound": "mfma", "achieved": feat_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
+                                         "WRITE_SIZE, separate passes, profiles/r01_c_feat_gemm_traffic.json; algorithmic "
+                                         "bytes 359 MB",
                          "avg_ms": feat_avg, "min_ms": feat_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["feat"] / 1e9},
-            "roofline_cross_score": {"kernel": "cross_score_kernel<96,32,3> (final norm + CrossAttentionBlock)",
+            "roofline_cross_score": {"kernel": "cross_score_kernel_w16<96,32,3> (final norm + CrossAttentionBlock)",
                                      "bound": "mfma", "achieved": ca_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                                      "unit": "TFLOP/s", "frac": ca_tflops / PEAK_F32_MFMA_TFLOPS, "avg_ms": ca_avg,
                                      "min_ms": ca_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["ca"] / 1e9},
