@@ -29,7 +29,7 @@ struct GemmDev {
   int nrb, ncb;
 };
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int PF = 1>
 __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev args) {
   constexpr int NW = BM / 32, NT = NW * 64, LS = BK + 4, TN = BN / 32;
   constexpr int C4 = BK / 4;  // float4 slots per tile row
@@ -59,7 +59,7 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
   const int nt0 = (D.K0 + BK - 1) / BK, nt1 = (D.K1 + BK - 1) / BK;
   const int ntiles = nt0 + nt1;
 
-  f32x4 ra[A_PER], rbv[B_PER];
+  f32x4 ra[PF][A_PER], rbv[PF][B_PER];  // PF tiles of global loads in flight (register ring, compile-time indexed)
   // element offsets of this thread's A rows inside each k-source (loop invariant; handles [B, T, K] views)
   size_t aoff0[A_PER], aoff1[A_PER];
 #pragma unroll
@@ -82,7 +82,7 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
     v[3] = kk + 3 < klen ? p[3] : 0.f;
     return v;
   };
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t, f32x4 (&ra_)[A_PER], f32x4 (&rb_)[B_PER]) {
     const bool src1 = t >= nt0;
     const int k0 = (src1 ? t - nt0 : t) * BK;
     const int klen = src1 ? D.K1 : D.K0;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
       const int slot = tid + i * NT;
       if (A_SLOTS % NT != 0 && slot >= A_SLOTS) break;
       const int c4 = slot % C4;
-      ra[i] = load4(abase + (src1 ? aoff1[i] : aoff0[i]) + k0 + c4 * 4, full, k0 + c4 * 4, klen);
+      ra_[i] = load4(abase + (src1 ? aoff1[i] : aoff0[i]) + k0 + c4 * 4, full, k0 + c4 * 4, klen);
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
@@ -103,23 +103,23 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
       if (B_SLOTS % NT != 0 && slot >= B_SLOTS) break;
       const int r = slot / C4, c4 = slot - r * C4;
       const int gn = min(n0 + r, D.N - 1);
-      rbv[i] = load4(bbase + (size_t)gn * ldb + k0 + c4 * 4, full, k0 + c4 * 4, klen);
+      rb_[i] = load4(bbase + (size_t)gn * ldb + k0 + c4 * 4, full, k0 + c4 * 4, klen);
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const f32x4 (&ra_)[A_PER], const f32x4 (&rb_)[B_PER]) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int slot = tid + i * NT;
       if (A_SLOTS % NT != 0 && slot >= A_SLOTS) break;
       const int r = slot / C4, c4 = slot - r * C4;
-      *reinterpret_cast<f32x4*>(&As[r * LS + c4 * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&As[r * LS + c4 * 4]) = ra_[i];
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int slot = tid + i * NT;
       if (B_SLOTS % NT != 0 && slot >= B_SLOTS) break;
       const int r = slot / C4, c4 = slot - r * C4;
-      *reinterpret_cast<f32x4*>(&Bs[r * LS + c4 * 4]) = rbv[i];
+      *reinterpret_cast<f32x4*>(&Bs[r * LS + c4 * 4]) = rb_[i];
     }
   };
 
@@ -133,11 +133,7 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
   const float* a_frag = &As[(wave * 32 + lr) * LS + 4 * lh];
   const float* b_frag = &Bs[lr * LS + 4 * lh];
 
-  load_tile(0);
-  store_tile();
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) load_tile(t + 1);
+  auto compute_tile = [&]() {
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(a_frag + kg * 8);
@@ -149,10 +145,38 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tn] = mfma32(a[st], b[tn][st], acc[tn]);
     }
+  };
+  if constexpr (PF == 1) {
+    load_tile(0, ra[0], rbv[0]);
+    store_tile(ra[0], rbv[0]);
     __syncthreads();
-    if (t + 1 < ntiles) {
-      store_tile();
+    for (int t = 0; t < ntiles; ++t) {
+      if (t + 1 < ntiles) load_tile(t + 1, ra[0], rbv[0]);
+      compute_tile();
       __syncthreads();
+      if (t + 1 < ntiles) {
+        store_tile(ra[0], rbv[0]);
+        __syncthreads();
+      }
+    }
+  } else {
+    // short K loops at low occupancy (narrow outputs): the global latency of a tile is longer than its MFMAs,
+    // so keep PF tiles of loads in flight in a register ring; the ring slot is a compile-time index.
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (u < ntiles) load_tile(u, ra[u], rbv[u]);
+    for (int t0 = 0; t0 < ntiles; t0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int t = t0 + u;
+        if (t < ntiles) {
+          store_tile(ra[u], rbv[u]);
+          __syncthreads();
+          if (t + PF < ntiles) load_tile(t + PF, ra[u], rbv[u]);
+          compute_tile();
+          __syncthreads();
+        }
+      }
     }
   }
 
@@ -349,7 +373,7 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   CARCA_CHECK_ARG(desc->K1 == 0 || (desc->bt1 && desc->lda1 >= desc->K1 && desc->ldb1 >= desc->K1),
                   "gemm_rows: bad k-source 1");
   CARCA_CHECK_ARG(desc->ncols_out >= desc->N && desc->ncols_out <= desc->ldc, "gemm_rows: ncols_out outside [N, ldc]");
-  constexpr int BM = 128, BN = 96, BK = 32;
+  constexpr int BM = 128, BK = 32;
   GemmDev g{};
   g.d = *desc;
   int rb = 0;
@@ -367,9 +391,24 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   }
   g.rb_start[desc->nseg] = rb;
   g.nrb = rb;
-  g.ncb = (desc->ncols_out + BN - 1) / BN;
-  const int grid = ((rb + 7) / 8) * 8 * g.ncb;
-  hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
+  // Narrow outputs (the joint embedding, every d-wide product of the backward pass) give too few 128 x 96 blocks
+  // to fill 256 CUs and leave one long MFMA chain per wave: 32-column blocks triple the wave count instead
+  // (the A tile is re-read from L2 by the three column blocks of a row block, which share an XCD).
+  const bool narrow = carca_tuning(CARCA_TUNE_GEMM_VARIANT) != 1 && rb * ((desc->ncols_out + 95) / 96) < 384;
+  if (narrow) {
+    constexpr int BN = 32;
+    g.ncb = (desc->ncols_out + BN - 1) / BN;
+    const int grid = ((rb + 7) / 8) * 8 * g.ncb;
+    if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 2)
+      hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, 1>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
+    else
+      hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, 4>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
+  } else {
+    constexpr int BN = 96;
+    g.ncb = (desc->ncols_out + BN - 1) / BN;
+    const int grid = ((rb + 7) / 8) * 8 * g.ncb;
+    hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
+  }
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
