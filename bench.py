@@ -172,11 +172,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # test hooks (a 1-GPU box cannot run RCCL across ranks): CARCA_BENCH_DEVICE pins every rank to one device and
+    # CARCA_BENCH_BACKEND=gloo swaps the collective backend, so the N > 1 control flow can be rehearsed there
+    if os.environ.get("CARCA_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["CARCA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("CARCA_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from carca_replication_amd import ops
 

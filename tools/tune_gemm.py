@@ -24,9 +24,7 @@ ref = None
 res = {v: [] for v in variants}
 for rnd in range(6):
     for v in variants:
-        lib.carca_set_tuning(0, v % 10)
-        lib.carca_set_tuning(2, (v // 10) % 10)  # tens digit 1: no K rotation
-        lib.carca_set_tuning(1, v // 100)
+        lib.carca_set_tuning(0, v)
         evs = []
         for it in range(8):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
