@@ -364,6 +364,25 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
 
 }  // namespace
 
+template <int BM, int BN, int BK, int PF>
+static int launch_gemm_rows(const CarcaGemmDesc* desc, hipStream_t stream) {
+  GemmDev g{};
+  g.d = *desc;
+  int rb = 0;
+  for (int s = 0; s < desc->nseg; ++s) {
+    if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
+    g.rb_start[s] = rb;
+    rb += (desc->seg[s].rows + BM - 1) / BM;
+  }
+  g.rb_start[desc->nseg] = rb;
+  g.nrb = rb;
+  g.ncb = (desc->ncols_out + BN - 1) / BN;
+  const int grid = ((rb + 7) / 8) * 8 * g.ncb;
+  hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, PF>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
 extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(desc && desc->nseg >= 1 && desc->nseg <= CARCA_MAX_SEGS, "gemm_rows: bad segment count");
@@ -373,44 +392,24 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   CARCA_CHECK_ARG(desc->K1 == 0 || (desc->bt1 && desc->lda1 >= desc->K1 && desc->ldb1 >= desc->K1),
                   "gemm_rows: bad k-source 1");
   CARCA_CHECK_ARG(desc->ncols_out >= desc->N && desc->ncols_out <= desc->ldc, "gemm_rows: ncols_out outside [N, ldc]");
-  constexpr int BM = 128, BK = 32;
-  GemmDev g{};
-  g.d = *desc;
-  int rb = 0;
+  int rb128 = 0;
   for (int s = 0; s < desc->nseg; ++s) {
     const CarcaGemmSeg& sg = desc->seg[s];
     CARCA_CHECK_ARG(sg.rows >= 1 && sg.a0 && sg.c && (desc->K1 == 0 || sg.a1), "gemm_rows: segment %d malformed", s);
     CARCA_CHECK_ARG(sg.T >= 1 || (!sg.a0_bstride && !sg.a1_bstride && !sg.add_pos), "gemm_rows: segment %d needs T >= 1",
                     s);
-    if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
     CARCA_CHECK_ARG(!(sg.add_pos && (!desc->pos || sg.T < 1 || !sg.ids)) && !(desc->mask_rows && !sg.ids) &&
                         !(sg.rowscale && !desc->colvec) && !(sg.a0_gather && !sg.ids),
                     "gemm_rows: segment %d epilogue needs a pointer that is NULL", s);
-    g.rb_start[s] = rb;
-    rb += (sg.rows + BM - 1) / BM;
+    rb128 += (sg.rows + 127) / 128;
   }
-  g.rb_start[desc->nseg] = rb;
-  g.nrb = rb;
   // Narrow outputs (the joint embedding, every d-wide product of the backward pass) give too few 128 x 96 blocks
   // to fill 256 CUs and leave one long MFMA chain per wave: 32-column blocks triple the wave count instead
   // (the A tile is re-read from L2 by the three column blocks of a row block, which share an XCD).
-  const bool narrow = carca_tuning(CARCA_TUNE_GEMM_VARIANT) != 1 && rb * ((desc->ncols_out + 95) / 96) < 384;
-  if (narrow) {
-    constexpr int BN = 32;
-    g.ncb = (desc->ncols_out + BN - 1) / BN;
-    const int grid = ((rb + 7) / 8) * 8 * g.ncb;
-    if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 2)
-      hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, 1>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
-    else
-      hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, 4>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
-  } else {
-    constexpr int BN = 96;
-    g.ncb = (desc->ncols_out + BN - 1) / BN;
-    const int grid = ((rb + 7) / 8) * 8 * g.ncb;
-    hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
-  }
-  CARCA_LAUNCH_CHECK();
-  return CARCA_OK;
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
+  const bool narrow = variant != 1 && rb128 * ((desc->ncols_out + 95) / 96) < 384;
+  if (narrow) return launch_gemm_rows<128, 32, 32, 4>(desc, stream);
+  return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
 }
 
 extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
