@@ -122,7 +122,7 @@ class GemmDesc(C.Structure):
                 ("K0", C.c_int32), ("K1", C.c_int32), ("bt0", _fp), ("bt1", _fp), ("ldb0", C.c_int32),
                 ("ldb1", C.c_int32), ("N", C.c_int32), ("ldc", C.c_int32), ("ncols_out", C.c_int32), ("bias", _fp),
                 ("pos", _fp), ("colvec", _fp), ("ld_add", C.c_int32), ("ld_gate", C.c_int32),
-                ("gate_slope", C.c_float), ("mask_rows", C.c_int32), ("gate_scale", C.c_float),
+                ("gate_slope", C.c_float), ("mask_rows", C.c_int32), ("alpha", C.c_float), ("gate_scale", C.c_float),
                 ("gate_zero_drops", C.c_int32)]
 
 
@@ -177,7 +177,8 @@ class ForwardDesc(C.Structure):
                 ("joint_w", _fp), ("joint_b", _fp), ("pos", _fp), ("zq", _fp), ("x_work", _fp * 2),
                 ("sa", SaWeights * MAX_BLOCKS), ("sa_residual", C.c_int32 * MAX_BLOCKS), ("ca", CaWeights),
                 ("ca_residual", C.c_int32), ("training", C.c_int32), ("y", _fp * MAX_GROUPS),
-                ("N", C.c_int32 * MAX_GROUPS), ("p_normed", _fp)]
+                ("N", C.c_int32 * MAX_GROUPS), ("p_normed", _fp), ("fold_wc", _fp), ("fold_bias", _fp),
+                ("fold_ldwc", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/carca_hip.h declares

@@ -148,7 +148,7 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
   CARCA_CHECK_ARG(D && D->ngroups >= 1 && D->ngroups <= CARCA_MAX_GROUPS && D->n_blocks >= 0 &&
                       D->n_blocks <= CARCA_MAX_BLOCKS,
                   "forward: bad group / block count");
-  CARCA_CHECK_ARG(D->x_work[0] && D->x_work[1] && D->zq, "forward: null workspace");
+  CARCA_CHECK_ARG(D->x_work[0] && D->x_work[1] && (D->zq || D->fold_wc), "forward: null workspace");
   const int nseg = D->ngroups + 1;
   int rc;
 #define CARCA_TRY(call) \
@@ -156,14 +156,40 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     rc = (call);        \
     if (rc != CARCA_OK) return rc; \
   } while (0)
-  CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
-                            D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_GATHER, stream_));
-  if (ev) (void)hipEventRecord((hipEvent_t)ev[0], stream);
-  CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
-                            D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_FEAT, stream_));
-  if (ev) (void)hipEventRecord((hipEvent_t)ev[1], stream);
-  CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
-                            D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_JOINT, stream_));
+  if (!D->fold_wc) {
+    CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
+                              D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_GATHER, stream_));
+    if (ev) (void)hipEventRecord((hipEvent_t)ev[0], stream);
+    CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
+                              D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_FEAT, stream_));
+    if (ev) (void)hipEventRecord((hipEvent_t)ev[1], stream);
+    CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
+                              D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_JOINT, stream_));
+  } else {
+    // folded embedding: e0 = sqrt(d) * E[ids] W_jz^T + bias_c ; e = ([attrs ; ctx] W_c^T + e0 (+ pos)) * mask
+    CARCA_CHECK_ARG(D->fold_bias && D->fold_ldwc >= D->n_attrs + D->n_ctx, "forward: folded weights malformed");
+    CarcaGemmDesc z{}, f{};
+    z.nseg = f.nseg = nseg;
+    for (int s = 0; s < nseg; ++s) {
+      const CarcaRowSeg& sg = D->segs[s];
+      CarcaGemmSeg& a = z.seg[s];
+      a.a0 = D->items_w; a.a0_gather = 1; a.ids = sg.ids; a.c = sg.e_out; a.rows = sg.rows; a.T = sg.T;
+      CarcaGemmSeg& b = f.seg[s];
+      b.a0 = sg.attrs_table ? sg.attrs_table : sg.attrs; b.a0_gather = sg.attrs_table ? 1 : 0;
+      b.a0_bstride = sg.attrs_table ? 0 : sg.attrs_bstride;
+      b.a1 = sg.ctx; b.a1_bstride = sg.ctx_bstride;
+      b.ids = sg.ids; b.c = sg.e_out; b.add = sg.e_out; b.rows = sg.rows; b.T = sg.T; b.add_pos = sg.add_pos;
+    }
+    z.lda0 = D->d; z.K0 = D->d; z.bt0 = D->joint_w; z.ldb0 = D->d + D->g;
+    z.N = D->d; z.ldc = D->ld_e; z.ncols_out = D->ld_e; z.bias = D->fold_bias; z.alpha = (float)sqrt((double)D->d);
+    CARCA_TRY(carca_gemm_rows(&z, stream_));
+    f.lda0 = D->n_attrs; f.lda1 = D->n_ctx; f.K0 = D->n_attrs; f.K1 = D->n_ctx;
+    f.bt0 = D->fold_wc; f.ldb0 = D->fold_ldwc; f.bt1 = D->fold_wc + D->n_attrs; f.ldb1 = D->fold_ldwc;
+    f.N = D->d; f.ldc = D->ld_e; f.ncols_out = D->ld_e; f.ld_add = D->ld_e; f.pos = D->pos; f.mask_rows = 1;
+    if (ev) (void)hipEventRecord((hipEvent_t)ev[0], stream);
+    CARCA_TRY(carca_gemm_rows(&f, stream_));
+    if (ev) (void)hipEventRecord((hipEvent_t)ev[1], stream);
+  }
   const float* x = D->segs[0].e_out;
   for (int i = 0; i < D->n_blocks; ++i) {
     float* y = D->x_work[i & 1];

@@ -194,7 +194,7 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
       if (row >= sg.rows) continue;
       float v = 0.f;
       if (n_ok) {
-        v = acc[tn][r] + bias;
+        v = (D.alpha != 0.f ? D.alpha * acc[tn][r] : acc[tn][r]) + bias;
         if (sg.add_pos) v += D.pos[(size_t)(row % sg.T) * D.N + n];
         if (sg.add) v += sg.add[(size_t)row * D.ld_add + n];
         if (sg.rowscale) v += sg.rowscale[row] * cv;

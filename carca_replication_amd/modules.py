@@ -152,6 +152,12 @@ class AllEmbedding(Embedding):
         nn.init.zeros_(self.feats_embed.bias)
         nn.init.zeros_(self.joint_embed.bias)
 
+    def __getstate__(self):  # keep device-side caches (attribute table, folded weights) out of checkpoints
+        state = dict(super().__getstate__())
+        state.pop("_attr_table", None)
+        state.pop("_fold_cache", None)
+        return state
+
     def register_attr_table(self, attrs: Optional[Tensor]) -> None:
         """API-compatible extension: keep the item-attribute matrix [n_items, n_attrs] (row 0 = pad,
         exactly `load_attrs`' output, data.py:28-35) on the device.  Afterwards `a` may be None in forward():
@@ -167,6 +173,26 @@ class AllEmbedding(Embedding):
 
     def attr_table(self) -> Optional[Tensor]:
         return self.__dict__.get("_attr_table")
+
+    def folded_weights(self):
+        """(W_c [d, ldw], bias_c [d]) with W_c = W_jq W_f and bias_c = W_jq b_f + b_j, composed on the device with
+        carca_gemm_rows and cached per weight version (inference only: see CarcaForwardDesc.fold_wc)."""
+        prm = (self.feats_embed.weight, self.feats_embed.bias, self.joint_embed.weight, self.joint_embed.bias)
+        key = tuple((p.data_ptr(), p._version) for p in prm)
+        cache = self.__dict__.get("_fold_cache")
+        if cache is not None and cache[0] == key:
+            return cache[1], cache[2]
+        Wf, bf, Wj, bj = (p.detach() for p in prm)
+        d, g, F = self.d, Wf.shape[0], Wf.shape[1]
+        wf_t = ops.PackedWeights([ops.PackItem(Wf, F, g, transposed=True)], Wf.device)  # Bt[n = F][k = g]
+        wf_t.pack()
+        wjq = Wj[:, d:]  # [d, g] view, row stride d + g
+        ldw = ((F + 3) // 4) * 4
+        (wc,) = ops.gemm_rows([dict(a0=wjq)], wf_t.view(0), F, g, ldw)
+        (bc,) = ops.gemm_rows([dict(a0=wjq, add=bj.view(d, 1))], bf.view(1, g), 1, g, 4)
+        bias_c = bc[:, 0].contiguous()
+        self.__dict__["_fold_cache"] = (key, wc, bias_c)
+        return wc, bias_c
 
     def _pos(self, T: int) -> Optional[Tensor]:
         if hasattr(self.enc, "position_table"):
@@ -339,7 +365,7 @@ class _PackedModule:
 
     def __getstate__(self):  # torch.save(model) pickles whole modules (train.py:124): drop the ctypes caches
         state = dict(super().__getstate__())
-        for k in ("_pack_cache", "_final_norm_params", "_plan"):
+        for k in ("_pack_cache", "_final_norm_params", "_plan", "_fold_cache"):
             state.pop(k, None)
         return state
 
@@ -521,6 +547,12 @@ class CARCA(_PackedModule, Model):
         # each group's scores are squeezed the way CrossAttentionBlock does (carca.py:346), then joined (carca.py:431)
         return torch.cat([y.squeeze() for y in ys], dim=-1)
 
+    def fold_embedding(self, on: bool = True) -> "CARCA":
+        """Opt-in inference shortcut: compose AllEmbedding's two Linear layers into one (include/carca_hip.h,
+        CarcaForwardDesc.fold_wc).  Same algebra, ~1e-6 relative fp32 re-association; ignored while training."""
+        self.__dict__["_fold"] = bool(on)
+        return self
+
     # ---- inference: one host call per forward (include/carca_hip.h: carca_forward) -----------------------------
     def _fused_ok(self, trace) -> bool:
         if trace is not None or len(self.encoder) > _lib.MAX_BLOCKS:
@@ -590,6 +622,12 @@ class CARCA(_PackedModule, Model):
             keep.append(pos)
         D.pos = pos.data_ptr() if pos is not None else None
         D.zq = plan["zq"].data_ptr()
+        if self.__dict__.get("_fold") and not self.training:
+            wc, bias_c = emb.folded_weights()
+            keep += [wc, bias_c]
+            D.fold_wc, D.fold_bias, D.fold_ldwc = wc.data_ptr(), bias_c.data_ptr(), wc.stride(0)
+        else:
+            D.fold_wc, D.fold_bias, D.fold_ldwc = None, None, 0
         D.x_work[0], D.x_work[1] = plan["xw"][0].data_ptr(), plan["xw"][1].data_ptr()
         for i, blk in enumerate(self.encoder):
             blk._check_mode()

@@ -424,7 +424,7 @@ def _ptr(t: Optional[Tensor]):
 def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[Tensor] = None, K1: int = 0,
               bias: Optional[Tensor] = None, pos: Optional[Tensor] = None, colvec: Optional[Tensor] = None,
               gate_slope: float = 0.01, mask_rows: bool = False, ncols_out: Optional[int] = None,
-              gate_scale: float = 1.0, gate_zero_drops: bool = False) -> List[Tensor]:
+              gate_scale: float = 1.0, gate_zero_drops: bool = False, alpha: float = 1.0) -> List[Tensor]:
     """C_s[m][n] = sum_k A_s[m][k] Bt[n][k] (+ epilogue) for every row segment s.
 
     segs: list of dicts with keys a0 [rows, lda0] and optionally a1, ids, add, gate, rowscale, T, add_pos, out.
@@ -492,7 +492,7 @@ def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[
     D.N, D.ldc, D.ncols_out = N, out_ld, out_ld if ncols_out is None else ncols_out
     D.bias, D.pos, D.colvec = _ptr(bias), _ptr(pos), _ptr(colvec)
     D.ld_add, D.ld_gate, D.gate_slope, D.mask_rows = ld_add or 0, ld_gate or 0, gate_slope, int(mask_rows)
-    D.gate_scale, D.gate_zero_drops = gate_scale, int(gate_zero_drops)
+    D.gate_scale, D.gate_zero_drops, D.alpha = gate_scale, int(gate_zero_drops), alpha
     _lib.check(lib.carca_gemm_rows(C.byref(D), _stream()), "gemm_rows")
     return outs
 

@@ -78,7 +78,7 @@ int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream);
  * (one launch for profile + target groups); k runs over up to two column sources (a0 | a1), each
  * with its own Bt, so torch.cat((a, c), -1) @ W^T never materialises the concatenation.
  * Epilogue, in this order, each part optional:
- *   v = acc + bias[n] + pos[(row % T)][n] + add[row][n] + rowscale[row] * colvec[n]
+ *   v = alpha * acc + bias[n] + pos[(row % T)][n] + add[row][n] + rowscale[row] * colvec[n]
  *   v *= gate_scale * (gate[row][n] > 0 ? 1 : gate_slope) (LeakyReLU' (x dropout1'), from the saved activation)
  *   v  = ids[row] != 0 ? v : 0                          (when mask_rows)
  *   C[row][n] = v for n < N;  C[row][n] = 0 for N <= n < ncols_out                              */
@@ -112,6 +112,7 @@ typedef struct CarcaGemmDesc {
   int32_t ld_add, ld_gate;
   float gate_slope;
   int32_t mask_rows;
+  float alpha;             /* v = alpha * acc + bias + ...; 0 means 1 */
   float gate_scale;        /* extra factor on the gate (1/(1-p) when the saved activation went through dropout); 0 = 1 */
   int32_t gate_zero_drops; /* 1: an exactly-zero saved activation was DROPPED -> gradient 0 (else LeakyReLU'(0) = slope) */
 } CarcaGemmDesc;
@@ -310,6 +311,14 @@ typedef struct CarcaForwardDesc {
   float* y[CARCA_MAX_GROUPS];   /* [B, N_g] outputs */
   int32_t N[CARCA_MAX_GROUPS];
   float* p_normed;              /* optional [B*L, ld_e] */
+  /* Optional FOLDED embedding (inference with frozen weights).  AllEmbedding has no nonlinearity (carca.py:86-89),
+   * so e = z W_jz^T + [a;c] (W_jq W_f)^T + (W_jq b_f + b_j): with fold_wc = W_jq W_f [d, F] (row stride
+   * fold_ldwc) and fold_bias [d] prepared once per weight version, the F->g->d pair of GEMMs becomes one F->d
+   * GEMM (5x fewer executed flops at g = 5d) and zq is not touched.  Same algebra, different fp32 summation
+   * order (~1e-6 relative); NULL = the two-GEMM path that mirrors the reference operation by operation. */
+  const float* fold_wc;
+  const float* fold_bias;
+  int32_t fold_ldwc;
 } CarcaForwardDesc;
 int carca_forward(const CarcaForwardDesc* desc /*host*/, void* const* ev /*4 hipEvent_t or NULL*/, void* stream);
 /* Event helpers so that a host language without a HIP binding can time kernels on the launch stream. */

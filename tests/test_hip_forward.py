@@ -272,3 +272,29 @@ def test_baseline_config_shapes(case):
     assert bool(((rank >= lo) & (rank <= hi)).all())
     clear = lo == hi  # users whose rank is unambiguous
     assert torch.equal(rank[clear], O.positive_rank(want)[clear])
+
+
+def test_folded_embedding_matches_oracle():
+    """CARCA.fold_embedding(True): composed W_jq W_f path (inference shortcut) stays within the output tolerance."""
+    cfg = O.CarcaConfig(d=90, H=3, n_blocks=2, encoding="learnable")
+    n_items, n_attrs, n_ctx, g, L, N, B = 400, 300, 6, 450, 50, 101, 12
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    profile, target, table = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=5)
+    want = O.carca_forward(P, cfg, profile, [target], training=False)
+    model = model_from_params(P, cfg).eval()
+    model.fold_embedding(True)
+    with torch.no_grad():
+        got = model(profile=dev(profile), targets=[dev(target)])
+        assert float((got.cpu() - want).abs().max()) < Y_ATOL
+        # weights change -> the composed matrix is rebuilt
+        model.embeds.feats_embed.weight.mul_(0.5)
+        got2 = model(profile=dev(profile), targets=[dev(target)])
+        P2 = dict(P)
+        P2["embeds.feats_embed.weight"] = P["embeds.feats_embed.weight"] * 0.5
+        want2 = O.carca_forward(P2, cfg, profile, [target], training=False)
+        assert float((got2.cpu() - want2).abs().max()) < Y_ATOL
+        # with the attribute table resident as well
+        model.embeds.register_attr_table(table.cuda())
+        got3 = model(profile=(profile[0].cuda(), None, profile[2].cuda()), targets=[(target[0].cuda(), None, target[2].cuda())])
+        assert float((got3.cpu() - want2).abs().max()) < Y_ATOL
+    model.fold_embedding(False)
