@@ -108,7 +108,7 @@ class PackDesc(C.Structure):
 class RowSeg(C.Structure):
     _fields_ = [("ids", _fp), ("attrs", _fp), ("ctx", _fp), ("e_out", _fp), ("rows", C.c_int32), ("T", C.c_int32),
                 ("add_pos", C.c_int32), ("attrs_bstride", C.c_int64), ("ctx_bstride", C.c_int64),
-                ("attrs_table", _fp)]
+                ("attrs_table", _fp), ("attrs_table_rows", C.c_int32)]
 
 
 class GemmSeg(C.Structure):

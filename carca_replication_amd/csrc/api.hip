@@ -175,7 +175,7 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
       CarcaGemmSeg& a = z.seg[s];
       a.a0 = D->items_w; a.a0_gather = 1; a.ids = sg.ids; a.c = sg.e_out; a.rows = sg.rows; a.T = sg.T;
       CarcaGemmSeg& b = f.seg[s];
-      b.a0 = sg.attrs_table ? sg.attrs_table : sg.attrs; b.a0_gather = sg.attrs_table ? 1 : 0;
+      b.a0 = sg.attrs_table ? sg.attrs_table : sg.attrs; b.a0_gather = sg.attrs_table ? max(1, sg.attrs_table_rows) : 0;
       b.a0_bstride = sg.attrs_table ? 0 : sg.attrs_bstride;
       b.a1 = sg.ctx; b.a1_bstride = sg.ctx_bstride;
       b.ids = sg.ids; b.c = sg.e_out; b.add = sg.e_out; b.rows = sg.rows; b.T = sg.T; b.add_pos = sg.add_pos;

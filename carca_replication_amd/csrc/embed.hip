@@ -64,7 +64,7 @@ extern "C" int carca_embed_fwd(const CarcaRowSeg* segs, int nseg, int n_attrs, i
     ga.row_start[s] = row_start;
     CarcaGemmSeg& f = fa.seg[s];
     f.a0 = sg.attrs_table ? sg.attrs_table : sg.attrs; f.a1 = sg.ctx;
-    f.a0_gather = sg.attrs_table ? 1 : 0; f.c = zq + (size_t)row_start * ldz + d; f.ids = sg.ids;
+    f.a0_gather = sg.attrs_table ? max(1, sg.attrs_table_rows) : 0; f.c = zq + (size_t)row_start * ldz + d; f.ids = sg.ids;
     f.rows = sg.rows; f.T = sg.T; f.add_pos = 0;
     f.a0_bstride = sg.attrs_table ? 0 : sg.attrs_bstride; f.a1_bstride = sg.ctx_bstride;
     CarcaGemmSeg& j = ja.seg[s];

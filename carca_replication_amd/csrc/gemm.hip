@@ -12,13 +12,14 @@
 //   to 36 floats so that the 16-byte fragment reads are bank-conflict free; the next K tile's global
 //   loads are in flight while the current one is multiplied.  144 registers per lane -> 3 blocks per
 //   CU, which is what C2's 755 blocks want (256 CUs x 3 = 768 slots: one resident round).
-//   Block ids that share an A row block are 8 apart (same XCD under round-robin placement) so the
-//   A tile is fetched from HBM once and re-read from that XCD's L2 by the other column blocks
-//   (a speed choice only, never correctness).
+//   Blocks that share an A row block are numbered so that they land on the same XCD under round-robin
+//   placement: the A tile is fetched from HBM once and re-read from that XCD's L2 by the other column
+//   blocks (a speed choice only, never correctness).
 // gemm_wgrad: block tile 96 (n) x 128 (k), 32 rows per step; both operands are read from their
 //   row-major LDS tiles TRANSPOSED (lane = n resp. k, one ds_read_b32 per MFMA operand), so neither
 //   dY nor X is ever transposed in memory.  Row splits combine through fp32 atomics.
 #include "carca_common.h"
+#include <type_traits>
 #include "../../include/carca_hip.h"
 
 namespace {
@@ -27,6 +28,7 @@ struct GemmDev {
   CarcaGemmDesc d;
   int rb_start[CARCA_MAX_SEGS + 1];
   int nrb, ncb;
+  unsigned long long* dbg;  // phase-stamp buffer of a diagnostic run (DBG instantiation only)
 };
 
 template <int BM, int BN, int BK, int PF = 1>
@@ -41,12 +43,13 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
   __shared__ __attribute__((aligned(16))) float Bs[BN * LS];
 
   const CarcaGemmDesc& D = args.d;
-  // ---- block id -> (row block, col block); same row block => same id mod 8 (same XCD) ----------
-  const int id = blockIdx.x;
-  const int per = 8 * args.ncb;
-  const int grp = id / per, j = id - grp * per;
-  const int cb = j >> 3, rb = grp * 8 + (j & 7);
-  if (rb >= args.nrb) return;
+  // ---- block id -> (row block, col block): ids that are equal mod 8 land on one XCD under round-robin placement;
+  // renumber them contiguously per XCD (bijective for any grid size, no phantom blocks: a padded grid can push real
+  // blocks into a second round when the grid is sized to the chip) so that the column blocks of a row block share an L2
+  const int id = blockIdx.x, total = args.nrb * args.ncb;
+  const int xcd = id & 7, q8 = total >> 3, r8 = total & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  const int rb = wg / args.ncb, cb = wg - rb * args.ncb;
   int s = 0;
 #pragma unroll
   for (int i = 1; i < CARCA_MAX_SEGS; ++i)
@@ -204,6 +207,272 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
           v *= gv > 0.f ? gs : ((gv < 0.f || !D.gate_zero_drops) ? D.gate_slope * gs : 0.f);
         }
         if (D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;  // e * mask (carca.py:94): exact zeros
+      }
+      sg.c[(size_t)row * D.ldc + n] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_rows_cu_kernel: the same product for the ONE launch that carries 97 % of the model's flops
+// (feats_embed at n_attrs = 4096: ~19k rows x 4102 x 450).  One 768-thread block per CU, tile 384 x 96:
+// 36 of the 9060 32x32 output tiles per CU (255 blocks on 256 CUs, one round) like the 128 x 96 kernel's
+// three co-resident blocks, but the B tile is staged once instead of three times (107 instead of
+// 149 bytes through L1 per MFMA).  With a single lock-stepped block nothing else covers a wave's
+// non-MFMA instructions, and the SIMD serves its three waves oldest-first (measured: barrier waits
+// 4200 / 2200 / 300 cycles per step for the 1st / 2nd / 3rd wave of a SIMD), so the step is scheduled
+// by hand: every LDS read, LDS write and global load sits in the shadow of one of the wave's own
+// MFMAs, fragments are double-buffered in registers one 8-k group ahead, LDS is double-buffered so
+// that there is ONE barrier per K step, global loads run two tiles ahead on a scalar base + constant
+// per-lane offsets (no address arithmetic in the loop), and all LDS addresses are immediates.
+template <int DBG>
+__global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
+  constexpr int BM = 384, BN = 96, BK = 32, NW = 12, NT = 768, LS = BK + 4, TN = 3, C4 = BK / 4;
+  constexpr int A_PER = BM * C4 / NT, B_PER = 1;  // 4 + 1 staged float4 per thread and tile
+  static_assert(BN * C4 == NT, "one B slot per thread");
+  constexpr int A_BUF = BM * LS, B_BUF = BN * LS;  // floats per LDS buffer
+  __shared__ __attribute__((aligned(16))) float As[2 * A_BUF];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * B_BUF];
+
+  const CarcaGemmDesc& D = args.d;
+  const int id = blockIdx.x, total = args.nrb * args.ncb;
+  const int xcd = id & 7, q8 = total >> 3, r8 = total & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  const int rb = wg / args.ncb, cb = wg - rb * args.ncb;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+    if (i < D.nseg && rb >= args.rb_start[i]) s = i;
+  const CarcaGemmSeg sg = D.seg[s];
+  const int row0 = (rb - args.rb_start[s]) * BM;
+  const int n0 = cb * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nfast = D.K0 / BK;  // full tiles of k-source 0: the pipelined loop
+  const int nt0 = (D.K0 + BK - 1) / BK, nt1 = (D.K1 + BK - 1) / BK;
+  const int ntiles = nt0 + nt1;
+
+  // ---- staging slots: element offsets are loop invariants; the fast loop adds them to a scalar base ----
+  size_t aoff0[A_PER], aoff1[A_PER];
+  unsigned a_byte[A_PER];  // byte offset of the slot's 16 bytes inside tile 0 of k-source 0 (host: < 4 GiB)
+  int a_lds[A_PER];        // float index inside an A buffer
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int slot = tid + i * NT, r = slot / C4, c4 = slot - r * C4;
+    const int gr = min(row0 + r, sg.rows - 1);
+    const int ub = gr / sg.T, ut = gr - ub * sg.T;
+    aoff0[i] = sg.a0_gather ? (size_t)sg.ids[gr] * D.lda0
+               : sg.a0_bstride ? (size_t)ub * sg.a0_bstride + (size_t)ut * D.lda0
+                               : (size_t)gr * D.lda0;
+    aoff1[i] = sg.a1_bstride ? (size_t)ub * sg.a1_bstride + (size_t)ut * D.lda1 : (size_t)gr * D.lda1;
+    a_byte[i] = (unsigned)((aoff0[i] + c4 * 4) * sizeof(float));
+    a_lds[i] = r * LS + c4 * 4;
+  }
+  const int b_r = tid / C4, b_c4 = tid - b_r * C4;
+  const int b_gn = min(n0 + b_r, D.N - 1);
+  const unsigned b_byte = (unsigned)(((size_t)b_gn * D.ldb0 + b_c4 * 4) * sizeof(float));
+  const int b_lds = b_r * LS + b_c4 * 4;
+
+  f32x4 ra[A_PER], rbv;
+  // Buffer loads: scalar resource + 32-bit per-lane offset + scalar tile offset -- no address arithmetic in the
+  // loop and half the address data of a 64-bit global_load per instruction.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sg.a0, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)D.bt0, 0, -1, 0x00020000);
+  int k_byte = 0;  // scalar: byte offset of the NEXT tile to load inside a row
+  auto load_fast = [&](int i) {  // slot i of that tile (i == A_PER: the B slot)
+    const u32x4 v = i < A_PER ? __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_byte[i < A_PER ? i : 0], k_byte, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_byte, k_byte, 0);
+    f32x4 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(v[e]);
+    if (i < A_PER)
+      ra[i < A_PER ? i : 0] = f;
+    else
+      rbv = f;
+  };
+  auto store_slot = [&](int i, int buf) {
+    if (i < A_PER)
+      *reinterpret_cast<f32x4*>(&As[buf * A_BUF + a_lds[i]]) = ra[i];
+    else
+      *reinterpret_cast<f32x4*>(&Bs[buf * B_BUF + b_lds]) = rbv;
+  };
+  auto load4 = [](const float* p, bool full, int kk, int klen) -> f32x4 {
+    if (full) return *reinterpret_cast<const f32x4_u*>(p);
+    f32x4 v;
+    v[0] = kk + 0 < klen ? p[0] : 0.f;
+    v[1] = kk + 1 < klen ? p[1] : 0.f;
+    v[2] = kk + 2 < klen ? p[2] : 0.f;
+    v[3] = kk + 3 < klen ? p[3] : 0.f;
+    return v;
+  };
+  auto load_tail = [&](int t) {  // any tile, either k-source, ragged K (the few tiles behind the fast loop)
+    const bool src1 = t >= nt0;
+    const int k0 = (src1 ? t - nt0 : t) * BK;
+    const int klen = src1 ? D.K1 : D.K0;
+    const float* abase = src1 ? sg.a1 : sg.a0;
+    const float* bbase = src1 ? D.bt1 : D.bt0;
+    const int ldb = src1 ? D.ldb1 : D.ldb0;
+    const bool full = k0 + BK <= klen;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int c4 = (tid + i * NT) % C4;
+      ra[i] = load4(abase + (src1 ? aoff1[i] : aoff0[i]) + k0 + c4 * 4, full, k0 + c4 * 4, klen);
+    }
+    rbv = load4(bbase + (size_t)b_gn * ldb + k0 + b_c4 * 4, full, k0 + b_c4 * 4, klen);
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  const float* a_frag = &As[(wave * 32 + lr) * LS + 4 * lh];
+  const float* b_frag = &Bs[lr * LS + 4 * lh];
+  f32x4 fa0, fa1, fb0[TN], fb1[TN];  // fragment sets of two consecutive 8-k groups
+
+#define CARCA_PIN() __builtin_amdgcn_sched_barrier(0)
+  // fragment read j of group kg from LDS buffer `buf` into set (fa, fb): j = 0 is A, 1..3 the B tiles
+  auto read_frag = [&](int j, int buf, int kg, f32x4& fa, f32x4(&fb)[TN]) {
+    if (j == 0)
+      fa = *reinterpret_cast<const f32x4*>(a_frag + buf * A_BUF + kg * 8);
+    else
+      fb[j - 1] = *reinterpret_cast<const f32x4*>(b_frag + buf * B_BUF + (j - 1) * 32 * LS + kg * 8);
+  };
+  // 12 MFMAs of one 8-k group; aux(i) is issued behind MFMA i (i = 0..11) and must be independent of it
+  auto mfma_group = [&](const f32x4& fa, const f32x4(&fb)[TN], auto&& aux) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      acc[i % 3] = mfma32(fa[i / 3], fb[i % 3][i / 3], acc[i % 3]);
+      CARCA_PIN();
+      aux(i);
+      CARCA_PIN();
+    }
+  };
+  unsigned long long w_vm = 0, w_bar = 0, t_begin = 0;
+
+  // one K step on tile t (LDS buffer CUR); tile t+1 is in registers, tile t+2 gets loaded
+  // one K step on tile t (LDS buffer CUR); tile t+1 is in registers, tile t+2 gets loaded.  Gaps 0..3 of every group
+  // carry the fragment reads of the next group; gaps 4..8 of group 1 the LDS writes of tile t+1 and gaps 4..8 of
+  // group 2 the loads of tile t+2 (behind the writes: the staging registers are reused).
+  auto step = [&](auto cur_tag, int t) {
+    constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
+    const bool has1 = t + 1 < nfast, has2 = t + 2 < nfast;
+    mfma_group(fa0, fb0, [&](int i) {
+      if (i < 4) read_frag(i, CUR, 1, fa1, fb1);
+    });
+    if constexpr (DBG) {
+      const unsigned long long ta = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      w_vm += __builtin_amdgcn_s_memtime() - ta;
+      CARCA_PIN();
+    }
+    mfma_group(fa1, fb1, [&](int i) {
+      if (i < 4)
+        read_frag(i, CUR, 2, fa0, fb0);
+      else if (i < 4 + A_PER + B_PER && has1)
+        store_slot(i - 4, NXT);
+    });
+    mfma_group(fa0, fb0, [&](int i) {
+      if (i < 4)
+        read_frag(i, CUR, 3, fa1, fb1);
+      else if (i < 4 + A_PER + B_PER && has2)
+        load_fast(i - 4);
+    });
+    if (has2) k_byte += BK * sizeof(float);
+    CARCA_PIN();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS writes of tile t+1 and reads of tile t retired
+    if constexpr (DBG) {
+      const unsigned long long tb = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      w_bar += __builtin_amdgcn_s_memtime() - tb;
+    } else {
+      __builtin_amdgcn_s_barrier();  // raw: the loads of tile t+2 stay in flight across it
+    }
+    CARCA_PIN();
+    mfma_group(fa1, fb1, [&](int i) {
+      if (i < 4 && has1) read_frag(i, NXT, 0, fa0, fb0);
+    });
+  };
+
+  if (nfast > 0) {
+    // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers
+#pragma unroll
+    for (int i = 0; i < A_PER + B_PER; ++i) load_fast(i);
+    k_byte += BK * sizeof(float);
+#pragma unroll
+    for (int i = 0; i < A_PER + B_PER; ++i) store_slot(i, 0);
+    if (nfast > 1) {
+#pragma unroll
+      for (int i = 0; i < A_PER + B_PER; ++i) load_fast(i);
+      k_byte += BK * sizeof(float);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) read_frag(j, 0, 0, fa0, fb0);
+    if constexpr (DBG) t_begin = __builtin_amdgcn_s_memtime();
+    int t = 0;
+    for (; t + 1 < nfast; t += 2) {
+      step(std::integral_constant<int, 0>{}, t);
+      step(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < nfast) step(std::integral_constant<int, 0>{}, t);
+    if constexpr (DBG) {
+      if (args.dbg && lane == 0) {
+        unsigned long long* o = args.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
+        o[0] = __builtin_amdgcn_s_memtime() - t_begin;
+        o[1] = w_vm;
+        o[2] = w_bar;
+        o[3] = 0;
+      }
+    }
+  }
+#undef CARCA_PIN
+  // ---- tail tiles (ragged end of k-source 0, all of k-source 1): plain load -> LDS -> multiply ----
+  for (int t = nfast; t < ntiles; ++t) {
+    load_tail(t);
+    __syncthreads();  // every wave is done with both LDS buffers
+#pragma unroll
+    for (int i = 0; i < A_PER + B_PER; ++i) store_slot(i, 0);
+    __syncthreads();
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(a_frag + kg * 8);
+      f32x4 b[TN];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(b_frag + tn * 32 * LS + kg * 8);
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tn] = mfma32(a[st], b[tn][st], acc[tn]);
+    }
+  }
+
+  // ---- epilogue (same as gemm_rows_kernel) ----------------------------------------------------------
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + tn * 32 + lr;
+    if (n >= D.ncols_out) continue;
+    const bool n_ok = n < D.N;
+    const float bias = (n_ok && D.bias) ? D.bias[n] : 0.f;
+    const float cv = (n_ok && D.colvec) ? D.colvec[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= sg.rows) continue;
+      float v = 0.f;
+      if (n_ok) {
+        v = (D.alpha != 0.f ? D.alpha * acc[tn][r] : acc[tn][r]) + bias;
+        if (sg.add_pos) v += D.pos[(size_t)(row % sg.T) * D.N + n];
+        if (sg.add) v += sg.add[(size_t)row * D.ld_add + n];
+        if (sg.rowscale) v += sg.rowscale[row] * cv;
+        if (sg.gate) {
+          const float gv = sg.gate[(size_t)row * D.ld_gate + n];
+          const float gs = D.gate_scale != 0.f ? D.gate_scale : 1.0f;
+          v *= gv > 0.f ? gs : ((gv < 0.f || !D.gate_zero_drops) ? D.gate_slope * gs : 0.f);
+        }
+        if (D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;
       }
       sg.c[(size_t)row * D.ldc + n] = v;
     }
@@ -377,8 +646,27 @@ static int launch_gemm_rows(const CarcaGemmDesc* desc, hipStream_t stream) {
   g.rb_start[desc->nseg] = rb;
   g.nrb = rb;
   g.ncb = (desc->ncols_out + BN - 1) / BN;
-  const int grid = ((rb + 7) / 8) * 8 * g.ncb;
+  const int grid = rb * g.ncb;
   hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, PF>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+template <int DBG>
+static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream) {
+  GemmDev g{};
+  g.d = *desc;
+  int rb = 0;
+  for (int s = 0; s < desc->nseg; ++s) {
+    if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
+    g.rb_start[s] = rb;
+    rb += (desc->seg[s].rows + 383) / 384;
+  }
+  g.rb_start[desc->nseg] = rb;
+  g.nrb = rb;
+  g.ncb = (desc->ncols_out + 95) / 96;
+  g.dbg = carca_debug_buffer();
+  hipLaunchKernelGGL((gemm_rows_cu_kernel<DBG>), dim3(rb * g.ncb), dim3(768), 0, stream, g);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -406,9 +694,28 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   // Narrow outputs (the joint embedding, every d-wide product of the backward pass) give too few 128 x 96 blocks
   // to fill 256 CUs and leave one long MFMA chain per wave: 32-column blocks triple the wave count instead
   // (the A tile is re-read from L2 by the three column blocks of a row block, which share an XCD).
-  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);  // 0 auto, 1 force 128x96, 2 force one-block-per-CU, 3 = 2 + stamps
   const bool narrow = variant != 1 && rb128 * ((desc->ncols_out + 95) / 96) < 384;
   if (narrow) return launch_gemm_rows<128, 32, 32, 4>(desc, stream);
+  // One 384 x 96 block per CU when (a) its 32-bit load offsets provably fit and (b) the grid fills the chip's 256 CUs
+  // about as well as the 128 x 96 blocks (3 per CU) would: compare rounds x tiles per block.
+  bool cu_ok = desc->K0 >= 64 && (uint64_t)(desc->N - 1) * desc->ldb0 + desc->K0 < (1ull << 30);
+  int rb384 = 0;
+  for (int s = 0; s < desc->nseg && cu_ok; ++s) {
+    const CarcaGemmSeg& sg = desc->seg[s];
+    const int T = sg.T >= 1 ? sg.T : 1;
+    const uint64_t last = sg.a0_gather ? (sg.a0_gather > 1 ? (uint64_t)(sg.a0_gather - 1) * desc->lda0 : ~0ull >> 8)
+                          : sg.a0_bstride ? (uint64_t)((sg.rows - 1) / T) * sg.a0_bstride + (uint64_t)(T - 1) * desc->lda0
+                                          : (uint64_t)(sg.rows - 1) * desc->lda0;
+    cu_ok = last + desc->K0 < (1ull << 30);  // elements: < 4 GiB of bytes
+    rb384 += (sg.rows + 383) / 384;
+  }
+  if (cu_ok && variant != 1) {
+    const int ncb = (desc->ncols_out + 95) / 96;
+    const long units_cu = (long)((rb384 * ncb + 255) / 256) * 36, units_3 = (long)((rb128 * ncb + 255) / 256) * 12;
+    if (variant == 3) return launch_gemm_rows_cu<1>(desc, stream);
+    if (variant == 2 || units_cu <= units_3) return launch_gemm_rows_cu<0>(desc, stream);
+  }
   return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
 }
 

@@ -606,6 +606,7 @@ class CARCA(_PackedModule, Model):
                 S.attrs, S.attrs_bstride, S.attrs_table = a.data_ptr(), a_bs, None
             else:
                 S.attrs, S.attrs_bstride, S.attrs_table = None, 0, table.data_ptr()
+                S.attrs_table_rows = table.shape[0]
             if n_ctx > 0:
                 c, c_bs = ops._btk_view(c)
                 S.ctx, S.ctx_bstride = c.data_ptr(), c_bs

@@ -256,6 +256,7 @@ def embed_fwd(segs: Sequence[Tuple[Tensor, Tensor, Tensor, bool]], items_w: Tens
             a.attrs = attrs.data_ptr()
         else:
             a.attrs_table = attrs_table.data_ptr()
+            a.attrs_table_rows = attrs_table.shape[0]
         a.rows, a.T, a.add_pos = B * T, T, int(bool(add_pos))
         a.attrs_bstride, a.ctx_bstride = a_bs, c_bs
         total += B * T

@@ -94,8 +94,9 @@ typedef struct CarcaGemmSeg {
   /* Rows of a0 / a1 may belong to a [B, T, K] VIEW whose users are a0_bstride / a1_bstride elements apart
    * (e.g. o_a[:, :L] of train.py:86-88): row r then starts at (r / T) * bstride + (r % T) * lda.  0 = dense. */
   int64_t a0_bstride, a1_bstride;
-  /* 1: a0 is a TABLE [n_items, lda0] and row r reads a0[ids[r]] (attribute rows gathered by item id inside the
-   * GEMM's operand load -- no dense [B, T, n_attrs] tensor exists; data.py:119-132 always sets p_a = attrs[p_x]) */
+  /* >= 1: a0 is a TABLE [n_items, lda0] and row r reads a0[ids[r]] (attribute rows gathered by item id inside the
+   * GEMM's operand load -- no dense [B, T, n_attrs] tensor exists; data.py:119-132 always sets p_a = attrs[p_x]).
+   * A value > 1 also states the table's row count, which lets the launcher pick the 32-bit-offset load path. */
   int32_t a0_gather;
 } CarcaGemmSeg;
 typedef struct CarcaGemmDesc {
@@ -164,6 +165,7 @@ typedef struct CarcaRowSeg {
   int32_t add_pos;    /* 1: add pos[row % T] (profile side, carca.py:91-92) */
   int64_t attrs_bstride, ctx_bstride; /* elements between users when attrs/ctx are [B, T, .] views; 0 = dense */
   const float* attrs_table; /* optional [n_items, n_attrs]: when set, `attrs` is ignored and row r uses attrs_table[ids[r]] */
+  int32_t attrs_table_rows; /* n_items of attrs_table when known, else 0 (only a speed hint: see CarcaGemmSeg.a0_gather) */
 } CarcaRowSeg;
 int carca_embed_fwd(const CarcaRowSeg* segs /*host*/, int nseg, int n_attrs, int n_ctx, int d, int g,
                     const float* items_w /*[n_items,d]*/, const float* feats_w /*[g,n_attrs+n_ctx]*/,

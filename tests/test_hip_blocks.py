@@ -39,6 +39,41 @@ def test_gemm_rows_plain(rows, N, K0, K1):
     assert float(got[:, N:].abs().max()) == 0.0  # pad columns are written as zeros
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["auto", "tile128x96", "one-block-per-cu"])
+def gemm_variant(request):
+    """Every carca_gemm_rows test runs under each kernel choice (tuning key 0); the forced ones take effect where the
+    launcher's preconditions hold and otherwise fall through to the default, so all shapes stay valid."""
+    from carca_replication_amd import _lib
+
+    lib = _lib.load()
+    lib.carca_set_tuning(0, request.param)
+    yield request.param
+    lib.carca_set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("rows,T,N,K0,K1", [((500, 777), 7, 200, 300, 6), ((384, 1), 1, 96, 64, 0),
+                                            ((1000,), 50, 450, 4096, 6), ((40,), 1, 130, 65, 3)])
+def test_gemm_rows_kernel_choices(gemm_variant, rows, T, N, K0, K1):
+    """Ragged row blocks, a ragged K tail, a second k-source and unaligned strided rows under each kernel."""
+    from carca_replication_amd import _lib, ops
+
+    bt, bias = _rand(N, K0 + K1, seed=3), _rand(N, seed=4)
+    btc = bt.cuda()
+    segs, wants = [], []
+    for i, r in enumerate(rows):
+        big = _rand(r, K0 + 5, seed=10 + i)  # rows are a column slice of a wider matrix: lda0 > K0, 4-byte aligned only
+        a0 = big[:, 1:1 + K0]
+        a1 = _rand(r, max(K1, 1), seed=20 + i)
+        want = a0.double() @ bt[:, :K0].double().T + bias.double()
+        if K1:
+            want = want + a1.double() @ bt[:, K0:].double().T
+        wants.append(want)
+        segs.append(dict(a0=big.cuda()[:, 1:1 + K0], a1=a1.cuda() if K1 else None, T=T))
+    outs = ops.gemm_rows(segs, btc[:, :K0], N, K0, N, bt1=btc[:, K0:] if K1 else None, K1=K1, bias=bias.cuda())
+    for got, want in zip(outs, wants):
+        _close(got, want)
+
+
 def test_gemm_rows_epilogue_and_segments():
     from carca_replication_amd import ops
 
