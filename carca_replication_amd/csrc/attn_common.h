@@ -84,12 +84,12 @@ __device__ __forceinline__ void proj_tile_feat_major(const float* __restrict__ W
                                                      int lane, float* __restrict__ save = nullptr, int dpo = 0,
                                                      int L = 0) {
   const int ln = lane & 15, mq = lane >> 4;
-  const float* wrow = Wp + (size_t)(16 * ft + ln) * DPI + 4 * mq;
+  const int woff = (16 * ft + ln) * DPI + 4 * mq;
   const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
   f32x4 wf[DPI / 16];  // all weight fragments first: their latencies overlap instead of chaining
 #pragma unroll
-  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = glb4(wrow + 16 * kg);
-  const f32x4 bias = glb4(bp + 16 * ft + 4 * mq);
+  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = gload4(Wp, woff + 16 * kg);
+  const f32x4 bias = gload4(bp, 16 * ft + 4 * mq);
   f32x4 acc = zero4();
 #pragma unroll
   for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(wf[kg], lds4(xrow + 16 * kg), acc);
@@ -107,12 +107,12 @@ __device__ __forceinline__ void proj_tile_slot_major(const float* __restrict__ W
                                                      int lane, float* __restrict__ save = nullptr, int dpo = 0,
                                                      int L = 0) {
   const int ln = lane & 15, mq = lane >> 4;
-  const float* wrow = Wp + (size_t)(16 * ft + ln) * DPI + 4 * mq;
+  const int woff = (16 * ft + ln) * DPI + 4 * mq;
   const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
   f32x4 wf[DPI / 16];
 #pragma unroll
-  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = glb4(wrow + 16 * kg);
-  const float bias = bp[16 * ft + ln];
+  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = gload4(Wp, woff + 16 * kg);
+  const float bias = gload1(bp, 16 * ft + ln);
   f32x4 acc = zero4();
 #pragma unroll
   for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(lds4(xrow + 16 * kg), wf[kg], acc);
@@ -146,11 +146,11 @@ __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], cons
   f32x4 qt[G::NFH];
 #pragma unroll
   for (int ft = 0; ft < G::NFH; ++ft) {
-    const float* wrow = wq + (size_t)(h * DHP + 16 * ft + ln) * DPI + 4 * mq;
+    const int woff = (h * DHP + 16 * ft + ln) * DPI + 4 * mq;
     f32x4 wf[G::NKG];
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = glb4(wrow + 16 * kg);
-    const f32x4 bias = glb4(bq + h * DHP + 16 * ft + 4 * mq);
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(wq, woff + 16 * kg);
+    const f32x4 bias = gload4(bq, h * DHP + 16 * ft + 4 * mq);
     f32x4 acc = zero4();
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], qfrag[kg], acc);

@@ -20,6 +20,23 @@ typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 #define CARCA_WAVE 64
 
+// Global loads go through BUFFER instructions: wave-uniform base (scalar resource) + 32-bit per-lane element offset.
+// Measured on the feature GEMM (tools/stamp_gemm.py): a global_load_dwordx4 with 64-bit per-lane addresses costs the
+// SIMD ~130 cycles of MFMA issue per instruction, the same load as buffer_load_dwordx4 ~7.  `base` MUST be uniform
+// over the wave (kernel argument, or derived from blockIdx / a readfirstlane'd wave index); offsets are elements.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t carca_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ f32x4 gload4(const float* base, int elem_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(carca_rsrc(base), elem_off * 4, 0, 0);
+  f32x4 f = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+  return f;
+}
+__device__ __forceinline__ float gload1(const float* base, int elem_off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(carca_rsrc(base), elem_off * 4, 0, 0));
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
   float* Yp = Vt + G::DPO * ATT_SK;    // [CROSS_TPR][NH][16] partial logits
 
   const int u = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it (jobs, tiles, heads) is uniform
   const int LT = (L + 15) >> 4;
   const int32_t* uid = p_ids + (size_t)u * L;
   const unsigned long long pmask = __ballot(lane < L && uid[lane < L ? lane : 0] != 0);
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
     if (r < L) {
       const float* xr = p_raw + (ubase + r) * ldp + 4 * c4;
       if (vec_ok) {
-        v = glb4(xr);
+        v = gload4(p_raw, (int)((ubase + r) * ldp) + 4 * c4);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 4 * c4 + e < d ? xr[e] : 0.f;
@@ -116,10 +117,9 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
       const int n = 16 * qt + ln;
       const bool in_range = n < grp.N;
       const size_t row = (size_t)u * grp.N + (in_range ? n : grp.N - 1);
-      const float* orow = grp.o + row * ldo + 4 * mq;
       f32x4 qfrag[G::NKG];
 #pragma unroll
-      for (int kg = 0; kg < G::NKG; ++kg) qfrag[kg] = glb4(orow + 16 * kg);
+      for (int kg = 0; kg < G::NKG; ++kg) qfrag[kg] = gload4(grp.o, (int)(row * ldo) + 4 * mq + 16 * kg);
       const bool q_ok = in_range && grp.ids[row] != 0;
       unsigned okbits = 0;
 #pragma unroll
@@ -139,14 +139,14 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
       float ypart = 0.f;
 #pragma unroll
       for (int ft = 0; ft < G::NFH; ++ft) {
-        const f32x4 wp = glb4(w.ffn_w_pad + h * DHP + 16 * ft + 4 * mq);
+        const f32x4 wp = gload4(w.ffn_w_pad, h * DHP + 16 * ft + 4 * mq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) ypart += wp[r] * oh[ft][r];
       }
       if (residual && h == 0) {  // w . o, once per target
 #pragma unroll
         for (int kg = 0; kg < G::NKG; ++kg) {
-          const f32x4 wv = glb4(w.ffn_w + 16 * kg + 4 * mq);
+          const f32x4 wv = gload4(w.ffn_w, 16 * kg + 4 * mq);
 #pragma unroll
           for (int r = 0; r < 4; ++r) ypart += wv[r] * qfrag[kg][r];
         }

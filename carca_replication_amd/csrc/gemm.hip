@@ -31,7 +31,7 @@ struct GemmDev {
   unsigned long long* dbg;  // phase-stamp buffer of a diagnostic run (DBG instantiation only)
 };
 
-template <int BM, int BN, int BK, int PF = 1>
+template <int BM, int BN, int BK, int PF = 1, bool BUF = false>
 __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev args) {
   constexpr int NW = BM / 32, NT = NW * 64, LS = BK + 4, TN = BN / 32;
   constexpr int C4 = BK / 4;  // float4 slots per tile row
@@ -85,6 +85,8 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
     v[3] = kk + 3 < klen ? p[3] : 0.f;
     return v;
   };
+  // BUF: full tiles are fetched with buffer loads (scalar resource + 32-bit lane offset + scalar k offset; see
+  // gload4 in carca_common.h for why) -- the launcher sets it when every offset provably fits 32 bits
   auto load_tile = [&](int t, f32x4 (&ra_)[A_PER], f32x4 (&rb_)[B_PER]) {
     const bool src1 = t >= nt0;
     const int k0 = (src1 ? t - nt0 : t) * BK;
@@ -93,6 +95,27 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
     const float* bbase = src1 ? D.bt1 : D.bt0;
     const int ldb = src1 ? D.ldb1 : D.ldb0;
     const bool full = k0 + BK <= klen;  // block-uniform
+    if (BUF && full) {
+      const __amdgpu_buffer_rsrc_t ar = carca_rsrc(abase), br = carca_rsrc(bbase);
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+        const int slot = tid + i * NT;
+        if (A_SLOTS % NT != 0 && slot >= A_SLOTS) break;
+        const unsigned off = (unsigned)(((src1 ? aoff1[i] : aoff0[i]) + (slot % C4) * 4) * sizeof(float));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ar, off, k0 * (int)sizeof(float), 0);
+        ra_[i] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+      }
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int slot = tid + i * NT;
+        if (B_SLOTS % NT != 0 && slot >= B_SLOTS) break;
+        const int r = slot / C4, c4 = slot - r * C4;
+        const unsigned off = (unsigned)(((size_t)min(n0 + r, D.N - 1) * ldb + c4 * 4) * sizeof(float));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(br, off, k0 * (int)sizeof(float), 0);
+        rb_[i] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int slot = tid + i * NT;
@@ -486,7 +509,7 @@ struct WgradDev {
   int nnb, nkb, nkb0, nsplit, chunks_per_split;
 };
 
-template <int BNO, int BKO, int BR>
+template <int BNO, int BKO, int BR, bool BUF = false>
 __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
   static_assert(BNO == 96 && BKO == 128 && BR == 32, "tile shape baked into the lane maps below");
   constexpr int NT = 256;
@@ -530,7 +553,10 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
       if (ok) {
         const float* p = sg.dy + (size_t)row * D.ld_dy + n0 + c4 * 4;
         if (n_full) {
-          v = *reinterpret_cast<const f32x4_u*>(p);
+          if constexpr (BUF)
+            v = gload4(sg.dy, row * D.ld_dy + n0 + c4 * 4);
+          else
+            v = *reinterpret_cast<const f32x4_u*>(p);
         } else {
           const int nn = n0 + c4 * 4;
           v[0] = nn + 0 < D.N ? p[0] : 0.f;
@@ -554,7 +580,10 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
                                                     : (size_t)row * ldx;
         const float* p = (src1 ? sg.x1 : sg.x) + roff + k0 + c4 * 4;
         if (k_full) {
-          v = *reinterpret_cast<const f32x4_u*>(p);
+          if constexpr (BUF)
+            v = gload4(src1 ? sg.x1 : sg.x, (int)roff + k0 + c4 * 4);
+          else
+            v = *reinterpret_cast<const f32x4_u*>(p);
         } else {
           const int kk = k0 + c4 * 4;
           v[0] = kk + 0 < klen ? p[0] : 0.f;
@@ -633,7 +662,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
 
 }  // namespace
 
-template <int BM, int BN, int BK, int PF>
+template <int BM, int BN, int BK, int PF, bool BUF = false>
 static int launch_gemm_rows(const CarcaGemmDesc* desc, hipStream_t stream) {
   GemmDev g{};
   g.d = *desc;
@@ -647,7 +676,7 @@ static int launch_gemm_rows(const CarcaGemmDesc* desc, hipStream_t stream) {
   g.nrb = rb;
   g.ncb = (desc->ncols_out + BN - 1) / BN;
   const int grid = rb * g.ncb;
-  hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, PF>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
+  hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, PF, BUF>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -694,28 +723,37 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   // Narrow outputs (the joint embedding, every d-wide product of the backward pass) give too few 128 x 96 blocks
   // to fill 256 CUs and leave one long MFMA chain per wave: 32-column blocks triple the wave count instead
   // (the A tile is re-read from L2 by the three column blocks of a row block, which share an XCD).
-  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);  // 0 auto, 1 force 128x96, 2 force one-block-per-CU, 3 = 2 + stamps
-  const bool narrow = variant != 1 && rb128 * ((desc->ncols_out + 95) / 96) < 384;
-  if (narrow) return launch_gemm_rows<128, 32, 32, 4>(desc, stream);
-  // One 384 x 96 block per CU when (a) its 32-bit load offsets provably fit and (b) the grid fills the chip's 256 CUs
-  // about as well as the 128 x 96 blocks (3 per CU) would: compare rounds x tiles per block.
-  bool cu_ok = desc->K0 >= 64 && (uint64_t)(desc->N - 1) * desc->ldb0 + desc->K0 < (1ull << 30);
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);  // 0 auto, 1 force 128x96, 2 force one-block-per-CU, 3 = 2 + stamps, 4 = no buffer loads
+  // do all operand offsets fit 32 bits of bytes?  (buffer loads; the gather table's size is only known when stated)
+  const uint64_t lim = 1ull << 30;  // elements
+  bool fits = (uint64_t)(desc->N - 1) * desc->ldb0 + desc->K0 < lim &&
+              (desc->K1 == 0 || (uint64_t)(desc->N - 1) * desc->ldb1 + desc->K1 < lim);
   int rb384 = 0;
-  for (int s = 0; s < desc->nseg && cu_ok; ++s) {
+  for (int s = 0; s < desc->nseg && fits; ++s) {
     const CarcaGemmSeg& sg = desc->seg[s];
     const int T = sg.T >= 1 ? sg.T : 1;
-    const uint64_t last = sg.a0_gather ? (sg.a0_gather > 1 ? (uint64_t)(sg.a0_gather - 1) * desc->lda0 : ~0ull >> 8)
-                          : sg.a0_bstride ? (uint64_t)((sg.rows - 1) / T) * sg.a0_bstride + (uint64_t)(T - 1) * desc->lda0
-                                          : (uint64_t)(sg.rows - 1) * desc->lda0;
-    cu_ok = last + desc->K0 < (1ull << 30);  // elements: < 4 GiB of bytes
+    const uint64_t ub = (uint64_t)((sg.rows - 1) / T), ut = (uint64_t)(T - 1);
+    const uint64_t last0 = sg.a0_gather ? (sg.a0_gather > 1 ? (uint64_t)(sg.a0_gather - 1) * desc->lda0 : lim)
+                           : sg.a0_bstride ? ub * sg.a0_bstride + ut * desc->lda0
+                                           : (uint64_t)(sg.rows - 1) * desc->lda0;
+    const uint64_t last1 = desc->K1 == 0 ? 0
+                           : sg.a1_bstride ? ub * sg.a1_bstride + ut * desc->lda1
+                                           : (uint64_t)(sg.rows - 1) * desc->lda1;
+    fits = last0 + desc->K0 < lim && last1 + desc->K1 < lim;
     rb384 += (sg.rows + 383) / 384;
   }
-  if (cu_ok && variant != 1) {
+  if (variant == 4) fits = false;
+  const bool narrow = variant != 1 && rb128 * ((desc->ncols_out + 95) / 96) < 384;
+  if (narrow) return fits ? launch_gemm_rows<128, 32, 32, 4, true>(desc, stream) : launch_gemm_rows<128, 32, 32, 4>(desc, stream);
+  // One 384 x 96 block per CU when the grid fills the chip's 256 CUs about as well as the 128 x 96 blocks (3 per CU)
+  // would: compare rounds x tiles per block.
+  if (fits && desc->K0 >= 64 && variant != 1) {
     const int ncb = (desc->ncols_out + 95) / 96;
     const long units_cu = (long)((rb384 * ncb + 255) / 256) * 36, units_3 = (long)((rb128 * ncb + 255) / 256) * 12;
     if (variant == 3) return launch_gemm_rows_cu<1>(desc, stream);
     if (variant == 2 || units_cu <= units_3) return launch_gemm_rows_cu<0>(desc, stream);
   }
+  if (fits) return launch_gemm_rows<128, 96, 32, 1, true>(desc, stream);
   return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
 }
 
@@ -751,7 +789,25 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   nsplit = max(1, min(nsplit, (chunks + 3) / 4));
   g.chunks_per_split = (chunks + nsplit - 1) / nsplit;
   g.nsplit = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;
-  hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR>), dim3(tiles * g.nsplit), dim3(256), 0, stream, g);
+  // buffer loads when every operand offset provably fits 32 bits of bytes (a gather table's size must be stated)
+  const uint64_t lim = 1ull << 30;
+  bool fits = carca_tuning(CARCA_TUNE_GEMM_VARIANT) != 4;
+  for (int s = 0; s < desc->nseg && fits; ++s) {
+    const CarcaWgradSeg& sg = desc->seg[s];
+    const int T = sg.T >= 1 ? sg.T : 1;
+    const uint64_t ub = (uint64_t)((sg.rows - 1) / T), ut = (uint64_t)(T - 1);
+    const uint64_t lx = sg.x_gather ? (sg.x_gather > 1 ? (uint64_t)(sg.x_gather - 1) * desc->ld_x : lim)
+                        : sg.x_bstride ? ub * sg.x_bstride + ut * desc->ld_x
+                                       : (uint64_t)(sg.rows - 1) * desc->ld_x;
+    const uint64_t lx1 = desc->K1 == 0 ? 0
+                         : sg.x1_bstride ? ub * sg.x1_bstride + ut * desc->ld_x1
+                                         : (uint64_t)(sg.rows - 1) * desc->ld_x1;
+    fits = lx + desc->K < lim && lx1 + desc->K1 < lim && (uint64_t)sg.rows * desc->ld_dy < lim;
+  }
+  if (fits)
+    hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR, true>), dim3(tiles * g.nsplit), dim3(256), 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR>), dim3(tiles * g.nsplit), dim3(256), 0, stream, g);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   float* Vt = Ks + ATT_LMAX * G::SO;  // [DPO][ATT_SK]
 
   const int u = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it (jobs, tiles, heads) is uniform
   const int LT = (L + 15) >> 4;
   const int32_t* uid = ids + (size_t)u * L;
   const unsigned long long pmask = __ballot(lane < L && uid[lane < L ? lane : 0] != 0);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
     if (r < L) {
       const float* xr = x + (ubase + r) * ldx + 4 * c4;
       if (vec_ok) {
-        v = glb4(xr);
+        v = gload4(x, (int)((ubase + r) * ldx) + 4 * c4);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 4 * c4 + e < d ? xr[e] : 0.f;
@@ -158,12 +159,12 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   for (int job = wave; job < LT * G::NKG; job += NW) {
     const int qt = job / G::NKG, ft = job - qt * G::NKG;
     const int q = 16 * qt + ln;
-    const float* wrow = w.w1 + (size_t)(16 * ft + ln) * DPI + 4 * mq;
+    const int woff = (16 * ft + ln) * DPI + 4 * mq;
     const float* srow = Xs + q * G::SI + 4 * mq;
     f32x4 wf[G::NKG];
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = glb4(wrow + 16 * kg);
-    const f32x4 bias = glb4(w.b1 + 16 * ft + 4 * mq);
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(w.w1, woff + 16 * kg);
+    const f32x4 bias = gload4(w.b1, 16 * ft + 4 * mq);
     f32x4 acc = zero4();
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], lds4(srow + 16 * kg), acc);
@@ -188,12 +189,12 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   for (int job = wave; job < LT * G::NKG; job += NW) {
     const int qt = job / G::NKG, ft = job - qt * G::NKG;
     const int q = 16 * qt + ln;
-    const float* wrow = w.w2 + (size_t)(16 * ft + ln) * DPI + 4 * mq;
+    const int woff = (16 * ft + ln) * DPI + 4 * mq;
     const float* hrow = H1 + q * G::SI + 4 * mq;
     f32x4 wf[G::NKG];
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = glb4(wrow + 16 * kg);
-    const f32x4 bias = glb4(w.b2 + 16 * ft + 4 * mq);
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(w.w2, woff + 16 * kg);
+    const f32x4 bias = gload4(w.b2, 16 * ft + 4 * mq);
     f32x4 acc = zero4();
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], lds4(hrow + 16 * kg), acc);

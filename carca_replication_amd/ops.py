@@ -537,7 +537,7 @@ def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, ma
             raise CarcaHipError("gemm_wgrad: all segments must share row strides")
         S = D.seg[i]
         S.dy, S.x, S.rows, S.T, S.x_bstride = dy.data_ptr(), xp, dy.shape[0], xT, xbs
-        S.x_gather = int(bool(sg.get("x_gather", False)))
+        S.x_gather = max(1, int(sg["x"].shape[0])) if sg.get("x_gather", False) else 0
         if K1:
             x1p, lx1, x1rows, x1T, x1bs = xinfo(sg["x1"], "x1")
             if x1rows != dy.shape[0] or (xbs and x1bs and x1T != xT):

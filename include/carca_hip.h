@@ -132,7 +132,7 @@ typedef struct CarcaWgradSeg {
   int32_t rows;
   int32_t T;                     /* rows per user, used with the strides below */
   int64_t x_bstride, x1_bstride; /* users of a [B, T, K] view are this many elements apart; 0 = dense */
-  int32_t x_gather;              /* 1: x is a table [n_items, ld_x], row r reads x[ids[r]] */
+  int32_t x_gather;              /* >= 1: x is a table [n_items, ld_x], row r reads x[ids[r]]; > 1 also states n_items */
 } CarcaWgradSeg;
 typedef struct CarcaWgradDesc {
   CarcaWgradSeg seg[CARCA_MAX_SEGS];
