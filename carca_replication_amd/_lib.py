@@ -18,7 +18,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libcarca_hip.so")
 _STAMP = LIB_PATH + ".srchash"
-SOURCES = ["api.hip", "gemm.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip"]
+SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip"]
 HEADERS = ["carca_common.h", "attn_common.h"]
 
 MAX_SEGS = 4

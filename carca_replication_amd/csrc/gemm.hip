@@ -757,12 +757,27 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
 }
 
+int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream);  // wgrad_cu.hip
+
 extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(desc && desc->nseg >= 1 && desc->nseg <= CARCA_MAX_SEGS, "gemm_wgrad: bad segment count");
   CARCA_CHECK_ARG(desc->dw && desc->N >= 1 && desc->K >= 1 && desc->K1 >= 0 && desc->ldw >= desc->K + desc->K1 &&
                       desc->ld_dy >= desc->N && desc->ld_x >= desc->K && (desc->K1 == 0 || desc->ld_x1 >= desc->K1),
                   "gemm_wgrad: bad geometry");
+  for (int s = 0; s < desc->nseg; ++s) {
+    const CarcaWgradSeg& sg = desc->seg[s];
+    CARCA_CHECK_ARG(sg.rows >= 1 && sg.dy && sg.x && !(desc->mask_rows && !sg.ids) && (desc->K1 == 0 || sg.x1),
+                    "gemm_wgrad: segment %d malformed", s);
+    CARCA_CHECK_ARG(sg.T >= 1 || (!sg.x_bstride && !sg.x1_bstride), "gemm_wgrad: segment %d needs T >= 1", s);
+    CARCA_CHECK_ARG(!(sg.x_gather && !sg.ids), "gemm_wgrad: segment %d gathers without ids", s);
+  }
+  // the big product (dW of feats_embed) goes to the persistent one-block-per-CU kernel; tuning variant 4 / 5 = never
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
+  if (variant != 4 && variant != 5) {
+    const int r = carca_wgrad_cu_try(desc, stream);
+    if (r != 1) return r;
+  }
   constexpr int BNO = 96, BKO = 128, BR = 32;
   WgradDev g{};
   g.d = *desc;

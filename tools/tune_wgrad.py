@@ -1,5 +1,5 @@
-"""Time the feats_embed weight-gradient GEMM (dW_f = dq^T [attrs|ctx], as large as the forward GEMM) at C2
-train shapes for several row-split targets (tuning key 2)."""
+"""A/B the feats_embed weight-gradient GEMM (dW_f = dq^T [attrs|ctx], as large as the forward GEMM) at C2 train
+shapes: tuning key 0 = 0 (persistent one-block-per-CU kernel) vs 5 (tiled kernel with row splits), interleaved."""
 import os
 import sys
 
@@ -15,24 +15,30 @@ attrs = torch.rand(R // 50, 50, n_attrs, device="cuda")
 ctx = torch.rand(R // 50, 50, n_ctx, device="cuda")
 lib = _lib.load()
 flops = 2.0 * R * (n_attrs + n_ctx) * g
-slots = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["512", "768", "1024"])]
-res = {s: [] for s in slots}
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "5"])]
+res = {v: [] for v in variants}
+want = (dzq[:, d:].double().T @ torch.cat([attrs.reshape(R, -1), ctx.reshape(R, -1)], 1).double())
+want_b = dzq[:, d:].double().sum(0)
 for rnd in range(4):
-    for sl in slots:
-        lib.carca_set_tuning(2, sl)
-        dw = torch.zeros(g, n_attrs + n_ctx, device="cuda")
-        db = torch.zeros(g, device="cuda")
+    for v in variants:
+        lib.carca_set_tuning(0, v)
         evs = []
         for it in range(5):
+            dw = torch.zeros(g, n_attrs + n_ctx, device="cuda")
+            db = torch.zeros(g, device="cuda")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             ops.gemm_wgrad([dict(dy=dzq[:, d:], x=attrs, x1=ctx)], g, n_attrs, dw, db, K1=n_ctx)
             e1.record()
             evs.append((e0, e1))
         torch.cuda.synchronize()
+        err = float((dw.double() - want).abs().max() / want.abs().max())
+        errb = float((db.double() - want_b).abs().max() / want_b.abs().max())
+        assert err < 2e-5 and errb < 2e-5, (v, err, errb)
         if rnd:
-            res[sl] += [a.elapsed_time(b) for a, b in evs]
-for sl in slots:
-    t = sorted(res[sl])
+            res[v] += [a.elapsed_time(b) for a, b in evs]
+lib.carca_set_tuning(0, 0)
+for v in variants:
+    t = sorted(res[v])
     med = t[len(t) // 2]
-    print(f"slots {sl}: median {med*1e3:.1f} us ({flops/med/1e9:.1f} TF, {flops/med/1e9/157.3*100:.1f}%)  min {t[0]*1e3:.1f} us")
+    print(f"variant {v}: median {med*1e3:.1f} us ({flops/med/1e9:.1f} TF, {flops/med/1e9/157.3*100:.1f}%)  min {t[0]*1e3:.1f} us")
