@@ -369,7 +369,8 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
     g_num_cus = prop.multiProcessorCount;
   }
   // worth it only when every CU gets a long run of chunks (pipeline fill + two flushes per block are overhead)
-  if (total < (long)g_num_cus * 48 || chunks < 8) return 1;
+  const bool forced = carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 2 || carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 3;
+  if (!forced && (total < (long)g_num_cus * 48 || chunks < 8)) return 1;
   g.per = (int)((total + g_num_cus - 1) / g_num_cus);
   const int grid = (int)((total + g.per - 1) / g.per);
   g.V = chunks * WG_BR;

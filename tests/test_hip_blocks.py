@@ -119,3 +119,50 @@ def test_gemm_wgrad(rows, N, K):
     _close(dw[:, :K], want_w, tol=5e-5)
     _close(db, want_b, tol=5e-5)
     assert float(dw[:, K:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,T,N,K,K1,how", [
+    ((700, 333), 7, 130, 700, 6, "dense"),      # ragged last chunks, ragged n / k blocks, ctx columns in the pad columns
+    ((640,), 10, 96, 380, 3, "view"),           # K - k0 > 352: the ctx columns get a k block of their own
+    ((512, 96), 1, 200, 384, 0, "gather"),      # attribute rows gathered from a table by item id, no second source
+    ((950,), 50, 450, 1030, 8, "view"),
+])
+def test_gemm_wgrad_kernel_choices(gemm_variant, rows, T, N, K, K1, how):
+    """The persistent one-block-per-CU kernel (forced by variant 2 whatever the size) against the tiled one and fp64:
+    masked rows, [B, T, K] views, table gathers, both k-sources, bias gradient."""
+    from carca_replication_amd import ops
+
+    want_w = torch.zeros(N, K + K1, dtype=torch.float64)
+    want_b = torch.zeros(N, dtype=torch.float64)
+    table = _rand(57, K, seed=5)
+    segs = []
+    for i, r in enumerate(rows):
+        r = (r // T) * T
+        dy = _rand(r, N + 2, seed=60 + i)
+        ids = torch.randint(0, 57, (r,), generator=torch.Generator().manual_seed(80 + i)).int()
+        ids[::5] = 0
+        m = (ids != 0).double()[:, None]
+        x1 = _rand(r, max(K1, 1), seed=90 + i)
+        sg = dict(dy=dy.cuda()[:, :N], ids=ids.cuda())
+        if how == "gather":
+            x = table[ids.long()]
+            sg.update(x=table.cuda(), x_gather=True)
+        elif how == "view":
+            big = _rand(r // T, T + 2, K, seed=70 + i)
+            x = big[:, 1:1 + T].reshape(r, K)
+            sg.update(x=big.cuda()[:, 1:1 + T])
+        else:
+            x = _rand(r, K + 2, seed=70 + i)[:, :K]
+            sg.update(x=_rand(r, K + 2, seed=70 + i).cuda()[:, :K])
+        if K1:
+            sg.update(x1=x1.cuda())
+            want_w[:, K:] += (dy[:, :N].double() * m).T @ x1.double()
+        want_w[:, :K] += (dy[:, :N].double() * m).T @ x.double()
+        want_b += (dy[:, :N].double() * m).sum(0)
+        segs.append(sg)
+    dw = torch.zeros(N, K + K1 + 3, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    ops.gemm_wgrad(segs, N, K, dw, db, K1=K1, mask_rows=True)
+    _close(dw[:, :K + K1], want_w, tol=5e-5)
+    _close(db, want_b, tol=5e-5)
+    assert float(dw[:, K + K1:].abs().max()) == 0.0
