@@ -30,8 +30,8 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
                                                                float* __restrict__ p_normed,
                                                                const GroupsDev groups, int ldo, int L, int d, int dh,
                                                                const CarcaCaWeights w, int residual, int training,
-                                                               const CarcaCaSave sv, const DropCfg dc,
-                                                               unsigned site) {
+                                                               const CarcaCaSave sv_in, const DropCfg dc,
+                                                               unsigned site, int nparts) {
   using G = AttGeom<DPI, DHP, NH>;
   constexpr int NW = 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -40,7 +40,15 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
   float* Vt = Ks + ATT_LMAX * G::SO;   // [DPO][ATT_SK]
   float* Yp = Vt + G::DPO * ATT_SK;    // [CROSS_TPR][NH][16] partial logits
 
-  const int u = blockIdx.x;
+  // With fewer users than CUs a user's target tiles are shared by TWO workgroups; both build the same final-norm /
+  // K / V^T images (nothing passes between them), the first one writes the copies kept for the backward pass.
+  const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
+  CarcaCaSave sv = sv_in;
+  if (part != 0) {
+    sv.kh = nullptr;
+    sv.vh = nullptr;
+    p_normed = nullptr;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it (jobs, tiles, heads) is uniform
   const int LT = (L + 15) >> 4;
@@ -102,8 +110,10 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
   // ---- C: rounds of CROSS_TPR target tiles; job = (tile, head) -----------------------------------------------
   const float sqrt_dh = sqrtf((float)dh);
   const float ffn_b = w.ffn_b[0];
-  const int ntiles = groups.tile_start[groups.n];
-  for (int t0 = 0; t0 < ntiles; t0 += CROSS_TPR) {
+  const int all_tiles = groups.tile_start[groups.n];
+  const int per_part = (all_tiles + nparts - 1) / nparts;
+  const int ntiles = min(all_tiles, (part + 1) * per_part);
+  for (int t0 = part * per_part; t0 < ntiles; t0 += CROSS_TPR) {
     const int nt = min(CROSS_TPR, ntiles - t0);
     for (int job = wave; job < nt * NH; job += NW) {
       const int tl = job / NH, h = job - tl * NH;
@@ -191,8 +201,17 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L, d,
-                     d / NH, w, residual, training, sv, dc, site);
+  static int num_cus = 0;
+  if (num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    num_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                  ? prop.multiProcessorCount : 256;
+  }
+  const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);  // 1 = one workgroup per user, 2 = always two
+  const int nparts = (groups.tile_start[groups.n] > 1 && tune != 1 && (tune == 2 || 2 * B <= num_cus)) ? 2 : 1;
+  hipLaunchKernelGGL(kern, dim3(B * nparts), dim3(1024), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L,
+                     d, d / NH, w, residual, training, sv, dc, site, nparts);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
                                                             float* __restrict__ y, int ldy, int L, int d, int dh,
                                                             const CarcaSaWeights w, int residual,
                                                             const CarcaSaSave sv, const DropCfg dc, unsigned site,
-                                                            unsigned long long* stamps) {
+                                                            unsigned long long* stamps, int nparts) {
   using G = AttGeom<DPI, DHP, NH>;
   static_assert(G::SO >= G::SI, "H1 reuses the K image");
 #define SA_STAMP(i)                                                                       \
@@ -39,10 +39,29 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   float* Ks = Qn + ATT_LMAX * G::SI;  // [64][SO]  K -> H1
   float* Vt = Ks + ATT_LMAX * G::SO;  // [DPO][ATT_SK]
 
-  const int u = blockIdx.x;
+  // With fewer users than CUs a user is shared by TWO workgroups: each owns a set of 16-query tiles (balanced for
+  // the causal cost: {1,2} | {0,3} of four) and everything row-wise about them; K / V^T are projected by both, but
+  // only for the key tiles its queries can attend.  No data passes between the two.
+  const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it (jobs, tiles, heads) is uniform
   const int LT = (L + 15) >> 4;
+  // own query tiles (bit t of tmask), their list, and the number of key tiles they need
+  const unsigned tmask = nparts == 1 ? (1u << LT) - 1u
+                         : LT == 4   ? (part == 0 ? 0x6u : 0x9u)
+                         : LT == 3   ? (part == 0 ? 0x4u : 0x3u)
+                                     : (part == 0 ? 0x2u : 0x1u);
+  unsigned own_packed = 0;  // 4 bits per own tile index
+  int n_own = 0, kmax = 0;
+#pragma unroll
+  for (int t = 0; t < ATT_LT; ++t)
+    if (t < LT && ((tmask >> t) & 1u)) {
+      own_packed |= (unsigned)t << (4 * n_own);
+      ++n_own;
+      kmax = t + 1;
+    }
+  auto own = [&](int i) { return (int)((own_packed >> (4 * i)) & 15u); };
+  const bool owns_last = (tmask >> (LT - 1)) & 1u;  // this workgroup projects every key: it saves K / V for backward
   const int32_t* uid = ids + (size_t)u * L;
   const unsigned long long pmask = __ballot(lane < L && uid[lane < L ? lane : 0] != 0);
   const size_t ubase = (size_t)u * L;
@@ -68,7 +87,8 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   __syncthreads();
   SA_STAMP(1);
   // ---- A1 ---------------------------------------------------------------------------------------------
-  for (int r = wave; r < 16 * LT; r += NW) {
+  for (int ri = wave; ri < 16 * n_own; ri += NW) {
+    const int r = 16 * own(ri >> 4) + (ri & 15);
     float v0 = lane < DPI ? Xs[r * G::SI + lane] : 0.f;
     float v1 = lane + 64 < DPI ? Xs[r * G::SI + lane + 64] : 0.f;
     if (lane >= d) v0 = 0.f;
@@ -85,17 +105,17 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   SA_STAMP(2);
   // ---- B (reads Xs only, so no barrier is needed between A1 and B) ---------------------------------------
   {
-    const int nk = G::NF * LT;
+    const int nk = G::NF * kmax;  // only the key tiles the own queries can attend (causal)
     for (int job = wave; job < 2 * nk; job += NW) {
       const bool isv = job >= nk;
       const int jj = isv ? job - nk : job;
-      const int ft = jj / LT, st = jj - ft * LT;
+      const int ft = jj / kmax, st = jj - ft * kmax;
       if (!isv)
         proj_tile_feat_major<DPI>(w.wk, w.bk, Xs, G::SI, Ks, G::SO, ft, st, lane,
-                                  sv.kh ? sv.kh + ubase * G::DPO : nullptr, G::DPO, L);
+                                  (sv.kh && owns_last) ? sv.kh + ubase * G::DPO : nullptr, G::DPO, L);
       else
         proj_tile_slot_major<DPI>(w.wv, w.bv, Xs, G::SI, Vt, ATT_SK, ft, st, lane,
-                                  sv.vh ? sv.vh + ubase * G::DPO : nullptr, G::DPO, L);
+                                  (sv.vh && owns_last) ? sv.vh + ubase * G::DPO : nullptr, G::DPO, L);
     }
   }
   __syncthreads();
@@ -103,8 +123,9 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
 
   // ---- C1: attention per (query tile, head) -----------------------------------------------------------------
   const float sqrt_dh = sqrtf((float)dh);
-  for (int job = wave; job < LT * NH; job += NW) {
-    const int qt = job / NH, h = job - qt * NH;
+  for (int job = wave; job < n_own * NH; job += NW) {
+    const int qi = job / NH, h = job - qi * NH;
+    const int qt = own(qi);
     const int q = 16 * qt + ln;
     const bool q_ok = (pmask >> q) & 1ull;
     f32x4 qfrag[G::NKG];
@@ -140,7 +161,8 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   __syncthreads();
   SA_STAMP(4);
   // ---- C2: LayerNorm2 rows, in place -------------------------------------------------------------------------
-  for (int r = wave; r < 16 * LT; r += NW) {
+  for (int ri = wave; ri < 16 * n_own; ri += NW) {
+    const int r = 16 * own(ri >> 4) + (ri & 15);
     float v0 = lane < d ? Xs[r * G::SI + lane] : 0.f;
     float v1 = lane + 64 < d ? Xs[r * G::SI + lane + 64] : 0.f;
     row_layernorm(v0, v1, lane, d, w.ln2_w, w.ln2_b);
@@ -156,8 +178,9 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   SA_STAMP(5);
   // ---- C3: ffn_1 + LeakyReLU per (query tile, f tile) -> H1 (over the dead K image) ---------------------------
   float* H1 = Ks;
-  for (int job = wave; job < LT * G::NKG; job += NW) {
-    const int qt = job / G::NKG, ft = job - qt * G::NKG;
+  for (int job = wave; job < n_own * G::NKG; job += NW) {
+    const int qi = job / G::NKG, ft = job - qi * G::NKG;
+    const int qt = own(qi);
     const int q = 16 * qt + ln;
     const int woff = (16 * ft + ln) * DPI + 4 * mq;
     const float* srow = Xs + q * G::SI + 4 * mq;
@@ -186,8 +209,9 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   __syncthreads();
   SA_STAMP(6);
   // ---- C4: ffn_2 + residual per (query tile, f tile) -> y ------------------------------------------------------
-  for (int job = wave; job < LT * G::NKG; job += NW) {
-    const int qt = job / G::NKG, ft = job - qt * G::NKG;
+  for (int job = wave; job < n_own * G::NKG; job += NW) {
+    const int qi = job / G::NKG, ft = job - qi * G::NKG;
+    const int qt = own(qi);
     const int q = 16 * qt + ln;
     const int woff = (16 * ft + ln) * DPI + 4 * mq;
     const float* hrow = H1 + q * G::SI + 4 * mq;
@@ -231,8 +255,18 @@ int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, in
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((sa_block_kernel_w16<DPI, DHP, NH>), dim3(B), dim3(1024), lds_bytes, stream, x, ldx, ids, y, ldy, L,
-                     d, d / NH, w, residual, sv, dc, site, carca_debug_buffer());
+  // two workgroups per user while that still fits the chip in one round (tuning key 1: 1 = never, 2 = always)
+  static int num_cus = 0;
+  if (num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    num_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                  ? prop.multiProcessorCount : 256;
+  }
+  const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);
+  const int nparts = (L > 16 && tune != 1 && (tune == 2 || 2 * B <= num_cus)) ? 2 : 1;
+  hipLaunchKernelGGL((sa_block_kernel_w16<DPI, DHP, NH>), dim3(B * nparts), dim3(1024), lds_bytes, stream, x, ldx, ids,
+                     y, ldy, L, d, d / NH, w, residual, sv, dc, site, carca_debug_buffer(), nparts);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

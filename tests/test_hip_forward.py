@@ -298,3 +298,26 @@ def test_folded_embedding_matches_oracle():
         got3 = model(profile=(profile[0].cuda(), None, profile[2].cuda()), targets=[(target[0].cuda(), None, target[2].cuda())])
         assert float((got3.cpu() - want2).abs().max()) < Y_ATOL
     model.fold_embedding(False)
+
+
+def test_two_workgroups_per_user_is_bitwise_the_same():
+    """Tuning key 1 (1 = one workgroup per user, 2 = two): the split only moves rows / target tiles between workgroups."""
+    from carca_replication_amd import _lib
+
+    cfg = O.CarcaConfig(d=90, H=3, n_blocks=2, encoding="learnable")
+    n_items, n_attrs, n_ctx, g, L, N, B = 300, 200, 6, 450, 50, 101, 5
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    profile, target, _ = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=7)
+    model = model_from_params(P, cfg).eval()
+    lib = _lib.load()
+    outs = {}
+    try:
+        for tune in (1, 2):
+            lib.carca_set_tuning(1, tune)
+            with torch.no_grad():
+                outs[tune] = model(profile=dev(profile), targets=[dev(target)]).cpu()
+    finally:
+        lib.carca_set_tuning(1, 0)
+    assert torch.equal(outs[1], outs[2])
+    want = O.carca_forward(P, cfg, profile, [target], training=False)
+    assert float((outs[2] - want).abs().max()) < Y_ATOL

@@ -19,12 +19,13 @@ sw = model.encoder[0].weights_struct(x.device)
 lib = _lib.load()
 for _ in range(5):
     ops.sa_block_fwd(x, ids, sw, d, H, True)
-buf = torch.zeros(B * 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(2 * B * 16, dtype=torch.int64, device="cuda")
 lib.carca_set_debug_buffer(buf.data_ptr())
 ops.sa_block_fwd(x, ids, sw, d, H, True)
 torch.cuda.synchronize()
 lib.carca_set_debug_buffer(None)
-st = buf.view(B, 16)[:, :8].cpu().double()
+st = buf.view(2 * B, 16)[:, :8].cpu().double()
+st = st[st[:, 0] > 0]
 dt = (st[:, 1:] - st[:, :-1])
 names = ["A0 load x", "A1 LN1", "B K/V", "C1 attn", "C2 LN2", "C3 ffn1", "C4 ffn2"]
 print("median cycles per phase over workgroups (s_memtime ticks = shader cycles):")
