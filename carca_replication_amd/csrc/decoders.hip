@@ -1,0 +1,187 @@
+// The reference's ablation decoders as row kernels on the same padded layouts:
+//   DotProduct.forward          carca.py:352-367   y = sigmoid(p . o)        train: slot-wise, eval: last profile slot
+//   WeightedDotProduct.forward  carca.py:370-399   p'[t] = p[t] sum_{j<=t} gamma^j; optional L2 normalisation;
+//                                                  y = sigmoid(p' . o) or (p' . o + 1) / 2
+// plus the stand-alone final LayerNorm (carca.py:421) that the cross-attention kernel otherwise fuses.
+// One wave per row, two features per lane (d <= 128): HBM/latency-bound row work, nothing to tile.
+#include "attn_common.h"
+#include "../../include/carca_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                            int ldy, int rows, int d, const float* __restrict__ w,
+                                                            const float* __restrict__ b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * ldx;
+    float v0 = lane < d ? xr[lane] : 0.f, v1 = lane + 64 < d ? xr[lane + 64] : 0.f;
+    row_layernorm(v0, v1, lane, d, w, b);
+    float* yr = y + (size_t)row * ldy;
+    if (lane < ldy) yr[lane] = v0;
+    if (lane + 64 < ldy) yr[lane + 64] = v1;
+  }
+}
+
+// y[b][t] = link(p_row . o[b][t]); p_row = p[b][t] (slotwise, T == L) or p[b][L-1]
+__global__ __launch_bounds__(256) void dot_score_fwd_kernel(const float* __restrict__ p, int ldp,
+                                                            const float* __restrict__ o, int ldo,
+                                                            float* __restrict__ y, int B, int L, int T, int d,
+                                                            int slotwise, int link) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < B * T; row += gridDim.x * 4) {
+    const int b = row / T, t = row - b * T;
+    const float* pr = p + (size_t)(b * L + (slotwise ? t : L - 1)) * ldp;
+    const float* orow = o + (size_t)row * ldo;
+    float s = 0.f;
+    if (lane < d) s += pr[lane] * orow[lane];
+    if (lane + 64 < d) s += pr[lane + 64] * orow[lane + 64];
+    s = wave_sum(s);
+    if (lane == 0) y[row] = link == 0 ? 1.0f / (1.0f + expf(-s)) : (s + 1.0f) * 0.5f;
+  }
+}
+
+// dl = dy * dlink/ds; d_o[row] = dl * p_row; d_p[p_row] += dl * o[row]
+__global__ __launch_bounds__(256) void dot_score_bwd_kernel(const float* __restrict__ p, int ldp,
+                                                            const float* __restrict__ o, int ldo,
+                                                            const float* __restrict__ y, const float* __restrict__ dy,
+                                                            float* __restrict__ dp, int ld_dp, float* __restrict__ d_o,
+                                                            int ld_do, int B, int L, int T, int d, int slotwise,
+                                                            int link) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < B * T; row += gridDim.x * 4) {
+    const int b = row / T, t = row - b * T;
+    const size_t prow = (size_t)(b * L + (slotwise ? t : L - 1));
+    const float yy = y[row];
+    const float dl = dy[row] * (link == 0 ? yy * (1.0f - yy) : 0.5f);
+    const float* pr = p + prow * ldp;
+    const float* orow = o + (size_t)row * ldo;
+    float* dor = d_o + (size_t)row * ld_do;
+    float* dpr = dp + prow * ld_dp;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = lane + 64 * h;
+      if (c < ld_do) dor[c] = c < d ? dl * pr[c] : 0.f;
+      if (c < d) {
+        if (slotwise)
+          dpr[c] += dl * orow[c];  // one writer per element and launch; groups are separate, stream-ordered launches
+        else
+          atomicAdd(&dpr[c], dl * orow[c]);
+      }
+    }
+  }
+}
+
+// out[b][t][:] = c_t x[b][t][:], c_t = sum_{j<=t} gamma^j: what WeightedDotProduct's repeat / tril / sum amounts to
+// (carca.py:376-378,385-386: the history is repeated along a NEW axis, so slots are scaled, not mixed).  Self-adjoint.
+__global__ void slot_decay_scale_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo, int rows,
+                                        int L, int d, float gamma) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ldo) return;
+  const int row = i / ldo, f = i - row * ldo;
+  const int t = row % L;
+  float c = 0.f;
+  for (int j = 0; j <= t; ++j) c += powf(gamma, (float)j);
+  out[i] = f < d ? c * x[(size_t)row * ldx + f] : 0.f;
+}
+
+// torch.nn.functional.normalize(x, dim=-1): y = x / max(||x||, 1e-12)
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                         int ldy, int rows, int d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * ldx;
+    const float v0 = lane < d ? xr[lane] : 0.f, v1 = lane + 64 < d ? xr[lane + 64] : 0.f;
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(v0 * v0 + v1 * v1)), 1e-12f);
+    float* yr = y + (size_t)row * ldy;
+    if (lane < ldy) yr[lane] = v0 * inv;
+    if (lane + 64 < ldy) yr[lane + 64] = v1 * inv;
+  }
+}
+// dx = (dy - y (y . dy)) / max(||x||, 1e-12), y = normalize(x)   (rows with ||x|| < 1e-12: dx = dy / 1e-12 like autograd)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ dy, int ld_dy,
+                                                         float* __restrict__ dx, int ld_dx, int rows, int d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * ldx;
+    const float* gr = dy + (size_t)row * ld_dy;
+    const float v0 = lane < d ? xr[lane] : 0.f, v1 = lane + 64 < d ? xr[lane + 64] : 0.f;
+    const float g0 = lane < d ? gr[lane] : 0.f, g1 = lane + 64 < d ? gr[lane + 64] : 0.f;
+    const float nrm = sqrtf(wave_sum(v0 * v0 + v1 * v1));
+    const bool tiny = nrm < 1e-12f;
+    const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+    const float y0 = v0 * inv, y1 = v1 * inv;
+    const float dot = tiny ? 0.f : wave_sum(y0 * g0 + y1 * g1);
+    float* outr = dx + (size_t)row * ld_dx;
+    if (lane < ld_dx) outr[lane] = lane < d ? (g0 - y0 * dot) * inv : 0.f;
+    if (lane + 64 < ld_dx) outr[lane + 64] = lane + 64 < d ? (g1 - y1 * dot) * inv : 0.f;
+  }
+}
+
+inline int row_blocks(int rows) { return min((rows + 3) / 4, 4096); }
+
+}  // namespace
+
+extern "C" int carca_layernorm_fwd(const float* x, int ldx, float* y, int ldy, int rows, int d, const float* w,
+                                   const float* b, void* stream_) {
+  CARCA_CHECK_ARG(x && y && w && b && rows >= 1 && d >= 1 && ldx >= d && ldy >= d, "layernorm_fwd: bad arguments");
+  CARCA_CHECK_SUPPORTED(d <= 128 && ldy <= 128, "layernorm_fwd: d=%d / ldy=%d > 128", d, ldy);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream_, x, ldx, y, ldy,
+                     rows, d, w, b);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_dot_score_fwd(const float* p, int ldp, const float* o, int ldo, float* y, int B, int L, int T, int d,
+                                   int slotwise, int link, void* stream_) {
+  CARCA_CHECK_ARG(p && o && y && B >= 1 && L >= 1 && T >= 1 && d >= 1 && ldp >= d && ldo >= d, "dot_score_fwd: bad arguments");
+  CARCA_CHECK_ARG(!slotwise || T == L, "dot_score_fwd: slot-wise scoring needs T == L (got T=%d, L=%d)", T, L);
+  CARCA_CHECK_SUPPORTED(d <= 128, "dot_score_fwd: d=%d > 128", d);
+  hipLaunchKernelGGL(dot_score_fwd_kernel, dim3(row_blocks(B * T)), dim3(256), 0, (hipStream_t)stream_, p, ldp, o, ldo, y,
+                     B, L, T, d, slotwise, link);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_dot_score_bwd(const float* p, int ldp, const float* o, int ldo, const float* y, const float* dy,
+                                   float* dp, int ld_dp, float* d_o, int ld_do, int B, int L, int T, int d, int slotwise,
+                                   int link, void* stream_) {
+  CARCA_CHECK_ARG(p && o && y && dy && dp && d_o && B >= 1 && L >= 1 && T >= 1 && d >= 1 && ldp >= d && ldo >= d &&
+                      ld_dp >= d && ld_do >= d,
+                  "dot_score_bwd: bad arguments");
+  CARCA_CHECK_ARG(!slotwise || T == L, "dot_score_bwd: slot-wise scoring needs T == L");
+  CARCA_CHECK_SUPPORTED(d <= 128 && ld_do <= 128, "dot_score_bwd: d=%d / ld_do=%d > 128", d, ld_do);
+  hipLaunchKernelGGL(dot_score_bwd_kernel, dim3(row_blocks(B * T)), dim3(256), 0, (hipStream_t)stream_, p, ldp, o, ldo, y,
+                     dy, dp, ld_dp, d_o, ld_do, B, L, T, d, slotwise, link);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_slot_decay_scale(const float* x, int ldx, float* out, int ldo, int B, int L, int d, float gamma,
+                                     void* stream_) {
+  CARCA_CHECK_ARG(x && out && B >= 1 && L >= 1 && d >= 1 && ldx >= d && ldo >= d, "slot_decay_scale: bad arguments");
+  hipLaunchKernelGGL(slot_decay_scale_kernel, dim3((B * L * ldo + 255) / 256), dim3(256), 0, (hipStream_t)stream_, x, ldx,
+                     out, ldo, B * L, L, d, gamma);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_l2norm_fwd(const float* x, int ldx, float* y, int ldy, int rows, int d, void* stream_) {
+  CARCA_CHECK_ARG(x && y && rows >= 1 && d >= 1 && ldx >= d && ldy >= d, "l2norm_fwd: bad arguments");
+  CARCA_CHECK_SUPPORTED(d <= 128 && ldy <= 128, "l2norm_fwd: d=%d / ldy=%d > 128", d, ldy);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream_, x, ldx, y, ldy, rows,
+                     d);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_l2norm_bwd(const float* x, int ldx, const float* dy, int ld_dy, float* dx, int ld_dx, int rows,
+                                int d, void* stream_) {
+  CARCA_CHECK_ARG(x && dy && dx && rows >= 1 && d >= 1 && ldx >= d && ld_dy >= d && ld_dx >= d, "l2norm_bwd: bad arguments");
+  CARCA_CHECK_SUPPORTED(d <= 128 && ld_dx <= 128, "l2norm_bwd: d=%d / ld_dx=%d > 128", d, ld_dx);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream_, x, ldx, dy, ld_dy, dx,
+                     ld_dx, rows, d);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}

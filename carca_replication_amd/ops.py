@@ -582,6 +582,67 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, d: int, out_ld: int, add
     return dx
 
 
+def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, d: int, out_ld: int) -> Tensor:
+    """y [rows, out_ld] = LayerNorm(x[:, :d]) with zeroed pad columns (carca.py:421 outside the cross-attention kernel)."""
+    lib = _lib.load()
+    x = _row2d(x, "x")
+    y = torch.empty(x.shape[0], out_ld, dtype=torch.float32, device=x.device)
+    _lib.check(lib.carca_layernorm_fwd(x.data_ptr(), x.stride(0), y.data_ptr(), out_ld, x.shape[0], d, w.data_ptr(),
+                                       b.data_ptr(), _stream()), "layernorm_fwd")
+    return y
+
+
+def dot_score_fwd(p: Tensor, o: Tensor, B: int, L: int, T: int, d: int, slotwise: bool, link: int = 0) -> Tensor:
+    """y [B, T] = link(p_row . o) (DotProduct / WeightedDotProduct scoring, carca.py:361-367,390-397)."""
+    lib = _lib.load()
+    p, o = _row2d(p, "p"), _row2d(o, "o")
+    y = torch.empty(B, T, dtype=torch.float32, device=p.device)
+    _lib.check(lib.carca_dot_score_fwd(p.data_ptr(), p.stride(0), o.data_ptr(), o.stride(0), y.data_ptr(), B, L, T, d,
+                                       int(bool(slotwise)), int(link), _stream()), "dot_score_fwd")
+    return y
+
+
+def dot_score_bwd(p: Tensor, o: Tensor, y: Tensor, dy: Tensor, dp: Tensor, B: int, L: int, T: int, d: int, slotwise: bool,
+                  link: int, out_ld: int) -> Tensor:
+    """Returns d_o [B*T, out_ld]; ACCUMULATES into dp [B*L, ld] (caller zeroes it before the first group)."""
+    lib = _lib.load()
+    p, o, dp = _row2d(p, "p"), _row2d(o, "o"), _row2d(dp, "dp")
+    y, dy = _f32(y.reshape(-1)), _f32(dy.reshape(-1))
+    d_o = torch.empty(B * T, out_ld, dtype=torch.float32, device=p.device)
+    _lib.check(lib.carca_dot_score_bwd(p.data_ptr(), p.stride(0), o.data_ptr(), o.stride(0), y.data_ptr(), dy.data_ptr(),
+                                       dp.data_ptr(), dp.stride(0), d_o.data_ptr(), out_ld, B, L, T, d,
+                                       int(bool(slotwise)), int(link), _stream()), "dot_score_bwd")
+    return d_o
+
+
+def slot_decay_scale(x: Tensor, B: int, L: int, d: int, gamma: float, out_ld: int) -> Tensor:
+    """out[b][t] = x[b][t] * sum_{j<=t} gamma^j (WeightedDotProduct's history weights; its own backward); [B*L, out_ld]."""
+    lib = _lib.load()
+    x = _row2d(x, "x")
+    out = torch.empty(B * L, out_ld, dtype=torch.float32, device=x.device)
+    _lib.check(lib.carca_slot_decay_scale(x.data_ptr(), x.stride(0), out.data_ptr(), out_ld, B, L, d, float(gamma),
+                                          _stream()), "slot_decay_scale")
+    return out
+
+
+def l2norm_fwd(x: Tensor, d: int, out_ld: int) -> Tensor:
+    lib = _lib.load()
+    x = _row2d(x, "x")
+    y = torch.empty(x.shape[0], out_ld, dtype=torch.float32, device=x.device)
+    _lib.check(lib.carca_l2norm_fwd(x.data_ptr(), x.stride(0), y.data_ptr(), out_ld, x.shape[0], d, _stream()),
+               "l2norm_fwd")
+    return y
+
+
+def l2norm_bwd(x: Tensor, dy: Tensor, d: int, out_ld: int) -> Tensor:
+    lib = _lib.load()
+    x, dy = _row2d(x, "x"), _row2d(dy, "dy")
+    dx = torch.empty(x.shape[0], out_ld, dtype=torch.float32, device=x.device)
+    _lib.check(lib.carca_l2norm_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), dx.data_ptr(), out_ld,
+                                    x.shape[0], d, _stream()), "l2norm_bwd")
+    return dx
+
+
 def embed_scatter(dz: Tensor, ids: Tensor, d: int, scale: float, d_items: Tensor) -> None:
     lib = _lib.load()
     dz = _row2d(dz, "dz")

@@ -284,6 +284,29 @@ int carca_dropout_fwd(float* x, int rows, int cols, int ld, const CarcaDropout* 
 /* out[r][c] = x[r][c] * mask[r][c] * scale for c < cols, 0 for cols <= c < ncols_out (dropout backward) */
 int carca_mask_mul(const float* x, int ld_x, const uint8_t* mask, int ld_m, float scale, float* out, int ld_out,
                    int rows, int cols, int ncols_out, void* stream);
+/* ---- f4: the reference's ablation decoders and the stand-alone final LayerNorm ---------------------------
+ * Row kernels on the padded activation layout (d <= 128; pad columns of every output are written as zeros).
+ * carca_layernorm_fwd replaces CARCA.norm.forward (carca.py:421) where no cross-attention kernel fuses it. */
+int carca_layernorm_fwd(const float* x, int ldx, float* y, int ldy, int rows, int d, const float* w, const float* b,
+                        void* stream);
+/* DotProduct.forward (carca.py:361-367) / the scoring step of WeightedDotProduct.forward (carca.py:390-397):
+ * y[b][t] = link(p_row . o[b][t]) with p_row = p[b][t] (slotwise = 1: train mode, needs T == L) or p[b][L-1]
+ * (slotwise = 0: eval mode); link 0 = sigmoid, 1 = (s + 1) / 2.  p is [B*L, ldp], o is [B*T, ldo], y is [B*T]. */
+int carca_dot_score_fwd(const float* p, int ldp, const float* o, int ldo, float* y, int B, int L, int T, int d,
+                        int slotwise, int link, void* stream);
+/* its backward: d_o[row] = dl * p_row (written), dp[p_row] += dl * o[row] (ACCUMULATED: caller zeroes dp before the
+ * first group), dl = dy * dlink/ds */
+int carca_dot_score_bwd(const float* p, int ldp, const float* o, int ldo, const float* y, const float* dy, float* dp,
+                        int ld_dp, float* d_o, int ld_do, int B, int L, int T, int d, int slotwise, int link,
+                        void* stream);
+/* WeightedDotProduct's history weighting (carca.py:376-378,385-386): out[b][t][:] = c_t x[b][t][:] with
+ * c_t = sum_{j<=t} gamma^j (the reference repeats the history along a new axis, so slots are scaled, not mixed).
+ * The map is diagonal, hence its own backward. */
+int carca_slot_decay_scale(const float* x, int ldx, float* out, int ldo, int B, int L, int d, float gamma, void* stream);
+/* torch.nn.functional.normalize(x, dim=-1) (carca.py:388-389) and its backward */
+int carca_l2norm_fwd(const float* x, int ldx, float* y, int ldy, int rows, int d, void* stream);
+int carca_l2norm_bwd(const float* x, int ldx, const float* dy, int ld_dy, float* dx, int ld_dx, int rows, int d,
+                     void* stream);
 /* Inverse of carca_pack_weights for gradients: real[r][c] (+)= packed[rp][cp] (same descriptor fields:
  * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
 int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);

@@ -48,6 +48,11 @@ class CarcaConfig:
     residual_sa: bool = True
     residual_ca: bool = True
     encoding: str = "identity"  # identity | learnable | positional
+    # ablation variants (training.py:76-100)
+    embedding: str = "all"      # all | attrctx | attr | id | mlpid        carca.py:63-198
+    decoder: str = "ca"         # ca | dot | wdot                          carca.py:321-399
+    gamma: float = 0.9          # WeightedDotProduct decay                 training.py:55
+    l2_norm: bool = False       # WeightedDotProduct normalisation         training.py:56
 
 
 # --------------------------------------------------------------------------- #
@@ -109,6 +114,61 @@ def all_embedding(params: Params, cfg: CarcaConfig, x: Tensor, a: Tensor, c: Ten
     if return_q:
         return e, q, z
     return e
+
+
+# --------------------------------------------------------------------------- #
+# f4: ablation embeddings                                    carca.py:98-198  #
+# --------------------------------------------------------------------------- #
+def embedding(params: Params, cfg: CarcaConfig, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
+    """Dispatch on cfg.embedding; every variant ends with (+pos on the profile side) * mask like AllEmbedding."""
+    kind = cfg.embedding
+    if kind == "all":
+        return all_embedding(params, cfg, x, a, c, mask, target)
+    if kind in ("attrctx", "attr"):
+        Wf, bf = params["embeds.feats_embed.weight"], params["embeds.feats_embed.bias"]
+        Wj, bj = params["embeds.joint_embed.weight"], params["embeds.joint_embed.bias"]
+        n_attrs = a.shape[-1]
+        q = a @ Wf[:, :n_attrs].T + bf                      # AttrEmbedding: attributes only (carca.py:142)
+        if kind == "attrctx":
+            q = q + c @ Wf[:, n_attrs:].T                   # AttrCtxEmbedding: cat((a, c)) (carca.py:113)
+        e = q @ Wj.T + bj                                   # joint_embed: g -> d, no item-id term (carca.py:114,143)
+    elif kind == "id":
+        e = params["embeds.items_embed.weight"][x.long()] * (cfg.d ** 0.5)          # carca.py:164-165
+    elif kind == "mlpid":
+        z = params["embeds.items_embed.weight"][x.long()] * (cfg.d ** 0.5)          # [.., g] (carca.py:190-191)
+        e = z @ params["embeds.feats_embed.weight"].T + params["embeds.feats_embed.bias"]  # carca.py:192
+    else:
+        raise ValueError(f"Unknown embedding type: {kind}")
+    if not target:
+        pos = position_term(params, cfg, x.shape[1])
+        if pos is not None:
+            e = e + pos.unsqueeze(0)
+    return e * mask.unsqueeze(-1)
+
+
+# --------------------------------------------------------------------------- #
+# f4: ablation decoders                                     carca.py:352-399  #
+# --------------------------------------------------------------------------- #
+def dot_decoder(cfg: CarcaConfig, o: Tensor, p: Tensor, training: bool) -> Tensor:
+    """DotProduct (carca.py:361-367) and WeightedDotProduct (carca.py:383-399).  Neither looks at the masks."""
+    L = p.shape[1]
+    if cfg.decoder == "wdot":
+        # carca.py:376-378,385-386: W[t][j] = gamma^j for j <= t; pw[b,t,j,:] = p[b,t,:] (the repeat runs along the
+        # NEW axis), so the sum over j scales slot t by c_t = sum_{j<=t} gamma^j -- it does not mix slots
+        # (kept as the same product-then-sum so that the fp32 rounding matches the fixtures to the last bit or two)
+        w = cfg.gamma ** torch.arange(0, L)                                  # float32, like the reference's buffer
+        W = torch.tril(w.unsqueeze(0).expand(L, L)).to(p.dtype)              # [t][j]
+        p = (p.unsqueeze(2) * W.view(1, L, L, 1)).sum(dim=2)                 # = p[b,t,:] * c_t
+        if cfg.l2_norm:
+            p = torch.nn.functional.normalize(p, dim=2)
+            o = torch.nn.functional.normalize(o, dim=2)
+    if training:
+        s = (p * o).sum(-1)               # slot t of the profile against target t (carca.py:362,391)
+    else:
+        s = (p[:, -1:, :] * o).sum(-1)    # last profile slot against every candidate (carca.py:364,393)
+    if cfg.decoder == "wdot" and cfg.l2_norm:
+        return (s + 1.0) / 2.0            # carca.py:395-396
+    return torch.sigmoid(s)
 
 
 # --------------------------------------------------------------------------- #
@@ -215,7 +275,7 @@ def carca_forward(params: Params, cfg: CarcaConfig, profile: Tuple[Tensor, Tenso
     dt = p_a.dtype
     p_mask = get_mask(p_x, dt)
     mk = masks or {}
-    p_e = all_embedding(params, cfg, p_x, p_a, p_c, p_mask, target=False)
+    p_e = embedding(params, cfg, p_x, p_a, p_c, p_mask, target=False)
     if trace is not None:
         trace["p_mask"], trace["p_embed"] = p_mask, p_e
     if "embed" in mk:
@@ -230,9 +290,12 @@ def carca_forward(params: Params, cfg: CarcaConfig, profile: Tuple[Tensor, Tenso
     ys = []
     for gi, (o_x, o_a, o_c) in enumerate(targets):
         o_mask = get_mask(o_x, dt)
-        o_e = all_embedding(params, cfg, o_x, o_a, o_c, o_mask, target=True)
-        y, w = cross_block(params, cfg, o_e, o_mask, p_e, p_mask, training, return_w=True,
-                           drop_mask=mk.get(f"cross{gi}"))
+        o_e = embedding(params, cfg, o_x, o_a, o_c, o_mask, target=True)
+        if cfg.decoder == "ca":
+            y, w = cross_block(params, cfg, o_e, o_mask, p_e, p_mask, training, return_w=True,
+                               drop_mask=mk.get(f"cross{gi}"))
+        else:
+            y, w = dot_decoder(cfg, o_e, p_e, training), None
         if trace is not None:
             trace[f"o_embed{gi}"], trace[f"dec_w{gi}"] = o_e, w
         ys.append(y)
@@ -300,13 +363,19 @@ def init_params(cfg: CarcaConfig, n_items: int, g: int, n_ctx: int, n_attrs: int
         return ((torch.rand(*shape, generator=gen) * 2 - 1) * bound).to(dtype)
 
     P: Params = {}
-    E = xavier(n_items, d)
-    E[0] = 0
-    P["embeds.items_embed.weight"] = E
-    P["embeds.feats_embed.weight"] = xavier(g, F)
-    P["embeds.feats_embed.bias"] = torch.zeros(g, dtype=dtype)
-    P["embeds.joint_embed.weight"] = xavier(d, d + g)
-    P["embeds.joint_embed.bias"] = torch.zeros(d, dtype=dtype)
+    kind = cfg.embedding
+    if kind in ("all", "id", "mlpid"):
+        E = xavier(n_items, g if kind == "mlpid" else d)
+        E[0] = 0
+        P["embeds.items_embed.weight"] = E
+    if kind in ("all", "attrctx", "attr"):
+        P["embeds.feats_embed.weight"] = xavier(g, n_attrs if kind == "attr" else F)
+        P["embeds.feats_embed.bias"] = torch.zeros(g, dtype=dtype)
+        P["embeds.joint_embed.weight"] = xavier(d, d + g if kind == "all" else g)
+        P["embeds.joint_embed.bias"] = torch.zeros(d, dtype=dtype)
+    if kind == "mlpid":
+        P["embeds.feats_embed.weight"] = xavier(d, g)
+        P["embeds.feats_embed.bias"] = torch.zeros(d, dtype=dtype)
     if cfg.encoding == "learnable":
         P["embeds.enc.encoding.weight"] = xavier(L, d)
     elif cfg.encoding == "positional":
@@ -328,9 +397,10 @@ def init_params(cfg: CarcaConfig, n_items: int, g: int, n_ctx: int, n_attrs: int
             P[pre + n + ".bias"] = torch.zeros(d, dtype=dtype)
     P["norm.weight"] = torch.ones(d, dtype=dtype)
     P["norm.bias"] = torch.zeros(d, dtype=dtype)
-    attn("decoder.attn.")
-    P["decoder.ffn.weight"] = xavier(1, d)
-    P["decoder.ffn.bias"] = torch.zeros(1, dtype=dtype)
+    if cfg.decoder == "ca":
+        attn("decoder.attn.")
+        P["decoder.ffn.weight"] = xavier(1, d)
+        P["decoder.ffn.bias"] = torch.zeros(1, dtype=dtype)
     return P
 
 

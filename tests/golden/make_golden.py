@@ -17,6 +17,8 @@ seeded inputs and storing inputs, weights and outputs as small .npz files:
   g6_shapes.npz  squeeze() quirks, B=1 and N=1             (carca.py:346)
   g7_<variant>.npz learnable / positional encoding, residual=False
   g8_ranking.npz briefly trained weights -> per-user rank, HR@10, NDCG@10
+  g9_<variant>.npz ablation embeddings (attrctx, attr, id, mlpid) and decoders (dot, wdot, wdot + l2 norm):
+                 eval scores + loss, train-mode scores + loss + all grads   (carca.py:98-198,352-399)
 
 Only data is written: inputs and the reference's outputs.
 """
@@ -295,5 +297,67 @@ def main():
          outs)
 
 
+def build_variant(cfg, n_items, n_attrs, n_ctx, L, seed=0):
+    """The factories of scripts/training.py:76-100, by hand (the script itself is an argparse entry point)."""
+    torch.manual_seed(seed)
+    d, g = cfg["d"], cfg["g"]
+    enc = R.LearnableEncoding(d, L) if cfg.get("encoding") == "learnable" else R.IdentityEncoding()
+    kind = cfg.get("embedding", "all")
+    emb = {"all": lambda: R.AllEmbedding(n_items, d, g, n_ctx, n_attrs, enc),
+           "attrctx": lambda: R.AttrCtxEmbedding(d, g, n_ctx, n_attrs, enc),
+           "attr": lambda: R.AttrEmbedding(d, g, n_attrs, enc),
+           "id": lambda: R.IdEmbedding(n_items, d, enc),
+           "mlpid": lambda: R.MLPIdEmbedding(n_items, d, g, enc)}[kind]()
+    blocks = torch.nn.ModuleList([R.SelfAttentionBlock(d, cfg["H"], 0.0, True) for _ in range(cfg["n_blocks"])])
+    dk = cfg.get("decoder", "ca")
+    dec = {"ca": lambda: R.CrossAttentionBlock(d, cfg["H"], 0.0, True),
+           "dot": lambda: R.DotProduct(),
+           "wdot": lambda: R.WeightedDotProduct(cfg.get("gamma", 0.9), L, bool(cfg.get("l2_norm", False)), "cpu")}[dk]()
+    model = R.CARCA(d=d, p=0.0, emb=emb, enc=blocks, dec=dec)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if name.endswith(".bias") or (".norm" in name or name.startswith("norm.")) and name.endswith(".weight"):
+                prm.add_(0.05 * torch.randn(prm.shape, generator=gen))
+    return model
+
+
+VARIANTS = {
+    "attrctx": dict(embedding="attrctx", encoding="learnable"),
+    "attr": dict(embedding="attr"),
+    "id": dict(embedding="id", encoding="learnable"),
+    "mlpid": dict(embedding="mlpid"),
+    "dot": dict(decoder="dot"),
+    "wdot": dict(decoder="wdot", gamma=0.9, l2_norm=False),
+    "wdotnorm": dict(decoder="wdot", gamma=0.8, l2_norm=True),
+    "iddot": dict(embedding="id", decoder="dot"),  # the cheapest ablation pair
+}
+
+
+def main_g9():
+    torch.set_num_threads(4)
+    B, L, N, n_items, n_attrs, n_ctx = SHAPES["d90h2"]
+    dims = dict(B=B, L=L, N=N, n_items=n_items, n_attrs=n_attrs, n_ctx=n_ctx)
+    for vname, extra in VARIANTS.items():
+        cfg = dict(CFGS["d90h2"], **extra)
+        model = build_variant(cfg, n_items, n_attrs, n_ctx, L, seed=6)
+        x = make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed=18)
+        model.eval()
+        with torch.no_grad():
+            y = model.forward(profile=(x["p_x"], x["p_a"], x["p_c"]), targets=[(x["o_x"], x["o_a"], x["o_c"])])
+            loss = R.BinaryCrossEntropy().forward(y, x["y_true"], get_mask(x["o_x"]))
+        outs = dict(y=y, loss=loss)
+        xt = make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed=19, train_shape=True)
+        tr = train_trace(model, xt)
+        ins = dict(x)
+        ins.update({"train/" + k: v for k, v in xt.items()})
+        outs.update({"train/" + k: v for k, v in tr.items()})
+        save("g9_" + vname, cfg, dims, model.state_dict(), ins, outs)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        main_g9()
+    else:
+        main()
+        main_g9()

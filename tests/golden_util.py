@@ -29,8 +29,11 @@ def oracle_config(cfg):
 
     return CarcaConfig(d=int(cfg["d"]), H=int(cfg["H"]), n_blocks=int(cfg["n_blocks"]),
                        residual_sa=bool(cfg.get("residual_sa", True)), residual_ca=bool(cfg.get("residual_ca", True)),
-                       encoding=str(cfg.get("encoding", "identity")))
+                       encoding=str(cfg.get("encoding", "identity")), embedding=str(cfg.get("embedding", "all")),
+                       decoder=str(cfg.get("decoder", "ca")), gamma=float(cfg.get("gamma", 0.9)),
+                       l2_norm=bool(cfg.get("l2_norm", False)))
 
 
 G1_NAMES = ["d90h3", "d90h2", "d128h4", "d64h2"]
 G7_NAMES = ["learnable", "positional", "nores"]
+G9_NAMES = ["attrctx", "attr", "id", "mlpid", "dot", "wdot", "wdotnorm", "iddot"]
