@@ -49,22 +49,69 @@ def _attn_param_grads(packs: _Packs, attn, grads_by_param):
     packs.g.unpack_into(real, accumulate=True)
 
 
+def _cross_decoder_backward(model, st, ys, dys, gbp, dev):
+    """Backward of the sigmoid/ffn head + cross-attention (carca.py:340-347): returns (d p_normed, [d o_g])."""
+    dec = model.decoder
+    d, H = model.embeds.d, dec.attn.H
+    dpi, dhp, dpo = ops.padded_dims(d, H)
+    dh = d // H
+    B, L = st["B"], st["L"]
+    p_x = st["p_x"]
+    ngroups = st["ngroups"]
+    cp = _Packs(dec.attn, [], dev)
+    d_wpad = torch.zeros(dpo, dtype=torch.float32, device=dev)
+    bgroups = []
+    for gi in range(ngroups):
+        bgroups.append((st["csave"]["qh"][gi], ys[gi], dys[gi], st["segs"][gi + 1][0]))
+    ffn_w_pad_ptr = st["cw"].ffn_w_pad
+    cpd = st["csave"]["p"]
+    dqhs, dls, dkh, dvh = ops.cross_attn_bwd(st["csave"]["kh"], st["csave"]["vh"], p_x, bgroups, ffn_w_pad_ptr,
+                                             d_wpad, B, L, d, H, st["training"],
+                                             masks=st["csave"].get("m_attn") if cpd > 0 else None,
+                                             drop_scale=1.0 / (1.0 - cpd) if cpd > 0 else 1.0)
+    g_ffn_w, g_ffn_b = gbp[id(dec.ffn.weight)], gbp[id(dec.ffn.bias)]
+    o_rows = [st["es"][gi + 1].view(-1, dpi) for gi in range(ngroups)]
+    o_ids = [st["segs"][gi + 1][0] for gi in range(ngroups)]
+    for gi in range(ngroups):
+        ops.colsum(dls[gi].view(-1, 1), 1, g_ffn_b)                       # d ffn.bias = sum dlogit
+        if dec.residual:
+            ops.colsum(o_rows[gi], d, g_ffn_w, rowscale=dls[gi])          # residual part of d ffn.weight
+    wp_item = ops.PackedWeights([ops.PackItem(dec.ffn.weight, 1, dpo, col_heads=(dh, dhp))], dev)
+    wp_item.buf.copy_(d_wpad)                                             # attention part, head-padded
+    wp_item.unpack_into([g_ffn_w], accumulate=True)
+    # d o_g = dQ_g . W_Q (+ dlogit (x) w), masked like e * mask (carca.py:94)
+    wq_t, wk_t, wv_t = cp.wT.view(0), cp.wT.view(1), cp.wT.view(2)
+    ffn_w_plain = dec.ffn.weight.detach().reshape(-1)
+    des_t = ops.gemm_rows([dict(a0=dqhs[gi], rowscale=dls[gi] if dec.residual else None, ids=o_ids[gi])
+                           for gi in range(ngroups)], wq_t, d, dpo, dpi,
+                          colvec=ffn_w_plain if dec.residual else None, mask_rows=True)
+    ops.gemm_wgrad([dict(dy=dqhs[gi], x=o_rows[gi]) for gi in range(ngroups)], dpo, d, cp.g.view(0),
+                   cp.g.view(3).view(-1))
+    pn = st["p_normed"].view(-1, st["p_normed"].shape[-1])
+    ops.gemm_wgrad([dict(dy=dkh, x=pn)], dpo, d, cp.g.view(1), cp.g.view(4).view(-1))
+    ops.gemm_wgrad([dict(dy=dvh, x=pn)], dpo, d, cp.g.view(2), cp.g.view(5).view(-1))
+    _attn_param_grads(cp, dec.attn, gbp)
+    (dp,) = ops.gemm_rows([dict(a0=dkh, a1=dvh)], wk_t, d, dpo, dpi, bt1=wv_t, K1=dpo)
+    return dp, des_t
+
+
 class _CarcaFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, profile, targets, *params):
-        from .modules import AllEmbedding  # noqa: F401
+        from .modules import CrossAttentionBlock
 
         p_x, p_a, p_c = profile
         emb, dec = model.embeds, model.decoder
-        d, H = emb.d, dec.attn.H
-        dpi, dhp, dpo = ops.padded_dims(d, H)
+        is_ca = isinstance(dec, CrossAttentionBlock)
+        d = emb.d
+        dpi, _, _ = ops.padded_dims(d, model._heads())
         B, L = p_x.shape
         # train.py:86-88 passes torch.split views: ids are copied (tiny), the dense attrs/ctx views are walked
         # in place by the kernels (CarcaRowSeg.attrs_bstride / CarcaWgradSeg.x_bstride)
         c_ = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
         segs = [(c_(p_x), p_a, p_c, False)] + [(c_(o_x), o_a, o_c, True) for (o_x, o_a, o_c) in targets]
         p_x = segs[0][0]
-        es, zq = emb.embed_segments(segs, ld_e=dpi)
+        es, emb_saved = emb.embed_segments(segs, ld_e=dpi)
         x = es[0]
         # one seed per forward; every dropout site hashes (seed, site id, element index)  (include/carca_hip.h)
         seed = ops.new_dropout_seed() if model.training else 0
@@ -80,20 +127,31 @@ class _CarcaFn(torch.autograd.Function):
             saved["p"] = bp
             blocks.append(saved)
             x = y
-        dec._check_mode()
-        groups = [(es[gi + 1], segs[gi + 1][0]) for gi in range(len(targets))]
-        cw = dec.weights_struct(x.device, model.norm)
-        dp_ = dec.drop_p()
-        ys, p_normed, csave = ops.cross_score_fwd(x, p_x, groups, cw, d, H, dec.residual, model.training, save=True,
-                                                  drop=(dp_, seed, 2000) if dp_ > 0 else None)
-        csave["p"] = dp_
+        st = dict(p_x=p_x, segs=segs, es=es, emb_saved=emb_saved, blocks=blocks, enc_out=x, training=model.training,
+                  B=B, L=L, m_embed=m_embed, p_emb=p_emb, dpi=dpi, is_ca=is_ca)
+        if is_ca:
+            dec._check_mode()
+            H = dec.attn.H
+            groups = [(es[gi + 1], segs[gi + 1][0]) for gi in range(len(targets))]
+            cw = dec.weights_struct(x.device, model.norm)
+            dp_ = dec.drop_p()
+            ys, p_normed, csave = ops.cross_score_fwd(x, p_x, groups, cw, d, H, dec.residual, model.training, save=True,
+                                                      drop=(dp_, seed, 2000) if dp_ > 0 else None)
+            csave["p"] = dp_
+            st.update(p_normed=p_normed, csave=csave, cw=cw)
+        else:  # dot decoders: stand-alone final LayerNorm (carca.py:421) + row dots (carca.py:352-399)
+            p_n = ops.layernorm_fwd(x.view(B * L, -1), model.norm.weight, model.norm.bias, d, dpi)
+            ys, dsave = dec.score_groups(p_n, [e.view(-1, dpi) for e in es[1:]], [e.shape[1] for e in es[1:]], B, L, d,
+                                         dpi)
+            csave = {}
+            st.update(dsave=dsave)
         if getattr(model, "_keep_dropout_masks", False):  # test hook: lets a test replay the reference with these masks
             model._last_dropout_masks = dict(embed=m_embed, blocks=[{k: v for k, v in b.items() if k.startswith("m_")}
                                                                     for b in blocks], cross=csave.get("m_attn"))
+        st["ngroups"] = len(ys)
         ctx.model = model
         ctx.params = params
-        ctx.st = dict(p_x=p_x, segs=segs, es=es, zq=zq, blocks=blocks, enc_out=x, p_normed=p_normed, csave=csave,
-                      training=model.training, cw=cw, B=B, L=L, ngroups=len(ys), m_embed=m_embed, p_emb=p_emb)
+        ctx.st = st
         ctx.save_for_backward(*ys)
         return tuple(ys)
 
@@ -101,9 +159,8 @@ class _CarcaFn(torch.autograd.Function):
     def backward(ctx, *dys):
         model, params, st = ctx.model, ctx.params, ctx.st
         emb, dec = model.embeds, model.decoder
-        d, H = emb.d, dec.attn.H
-        dpi, dhp, dpo = ops.padded_dims(d, H)
-        dh = d // H
+        d = emb.d
+        dpi = st["dpi"]
         B, L = st["B"], st["L"]
         p_x = st["p_x"]
         dev = p_x.device
@@ -111,46 +168,11 @@ class _CarcaFn(torch.autograd.Function):
         gbp = {id(p): g for p, g in zip(params, grads)}
         ys = ctx.saved_tensors
         ngroups = st["ngroups"]
-        g_feats = emb.feats_embed.weight.shape[0]
-        table = emb.attr_table()
-        n_attrs = table.shape[1] if table is not None else st["segs"][0][1].shape[-1]
-
-        # ---------------- decoder: sigmoid/ffn head + cross-attention (carca.py:340-347) ----------------
-        cp = _Packs(dec.attn, [], dev)
-        d_wpad = torch.zeros(dpo, dtype=torch.float32, device=dev)
-        bgroups = []
-        for gi in range(ngroups):
-            dy = dys[gi] if dys[gi] is not None else torch.zeros_like(ys[gi])
-            bgroups.append((st["csave"]["qh"][gi], ys[gi], dy.contiguous(), st["segs"][gi + 1][0]))
-        ffn_w_pad_ptr = st["cw"].ffn_w_pad
-        cpd = st["csave"]["p"]
-        dqhs, dls, dkh, dvh = ops.cross_attn_bwd(st["csave"]["kh"], st["csave"]["vh"], p_x, bgroups, ffn_w_pad_ptr,
-                                                 d_wpad, B, L, d, H, st["training"],
-                                                 masks=st["csave"].get("m_attn") if cpd > 0 else None,
-                                                 drop_scale=1.0 / (1.0 - cpd) if cpd > 0 else 1.0)
-        g_ffn_w, g_ffn_b = gbp[id(dec.ffn.weight)], gbp[id(dec.ffn.bias)]
-        o_rows = [st["es"][gi + 1].view(-1, dpi) for gi in range(ngroups)]
-        o_ids = [st["segs"][gi + 1][0] for gi in range(ngroups)]
-        for gi in range(ngroups):
-            ops.colsum(dls[gi].view(-1, 1), 1, g_ffn_b)                       # d ffn.bias = sum dlogit
-            if dec.residual:
-                ops.colsum(o_rows[gi], d, g_ffn_w, rowscale=dls[gi])          # residual part of d ffn.weight
-        wp_item = ops.PackedWeights([ops.PackItem(dec.ffn.weight, 1, dpo, col_heads=(dh, dhp))], dev)
-        wp_item.buf.copy_(d_wpad)                                             # attention part, head-padded
-        wp_item.unpack_into([g_ffn_w], accumulate=True)
-        # d o_g = dQ_g . W_Q (+ dlogit (x) w), masked like e * mask (carca.py:94)
-        wq_t, wk_t, wv_t = cp.wT.view(0), cp.wT.view(1), cp.wT.view(2)
-        ffn_w_plain = dec.ffn.weight.detach().reshape(-1)
-        des_t = ops.gemm_rows([dict(a0=dqhs[gi], rowscale=dls[gi] if dec.residual else None, ids=o_ids[gi])
-                               for gi in range(ngroups)], wq_t, d, dpo, dpi,
-                              colvec=ffn_w_plain if dec.residual else None, mask_rows=True)
-        ops.gemm_wgrad([dict(dy=dqhs[gi], x=o_rows[gi]) for gi in range(ngroups)], dpo, d, cp.g.view(0),
-                       cp.g.view(3).view(-1))
-        pn = st["p_normed"].view(-1, st["p_normed"].shape[-1])
-        ops.gemm_wgrad([dict(dy=dkh, x=pn)], dpo, d, cp.g.view(1), cp.g.view(4).view(-1))
-        ops.gemm_wgrad([dict(dy=dvh, x=pn)], dpo, d, cp.g.view(2), cp.g.view(5).view(-1))
-        _attn_param_grads(cp, dec.attn, gbp)
-        (dp,) = ops.gemm_rows([dict(a0=dkh, a1=dvh)], wk_t, d, dpo, dpi, bt1=wv_t, K1=dpo)
+        dys = [dys[gi].contiguous() if dys[gi] is not None else torch.zeros_like(ys[gi]) for gi in range(ngroups)]
+        if st["is_ca"]:
+            dp, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, dev)
+        else:
+            dp, des_t = dec.score_backward(dys, st["dsave"], B, L, d, dpi)
         # final LayerNorm (carca.py:421)
         enc_out = st["enc_out"].view(-1, dpi)
         dx = ops.layernorm_bwd(dp, enc_out, model.norm.weight.detach(), d, dpi, dgamma=gbp[id(model.norm.weight)],
@@ -158,6 +180,7 @@ class _CarcaFn(torch.autograd.Function):
 
         # ---------------- encoder blocks, last to first (carca.py:297-318) --------------------------------
         for blk, sv in zip(reversed(list(model.encoder)), reversed(st["blocks"])):
+            _, _, dpo = ops.padded_dims(d, blk.attn.H)
             extra = [ops.PackItem(blk.ffn_1.weight[:, :, 0], dpi, dpi, transposed=True),
                      ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi, dpi, transposed=True)]
             bp = _Packs(blk.attn, extra, dev)
@@ -191,40 +214,11 @@ class _CarcaFn(torch.autograd.Function):
             dx = ops.layernorm_bwd(dqn, x_in, blk.norm1.weight.detach(), d, dpi, addend=dx_kv,
                                    dgamma=gbp[id(blk.norm1.weight)], dbeta=gbp[id(blk.norm1.bias)])
 
-        # ---------------- embedding (carca.py:85-95) ---------------------------------------------------
+        # ---------------- embedding (carca.py:85-95 and its ablations) -------------------------------------
         if st["p_emb"] > 0:  # CARCA.dropout on the profile embedding (carca.py:416)
             dx = ops.mask_mul(dx, st["m_embed"], 1.0 / (1.0 - st["p_emb"]), d, dpi)
         des = [dx] + des_t                      # d e per segment, [rows, dpi]; profile rows still unmasked
-        ids_seg = [s[0] for s in st["segs"]]
-        nseg = len(des)
-        row0 = [0]
-        for s in st["segs"]:
-            row0.append(row0[-1] + s[0].numel())
-        zq = st["zq"]
-        zq_seg = [zq[row0[i]: row0[i + 1]] for i in range(nseg)]
-        # positional table (learnable encoding only; carca.py:25-31)
-        enc = emb.enc
-        if hasattr(enc, "encoding"):
-            ops.colsum(des[0], d, gbp[id(enc.encoding.weight)], ids=ids_seg[0], T=L)
-        g_joint_w, g_joint_b = gbp[id(emb.joint_embed.weight)], gbp[id(emb.joint_embed.bias)]
-        ops.gemm_wgrad([dict(dy=des[i], x=zq_seg[i], ids=ids_seg[i]) for i in range(nseg)], d, d + g_feats, g_joint_w,
-                       g_joint_b, mask_rows=True)
-        wj_t = ops.PackedWeights([ops.PackItem(emb.joint_embed.weight, d + g_feats, dpi, transposed=True)], dev)
-        wj_t.pack()
-        dzq = ops.gemm_rows([dict(a0=des[i], ids=ids_seg[i]) for i in range(nseg)], wj_t.view(0), d + g_feats, d,
-                            d + g_feats, mask_rows=True)
-        g_items = gbp[id(emb.items_embed.weight)]
-        for i in range(nseg):
-            ops.embed_scatter(dzq[i], ids_seg[i], d, float(d) ** 0.5, g_items)
-        g_feats_w, g_feats_b = gbp[id(emb.feats_embed.weight)], gbp[id(emb.feats_embed.bias)]
-        n_ctx = st["segs"][0][2].shape[-1]
-        # d feats_embed.weight = dq^T [attrs | ctx]: one launch, the ctx columns ride along as a second X source
-        def xsrc(i):  # dense attrs batch tensor, or the registered table gathered by id
-            a = st["segs"][i][1]
-            return dict(x=a) if a is not None else dict(x=table, x_gather=True, ids=ids_seg[i])
-
-        ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x1=st["segs"][i][2] if n_ctx else None, **xsrc(i))
-                        for i in range(nseg)], g_feats, n_attrs, g_feats_w, g_feats_b, K1=n_ctx)
+        emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi)
         ctx.st = None
         return (None, None, None) + tuple(grads)
 

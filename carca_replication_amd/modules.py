@@ -15,6 +15,8 @@ SelfAttentionBlock      carca.py:297-318      ops.sa_block_fwd     (csrc/sa_bloc
 CARCA.norm + CrossAttentionBlock carca.py:421,338-349  ops.cross_score_fwd (csrc/cross_score.hip)
 CARCA.forward           carca.py:411-431      CARCA.forward below: 1 pack + 3 embed + n_blocks + 1 launches
 BinaryCrossEntropy      carca.py:441-444      ops.bce_fwd          (csrc/loss_metrics.hip)
+AttrCtx/Attr/Id/MLPId embeddings carca.py:98-198   the same row GEMM with terms removed (ops.gemm_rows)
+DotProduct / WeightedDotProduct  carca.py:352-399  ops.dot_score_fwd (+ layernorm_fwd, slot_decay_scale, l2norm; csrc/decoders.hip)
 """
 from __future__ import annotations
 
@@ -137,6 +139,30 @@ class PositionalEncoding(Encoding):
 # ------------------------------------------------------------------------------------------------
 
 
+def _position_table(enc: Encoding, T: int) -> Optional[Tensor]:
+    if hasattr(enc, "position_table"):
+        return enc.position_table(T)
+    raise CarcaHipError(f"encoding {type(enc).__name__} has no position_table(); cannot be fused")
+
+
+def _segs_pos(enc: Encoding, segs) -> Optional[Tensor]:
+    """Position table [T, d] for the profile segment(s) of `segs`, or None (targets never get one, carca.py:91)."""
+    if any(not tgt for (_, _, _, tgt) in segs):
+        T = next(x.shape[1] for (x, _, _, tgt) in segs if not tgt)
+        return _position_table(enc, T)
+    return None
+
+
+def _pos_grad(enc: Encoding, de_profile: Tensor, ids: Tensor, d: int, L: int, gbp) -> None:
+    """d LearnableEncoding.encoding.weight[t] += sum over users of (d e * mask)[t]  (carca.py:25-31)."""
+    if hasattr(enc, "encoding"):
+        ops.colsum(de_profile, d, gbp[id(enc.encoding.weight)], ids=ids, T=L)
+
+
+def _rows(x: Tensor) -> int:
+    return x.numel()
+
+
 class AllEmbedding(Embedding):
     def __init__(self, n_items: int, d: int, g: int, n_ctx: int, n_attrs: int, enc: Encoding):
         super().__init__()
@@ -195,19 +221,50 @@ class AllEmbedding(Embedding):
         return wc, bias_c
 
     def _pos(self, T: int) -> Optional[Tensor]:
-        if hasattr(self.enc, "position_table"):
-            return self.enc.position_table(T)
-        raise CarcaHipError(f"encoding {type(self.enc).__name__} has no position_table(); cannot be fused")
+        return _position_table(self.enc, T)
 
     def embed_segments(self, segs, ld_e: int):
         """segs: [(x, a, c, is_target)] -> ([e [B,T,ld_e]], zq).  One fused call for all segments."""
-        pos = None
-        if any(not tgt for (_, _, _, tgt) in segs):
-            T = next(x.shape[1] for (x, _, _, tgt) in segs if not tgt)
-            pos = self._pos(T)
+        pos = _segs_pos(self.enc, segs)
         call = [(x, a, c, (not tgt) and pos is not None) for (x, a, c, tgt) in segs]
         return ops.embed_fwd(call, self.items_embed.weight, self.feats_embed.weight, self.feats_embed.bias,
                              self.joint_embed.weight, self.joint_embed.bias, pos, ld_e, attrs_table=self.attr_table())
+
+    def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int) -> None:
+        """Backward of embed_segments (carca.py:85-95): des[i] = d e of segment i, [rows, dpi], NOT yet masked;
+        accumulates into the gradient buffers gbp[id(param)]."""
+        d = self.d
+        dev = des[0].device
+        g_feats = self.feats_embed.weight.shape[0]
+        table = self.attr_table()
+        n_attrs = table.shape[1] if table is not None else segs[0][1].shape[-1]
+        ids_seg = [s[0] for s in segs]
+        nseg = len(des)
+        row0 = [0]
+        for sg in segs:
+            row0.append(row0[-1] + sg[0].numel())
+        zq_seg = [zq[row0[i]: row0[i + 1]] for i in range(nseg)]
+        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
+        g_joint_w, g_joint_b = gbp[id(self.joint_embed.weight)], gbp[id(self.joint_embed.bias)]
+        ops.gemm_wgrad([dict(dy=des[i], x=zq_seg[i], ids=ids_seg[i]) for i in range(nseg)], d, d + g_feats, g_joint_w,
+                       g_joint_b, mask_rows=True)
+        wj_t = ops.PackedWeights([ops.PackItem(self.joint_embed.weight, d + g_feats, dpi, transposed=True)], dev)
+        wj_t.pack()
+        dzq = ops.gemm_rows([dict(a0=des[i], ids=ids_seg[i]) for i in range(nseg)], wj_t.view(0), d + g_feats, d,
+                            d + g_feats, mask_rows=True)
+        g_items = gbp[id(self.items_embed.weight)]
+        for i in range(nseg):
+            ops.embed_scatter(dzq[i], ids_seg[i], d, float(d) ** 0.5, g_items)
+        g_feats_w, g_feats_b = gbp[id(self.feats_embed.weight)], gbp[id(self.feats_embed.bias)]
+        n_ctx = segs[0][2].shape[-1]
+
+        # d feats_embed.weight = dq^T [attrs | ctx]: one launch, the ctx columns ride along as a second X source
+        def xsrc(i):  # dense attrs batch tensor, or the registered table gathered by id
+            a = segs[i][1]
+            return dict(x=a) if a is not None else dict(x=table, x_gather=True, ids=ids_seg[i])
+
+        ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x1=segs[i][2] if n_ctx else None, **xsrc(i)) for i in range(nseg)],
+                       g_feats, n_attrs, g_feats_w, g_feats_b, K1=n_ctx)
 
     def forward(self, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
         """`mask` must be get_mask(x) (it always is in the reference, carca.py:413-426); the kernel uses x != 0."""
@@ -220,47 +277,89 @@ class AllEmbedding(Embedding):
 
 
 # ------------------------------------------------------------------------------------------------
-# ablation variants (carca.py:98-198, 352-395; knn.py) -- OUTSIDE the hot path.
-# They construct with the reference's signatures and state_dict so that scripts/training.py:66-100 imports and
-# builds them, but no HIP kernel is written for their forward: calling one raises, it never falls back to ATen.
+# ablation variants (carca.py:98-198, 352-399) -- SURVEY.md section 8 row f4.  Same constructors and state_dict as
+# the reference; the embeddings are AllEmbedding's row GEMM with terms removed, the decoders a row-dot epilogue of
+# the final LayerNorm.  Each class brings the two halves the engine calls:
+#   embeddings: embed_segments(segs, ld_e) -> (es, saved) and embed_backward(des, segs, saved, gbp, L, dpi)
+#   decoders:   score_groups(p, os, B, L, d, dpi) -> (ys, saved) and score_backward(dys, saved, ...) -> (dp, d os)
 # ------------------------------------------------------------------------------------------------
-def _not_built(name: str):
-    raise CarcaHipError(f"{name} is an ablation variant outside the accelerated CARCA path (AllEmbedding + "
-                        f"SelfAttentionBlock + CrossAttentionBlock: run scripts/training.py with "
-                        f"--embedding all --decoder ca); no HIP kernel is built for it and there is no CPU fallback")
+def _standalone_embed(module, x, a, c, target):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise CarcaHipError(f"training through a stand-alone {type(module).__name__} is not built; train through "
+                            f"CARCA.forward")
+    (e,), _ = module.embed_segments([(x, a, c, target)], ld_e=module.d)
+    return e
 
 
-class AttrCtxEmbedding(Embedding):
+class _FeatsEmbedding(Embedding):
+    """AttrCtxEmbedding / AttrEmbedding: e = (W_j (W_f [a(;c)] + b_f) + b_j (+pos)) * mask  (carca.py:112-121,141-150)."""
+    _use_ctx = True
+
+    def _build(self, d: int, g: int, n_in: int, enc: Encoding):
+        self.d, self.enc = d, enc
+        self.feats_embed = nn.Linear(in_features=n_in, out_features=g)
+        self.joint_embed = nn.Linear(in_features=g, out_features=d)
+        for m in (self.feats_embed, self.joint_embed):
+            nn.init.xavier_uniform_(m.weight)
+        for m in (self.feats_embed, self.joint_embed):
+            nn.init.zeros_(m.bias)
+
+    def _split(self, segs):
+        n_ctx = segs[0][2].shape[-1] if self._use_ctx else 0
+        n_attrs = self.feats_embed.in_features - n_ctx
+        return n_attrs, n_ctx
+
+    def embed_segments(self, segs, ld_e: int):
+        d, Wf, Wj = self.d, self.feats_embed.weight, self.joint_embed.weight
+        g = Wf.shape[0]
+        n_attrs, n_ctx = self._split(segs)
+        g_ld = (g + 3) // 4 * 4
+        pos = _segs_pos(self.enc, segs)
+        qs = ops.gemm_rows([dict(a0=a, a1=c if n_ctx else None) for (_, a, c, _) in segs], Wf[:, :n_attrs], g, n_attrs,
+                           g_ld, bt1=Wf[:, n_attrs:] if n_ctx else None, K1=n_ctx, bias=self.feats_embed.bias)
+        es = ops.gemm_rows([dict(a0=qs[i], ids=x, T=x.shape[1], add_pos=(not tgt) and pos is not None)
+                            for i, (x, _, _, tgt) in enumerate(segs)], Wj, d, g, ld_e, bias=self.joint_embed.bias,
+                           pos=pos, mask_rows=True)
+        return [e.view(x.shape[0], x.shape[1], ld_e) for e, (x, _, _, _) in zip(es, segs)], qs
+
+    def embed_backward(self, des, segs, qs, gbp, L: int, dpi: int) -> None:
+        d, Wf, Wj = self.d, self.feats_embed.weight, self.joint_embed.weight
+        g = Wf.shape[0]
+        n_attrs, n_ctx = self._split(segs)
+        ids_seg = [sg[0] for sg in segs]
+        nseg = len(des)
+        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
+        ops.gemm_wgrad([dict(dy=des[i], x=qs[i], ids=ids_seg[i]) for i in range(nseg)], d, g, gbp[id(Wj)],
+                       gbp[id(self.joint_embed.bias)], mask_rows=True)
+        wj_t = ops.PackedWeights([ops.PackItem(Wj, g, dpi, transposed=True)], des[0].device)
+        wj_t.pack()
+        dqs = ops.gemm_rows([dict(a0=des[i], ids=ids_seg[i]) for i in range(nseg)], wj_t.view(0), g, d, g,
+                            mask_rows=True)
+        ops.gemm_wgrad([dict(dy=dqs[i], x=segs[i][1], x1=segs[i][2] if n_ctx else None) for i in range(nseg)], g,
+                       n_attrs, gbp[id(Wf)], gbp[id(self.feats_embed.bias)], K1=n_ctx)
+
+    def forward(self, x, a, c, mask, target):
+        return _standalone_embed(self, x, a, c, target)
+
+
+class AttrCtxEmbedding(_FeatsEmbedding):
     def __init__(self, d: int, g: int, n_ctx: int, n_attrs: int, enc: Encoding):
         super().__init__()
-        self.d, self.enc = d, enc
-        self.feats_embed = nn.Linear(in_features=n_ctx + n_attrs, out_features=g)
-        self.joint_embed = nn.Linear(in_features=g, out_features=d)
-        for m in (self.feats_embed, self.joint_embed):
-            nn.init.xavier_uniform_(m.weight)
-        for m in (self.feats_embed, self.joint_embed):
-            nn.init.zeros_(m.bias)
-
-    def forward(self, x, a, c, mask, target):
-        _not_built("AttrCtxEmbedding")
+        self._build(d, g, n_ctx + n_attrs, enc)
 
 
-class AttrEmbedding(Embedding):
+class AttrEmbedding(_FeatsEmbedding):
+    _use_ctx = False
+
     def __init__(self, d: int, g: int, n_attrs: int, enc: Encoding):
         super().__init__()
-        self.d, self.enc = d, enc
-        self.feats_embed = nn.Linear(in_features=n_attrs, out_features=g)
-        self.joint_embed = nn.Linear(in_features=g, out_features=d)
-        for m in (self.feats_embed, self.joint_embed):
-            nn.init.xavier_uniform_(m.weight)
-        for m in (self.feats_embed, self.joint_embed):
-            nn.init.zeros_(m.bias)
-
-    def forward(self, x, a, c, mask, target):
-        _not_built("AttrEmbedding")
+        self._build(d, g, n_attrs, enc)
 
 
 class IdEmbedding(Embedding):
+    """e = (E[x] * sqrt(d) (+pos)) * mask  (carca.py:164-171): the gather rides a d x d row GEMM against sqrt(d) I, whose
+    single non-zero term per output reproduces the reference's one rounding exactly."""
+
     def __init__(self, n_items: int, d: int, enc: Encoding):
         super().__init__()
         self.d, self.enc = d, enc
@@ -269,11 +368,40 @@ class IdEmbedding(Embedding):
         with torch.no_grad():
             self.items_embed.weight[0].zero_()
 
+    def _scaled_identity(self, device) -> Tensor:
+        eye = self.__dict__.get("_eye")
+        if eye is None or eye.device != device:
+            eye = torch.eye(self.d, dtype=torch.float32, device=device) * (float(self.d) ** 0.5)
+            self.__dict__["_eye"] = eye
+        return eye
+
+    def __getstate__(self):
+        state = dict(super().__getstate__())
+        state.pop("_eye", None)
+        return state
+
+    def embed_segments(self, segs, ld_e: int):
+        d, E = self.d, self.items_embed.weight
+        pos = _segs_pos(self.enc, segs)
+        es = ops.gemm_rows([dict(a0=E, a0_gather=True, ids=x, T=x.shape[1], add_pos=(not tgt) and pos is not None)
+                            for (x, _, _, tgt) in segs], self._scaled_identity(E.device), d, d, ld_e, pos=pos,
+                           mask_rows=True)
+        return [e.view(x.shape[0], x.shape[1], ld_e) for e, (x, _, _, _) in zip(es, segs)], None
+
+    def embed_backward(self, des, segs, saved, gbp, L: int, dpi: int) -> None:
+        d = self.d
+        ids_seg = [sg[0] for sg in segs]
+        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
+        for i in range(len(des)):  # rows with id 0 are skipped: that is the e * mask of carca.py:170
+            ops.embed_scatter(des[i], ids_seg[i], d, float(d) ** 0.5, gbp[id(self.items_embed.weight)])
+
     def forward(self, x, a, c, mask, target):
-        _not_built("IdEmbedding")
+        return _standalone_embed(self, x, a, c, target)
 
 
 class MLPIdEmbedding(Embedding):
+    """e = (W (E[x] * sqrt(d)) + b (+pos)) * mask with a g-wide item table (carca.py:190-198)."""
+
     def __init__(self, n_items: int, d: int, g: int, enc: Encoding):
         super().__init__()
         self.d, self.enc = d, enc
@@ -285,28 +413,107 @@ class MLPIdEmbedding(Embedding):
         with torch.no_grad():
             self.items_embed.weight[0].zero_()
 
+    def embed_segments(self, segs, ld_e: int):
+        d, E, W = self.d, self.items_embed.weight, self.feats_embed.weight
+        g = E.shape[1]
+        pos = _segs_pos(self.enc, segs)
+        es = ops.gemm_rows([dict(a0=E, a0_gather=True, ids=x, T=x.shape[1], add_pos=(not tgt) and pos is not None)
+                            for (x, _, _, tgt) in segs], W, d, g, ld_e, bias=self.feats_embed.bias, pos=pos,
+                           mask_rows=True, alpha=float(d) ** 0.5)
+        return [e.view(x.shape[0], x.shape[1], ld_e) for e, (x, _, _, _) in zip(es, segs)], None
+
+    def embed_backward(self, des, segs, saved, gbp, L: int, dpi: int) -> None:
+        d, E, W = self.d, self.items_embed.weight, self.feats_embed.weight
+        g = E.shape[1]
+        sd = float(d) ** 0.5
+        ids_seg = [sg[0] for sg in segs]
+        nseg = len(des)
+        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
+        # d W = sqrt(d) (d e * mask)^T E[x]; the table rows are gathered inside the product
+        gw = torch.zeros_like(gbp[id(W)])
+        ops.gemm_wgrad([dict(dy=des[i], x=E.detach(), x_gather=True, ids=ids_seg[i]) for i in range(nseg)], d, g, gw,
+                       gbp[id(self.feats_embed.bias)], mask_rows=True)
+        gbp[id(W)].add_(gw, alpha=sd)
+        w_t = ops.PackedWeights([ops.PackItem(W, g, dpi, transposed=True)], des[0].device)
+        w_t.pack()
+        dzs = ops.gemm_rows([dict(a0=des[i], ids=ids_seg[i]) for i in range(nseg)], w_t.view(0), g, d, g,
+                            mask_rows=True)
+        for i in range(nseg):
+            ops.embed_scatter(dzs[i], ids_seg[i], g, sd, gbp[id(E)])
+
     def forward(self, x, a, c, mask, target):
-        _not_built("MLPIdEmbedding")
+        return _standalone_embed(self, x, a, c, target)
 
 
-class DotProduct(Decoder):
+class _DotDecoder(Decoder):
+    """Row-dot decoders over the final-normed profile (carca.py:352-399).  Neither looks at the masks."""
+
+    def _standalone(self, o, p):
+        if torch.is_grad_enabled() and (o.requires_grad or p.requires_grad):
+            raise CarcaHipError(f"training through a stand-alone {type(self).__name__} is not built; train through "
+                                f"CARCA.forward")
+        B, L, d = p.shape
+        ys, _ = self.score_groups(p.reshape(B * L, d), [o.reshape(-1, d)], [o.shape[1]], B, L, d, d)
+        return ys[0]
+
+
+class DotProduct(_DotDecoder):
     def __init__(self) -> None:
         super().__init__()
         self.sig = nn.Sigmoid()
 
+    def score_groups(self, p2d: Tensor, os2d: List[Tensor], Ts: List[int], B: int, L: int, d: int, dpi: int):
+        """y_g = sigmoid(p . o): slot t against target t in train mode, last slot against all in eval (carca.py:361-367)."""
+        slot = self.training
+        ys = [ops.dot_score_fwd(p2d, o, B, L, T, d, slot, 0) for o, T in zip(os2d, Ts)]
+        return ys, dict(p=p2d, os=os2d, Ts=Ts, ys=ys, slot=slot)
+
+    def score_backward(self, dys, sv, B: int, L: int, d: int, dpi: int):
+        dp = torch.zeros(B * L, dpi, dtype=torch.float32, device=sv["p"].device)
+        dos = [ops.dot_score_bwd(sv["p"], o, y, dy, dp, B, L, T, d, sv["slot"], 0, dpi)
+               for o, y, dy, T in zip(sv["os"], sv["ys"], dys, sv["Ts"])]
+        return dp, dos
+
     def forward(self, o, o_mask, p, p_mask):
-        _not_built("DotProduct")
+        return self._standalone(o, p)
 
 
-class WeightedDotProduct(Decoder):
+class WeightedDotProduct(_DotDecoder):
     def __init__(self, gamma: float, seq_len: int, normalize: bool, device: str):
         super().__init__()
         self.norm = normalize
+        self.gamma = float(gamma)
         self.W = (gamma ** torch.arange(0, seq_len, device=device).unsqueeze(0).repeat(seq_len, 1)).tril().unsqueeze(-1)
         self.sig = nn.Sigmoid()
 
+    def score_groups(self, p2d: Tensor, os2d: List[Tensor], Ts: List[int], B: int, L: int, d: int, dpi: int):
+        """p' = p[t] * sum_{j<=t} gamma^j (what the reference's repeat / tril / sum does, carca.py:385-386); optional L2
+        normalisation of p' and o; y = sigmoid(p' . o) or (p' . o + 1) / 2 (carca.py:388-397)."""
+        slot = self.training
+        ld = max(dpi, d)
+        pw = ops.slot_decay_scale(p2d, B, L, d, self.gamma, ld)
+        if self.norm:
+            pq = ops.l2norm_fwd(pw, d, ld)
+            oq = [ops.l2norm_fwd(o, d, ld) for o in os2d]
+        else:
+            pq, oq = pw, os2d
+        link = 1 if self.norm else 0
+        ys = [ops.dot_score_fwd(pq, o, B, L, T, d, slot, link) for o, T in zip(oq, Ts)]
+        return ys, dict(pw=pw, pq=pq, os=os2d, oq=oq, Ts=Ts, ys=ys, slot=slot, link=link)
+
+    def score_backward(self, dys, sv, B: int, L: int, d: int, dpi: int):
+        dpq = torch.zeros(B * L, dpi, dtype=torch.float32, device=sv["pq"].device)
+        doq = [ops.dot_score_bwd(sv["pq"], o, y, dy, dpq, B, L, T, d, sv["slot"], sv["link"], dpi)
+               for o, y, dy, T in zip(sv["oq"], sv["ys"], dys, sv["Ts"])]
+        if self.norm:
+            dpw = ops.l2norm_bwd(sv["pw"], dpq, d, dpi)
+            dos = [ops.l2norm_bwd(o, g, d, dpi) for o, g in zip(sv["os"], doq)]
+        else:
+            dpw, dos = dpq, doq
+        return ops.slot_decay_scale(dpw, B, L, d, self.gamma, dpi), dos  # the slot weights are diagonal: own transpose
+
     def forward(self, o, o_mask, p, p_mask):
-        _not_built("WeightedDotProduct")
+        return self._standalone(o, p)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -529,14 +736,25 @@ class CARCA(_PackedModule, Model):
         self.decoder = dec
 
     def _fusable(self) -> bool:
+        """The single-call inference path (carca_forward) covers AllEmbedding + SelfAttentionBlocks + CrossAttentionBlock."""
         return (isinstance(self.embeds, AllEmbedding) and isinstance(self.decoder, CrossAttentionBlock)
                 and all(isinstance(b, SelfAttentionBlock) for b in self.encoder))
 
+    def _check_built(self) -> None:
+        ok_emb = hasattr(self.embeds, "embed_segments")
+        ok_dec = isinstance(self.decoder, CrossAttentionBlock) or hasattr(self.decoder, "score_groups")
+        if not (ok_emb and ok_dec and all(isinstance(b, SelfAttentionBlock) for b in self.encoder)):
+            raise CarcaHipError("CARCA.forward is built for the reference's embeddings (All/AttrCtx/Attr/Id/MLPId), "
+                                "SelfAttentionBlock encoders and its decoders (CrossAttentionBlock/DotProduct/"
+                                "WeightedDotProduct); there is no ATen fallback for anything else")
+
+    def _heads(self) -> int:
+        if len(self.encoder):
+            return self.encoder[0].attn.H
+        return self.decoder.attn.H if isinstance(self.decoder, CrossAttentionBlock) else 1
+
     def forward(self, profile: Tuple[Tensor, Tensor, Tensor], targets: List[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
-        if not self._fusable():
-            raise CarcaHipError(
-                "only the AllEmbedding + SelfAttentionBlock + CrossAttentionBlock path is built in HIP "
-                "(SURVEY.md section 8: the other embeddings/decoders are ablations outside the hot path)")
+        self._check_built()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if needs_grad:
             from .autograd import carca_forward_with_grad
@@ -544,8 +762,11 @@ class CARCA(_PackedModule, Model):
             ys = carca_forward_with_grad(self, profile, targets)
         else:
             ys = self.forward_nograd(profile, targets)
-        # each group's scores are squeezed the way CrossAttentionBlock does (carca.py:346), then joined (carca.py:431)
-        return torch.cat([y.squeeze() for y in ys], dim=-1)
+        # each group's scores are squeezed the way CrossAttentionBlock does (carca.py:346), then joined (carca.py:431);
+        # the dot decoders return [B, T] unsqueezed (carca.py:361-367)
+        if isinstance(self.decoder, CrossAttentionBlock):
+            ys = [y.squeeze() for y in ys]
+        return torch.cat(ys, dim=-1)
 
     def fold_embedding(self, on: bool = True) -> "CARCA":
         """Opt-in inference shortcut: compose AllEmbedding's two Linear layers into one (include/carca_hip.h,
@@ -555,7 +776,7 @@ class CARCA(_PackedModule, Model):
 
     # ---- inference: one host call per forward (include/carca_hip.h: carca_forward) -----------------------------
     def _fused_ok(self, trace) -> bool:
-        if trace is not None or len(self.encoder) > _lib.MAX_BLOCKS:
+        if trace is not None or len(self.encoder) > _lib.MAX_BLOCKS or not self._fusable():
             return False
         if self.training and (self.dropout.p > 0 or self.decoder.drop_p() > 0 or
                               any(b.drop_p() > 0 for b in self.encoder)):
@@ -654,7 +875,7 @@ class CARCA(_PackedModule, Model):
         if self._fused_ok(trace):
             return self._forward_fused(profile, targets, events=ops.fused_events())
         d = self.embeds.d
-        H = self.decoder.attn.H
+        H = self._heads()
         dpi, _, _ = ops.padded_dims(d, H)
         segs = [(p_x, p_a, p_c, False)] + [(o_x, o_a, o_c, True) for (o_x, o_a, o_c) in targets]
         es, _ = self.embeds.embed_segments(segs, ld_e=dpi)
@@ -673,7 +894,17 @@ class CARCA(_PackedModule, Model):
                                  drop=(bp, seed, 4 * i) if bp > 0 else None)
             if trace is not None:
                 trace[f"block{i}"] = x[..., :d]
+        if not isinstance(self.decoder, CrossAttentionBlock):
+            # dot decoders: stand-alone final LayerNorm (carca.py:421), then a row dot per target (carca.py:352-399)
+            B, L = p_x.shape
+            p_n = ops.layernorm_fwd(x.view(B * L, -1), self.norm.weight, self.norm.bias, d, dpi)
+            if trace is not None:
+                trace["p_final"] = p_n.view(B, L, dpi)[..., :d]
+            ys, _ = self.decoder.score_groups(p_n, [e.view(-1, dpi) for e in es[1:]], [e.shape[1] for e in es[1:]], B, L,
+                                              d, dpi)
+            return ys
         self.decoder._check_mode()
+        H = self.decoder.attn.H
         groups = [(es[gi + 1], targets[gi][0]) for gi in range(len(targets))]
         dp = self.decoder.drop_p()
         if dp > 0:

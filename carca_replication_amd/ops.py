@@ -430,6 +430,8 @@ def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[
 
     segs: list of dicts with keys a0 [rows, lda0] and optionally a1, ids, add, gate, rowscale, T, add_pos, out.
     All 2-D operands are row-major views whose LAST stride is 1; their row stride is taken from .stride(0).
+    a0 / a1 may also be [B, T, K] views whose users are strided (o_a[:, :L] of train.py:86-88): walked in place.
+    a0_gather=True: a0 is a TABLE [n, lda0] and row r reads a0[ids[r]] (then `rows` must be given by ids).
     Returns the output tensors [rows, out_ld] (allocated here unless the segment brings 'out').
     """
     lib = _lib.load()
@@ -445,21 +447,33 @@ def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[
         _need_cuda(t)
         return t.stride(0)
 
+    def operand(t, name):  # -> (tensor, row stride, rows, T or None, user stride)
+        if t.dim() == 3:
+            _need_cuda(t)
+            t, bs = _btk_view(t)
+            keep.append(t)
+            return t, t.shape[2], t.shape[0] * t.shape[1], t.shape[1], bs
+        return t, ld_of(t, name), t.shape[0], None, 0
+
     lda0 = lda1 = ld_add = ld_gate = None
     for i, sg in enumerate(segs):
-        a0 = sg["a0"]
-        rows = a0.shape[0]
         S = D.seg[i]
-        l0 = ld_of(a0, "a0")
+        a0, l0, rows, T3, bs0 = operand(sg["a0"], "a0")
+        if sg.get("a0_gather"):
+            rows = sg["ids"].numel()
+            S.a0_gather = max(1, int(a0.shape[0]))
         lda0 = l0 if lda0 is None else lda0
         if l0 != lda0:
             raise CarcaHipError("gemm_rows: all segments must share lda0")
-        S.a0 = a0.data_ptr()
+        S.a0, S.a0_bstride = a0.data_ptr(), bs0
         a1 = sg.get("a1")
         if K1:
-            l1 = ld_of(a1, "a1")
+            a1, l1, rows1, T31, bs1 = operand(a1, "a1")
+            if rows1 != rows:
+                raise CarcaHipError("gemm_rows: a0 and a1 row counts differ")
+            T3 = T3 if T3 is not None else T31
             lda1 = l1 if lda1 is None else lda1
-            S.a1 = a1.data_ptr()
+            S.a1, S.a1_bstride = a1.data_ptr(), bs1
         out = sg.get("out")
         if out is None:
             out = torch.empty(rows, out_ld, dtype=torch.float32, device=a0.device)
@@ -485,7 +499,7 @@ def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[
             rs = _f32(rs.reshape(-1))
             keep.append(rs)
             S.rowscale = rs.data_ptr()
-        S.rows, S.T, S.add_pos = rows, int(sg.get("T", 1)), int(bool(sg.get("add_pos", False)))
+        S.rows, S.T, S.add_pos = rows, int(sg.get("T", T3 or 1)), int(bool(sg.get("add_pos", False)))
     D.lda0, D.lda1, D.K0, D.K1 = lda0, lda1 or 0, K0, K1
     D.bt0, D.ldb0 = bt0.data_ptr(), ld_of(bt0, "bt0")
     if K1:

@@ -16,16 +16,25 @@ def build_model(cfg, n_items, g, n_ctx, n_attrs, L, p=0.0):
         enc = M.PositionalEncoding(d, L)
     else:
         raise ValueError(enc_name)
-    emb = M.AllEmbedding(n_items, d, g, n_ctx, n_attrs, enc)
+    kind = str(cfg.get("embedding", "all"))  # the factories of scripts/training.py:76-100
+    emb = {"all": lambda: M.AllEmbedding(n_items, d, g, n_ctx, n_attrs, enc),
+           "attrctx": lambda: M.AttrCtxEmbedding(d, g, n_ctx, n_attrs, enc),
+           "attr": lambda: M.AttrEmbedding(d, g, n_attrs, enc),
+           "id": lambda: M.IdEmbedding(n_items, d, enc),
+           "mlpid": lambda: M.MLPIdEmbedding(n_items, d, g, enc)}[kind]()
     blocks = torch.nn.ModuleList([M.SelfAttentionBlock(d, H, p, bool(cfg.get("residual_sa", True)))
                                   for _ in range(int(cfg["n_blocks"]))])
-    dec = M.CrossAttentionBlock(d, H, p, bool(cfg.get("residual_ca", True)))
+    dk = str(cfg.get("decoder", "ca"))
+    dec = {"ca": lambda: M.CrossAttentionBlock(d, H, p, bool(cfg.get("residual_ca", True))),
+           "dot": lambda: M.DotProduct(),
+           "wdot": lambda: M.WeightedDotProduct(float(cfg.get("gamma", 0.9)), L, bool(cfg.get("l2_norm", False)),
+                                                "cpu")}[dk]()
     return M.CARCA(d=d, p=p, emb=emb, enc=blocks, dec=dec)
 
 
 def model_from_fixture(fx, device="cuda"):
     dm = fx.dim
-    g = int(fx.params["embeds.feats_embed.weight"].shape[0])
+    g = int(fx.cfg["g"]) if "g" in fx.cfg else int(fx.params["embeds.feats_embed.weight"].shape[0])
     model = build_model(fx.cfg, int(dm["n_items"]), g, int(dm["n_ctx"]), int(dm["n_attrs"]), int(dm["L"]))
     missing, unexpected = model.load_state_dict(fx.params, strict=True)
     assert not missing and not unexpected

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import carca_oracle as O
-from tests.golden_util import G1_NAMES, G7_NAMES, load
+from tests.golden_util import G1_NAMES, G7_NAMES, G9_NAMES, load
 from tests.model_util import dev, model_from_fixture, model_from_params
 
 pytestmark = pytest.mark.gpu
@@ -65,6 +65,30 @@ def test_g7_variant_gradients(name):
     fx = load("g7_" + name)
     model = model_from_fixture(fx)
     _step(model, fx, "train/")
+    _check_grads(model, {k[len("train/grad/"):]: v for k, v in fx.outs.items() if k.startswith("train/grad/")})
+
+
+@pytest.mark.parametrize("name", G9_NAMES)
+def test_g9_ablation_variants_forward_and_gradients(name):
+    """The reference's other embeddings / decoders (carca.py:98-198,352-399) on the HIP path:
+    eval scores, train-mode scores, loss and every parameter gradient against the fixtures made from the reference."""
+    from carca_replication_amd import modules as M
+
+    fx = load("g9_" + name)
+    model = model_from_fixture(fx)
+    model.eval()
+    with torch.no_grad():
+        y = model(profile=tuple(fx.ins[k].cuda() for k in ("p_x", "p_a", "p_c")),
+                  targets=[tuple(fx.ins[k].cuda() for k in ("o_x", "o_a", "o_c"))])
+    assert y.shape == fx.outs["y"].shape
+    assert float((y.cpu() - fx.outs["y"]).abs().max()) < 2e-5
+    loss = M.BinaryCrossEntropy()(y, fx.ins["y_true"].cuda(), M.get_mask(fx.ins["o_x"].cuda()))
+    ref = float(fx.outs["loss"])
+    assert abs(float(loss) - ref) < 2e-5 * max(1.0, abs(ref))
+    y, loss = _step(model, fx, "train/")
+    assert float((y.detach().cpu() - fx.outs["train/y"]).abs().max()) < 2e-5
+    ref = float(fx.outs["train/loss"])
+    assert abs(float(loss) - ref) < 2e-5 * max(1.0, abs(ref))
     _check_grads(model, {k[len("train/grad/"):]: v for k, v in fx.outs.items() if k.startswith("train/grad/")})
 
 

@@ -82,7 +82,9 @@ def test_compute_hr_ndcg_match_reference_fixture():
     assert compute_HR(scores[:, perm], y_true[:, perm], 10) == float(fx.outs["hr10"])
 
 
-def test_ablation_variants_construct_but_refuse_to_run():
+def test_ablation_variants_construct_and_refuse_cpu_tensors():
+    """Same constructors / state_dict as the reference (training.py:76-100); like every module here they have no CPU
+    path: CPU tensors raise instead of falling back."""
     from carca_replication_amd import CarcaHipError
     from src.carca import AttrCtxEmbedding, DotProduct, IdEmbedding, IdentityEncoding, MLPIdEmbedding
 
@@ -93,4 +95,42 @@ def test_ablation_variants_construct_but_refuse_to_run():
     assert set(MLPIdEmbedding(10, 8, 4, IdentityEncoding()).state_dict()) == {
         "items_embed.weight", "feats_embed.weight", "feats_embed.bias"}
     with pytest.raises(CarcaHipError):
-        DotProduct()(None, None, None, None)
+        DotProduct().eval()(torch.zeros(2, 3, 8), None, torch.zeros(2, 4, 8), None)
+    with pytest.raises(CarcaHipError):
+        e(torch.ones(2, 3, dtype=torch.int32), None, None, None, True)
+
+
+def test_cli_default_model_trains_with_dropout():
+    """scripts/training.py's defaults (training.py:37-58): --embedding all --decoder dot, d 64, g 256, 2 heads, 3 blocks,
+    dropout 0.5.  One train step through the HIP path: finite loss, a gradient for every parameter, and the same
+    seed gives the same step."""
+    from src.carca import CARCA, AllEmbedding, BinaryCrossEntropy, DotProduct, IdentityEncoding, SelfAttentionBlock
+    from src.utils import get_mask
+
+    torch.manual_seed(0)
+    n_items, n_attrs, n_ctx, L, B = 200, 24, 4, 50, 6
+    emb = AllEmbedding(n_items, 64, 256, n_ctx, n_attrs, IdentityEncoding())
+    blocks = torch.nn.ModuleList([SelfAttentionBlock(64, 2, 0.5, True) for _ in range(3)])
+    model = CARCA(d=64, p=0.5, emb=emb, enc=blocks, dec=DotProduct()).to("cuda").train()
+    g = torch.Generator().manual_seed(1)
+    p_x = torch.randint(1, n_items, (B, L), generator=g).int()
+    p_x[:, :7] = 0
+    o_x = torch.cat([torch.randint(1, n_items, (B, L), generator=g).int() * (p_x != 0),
+                     torch.randint(1, n_items, (B, L), generator=g).int() * (p_x != 0)], 1)
+    attrs = torch.rand(n_items, n_attrs, generator=g)
+    mk = lambda ids: (ids.cuda(), attrs[ids.long()].cuda(), torch.rand(*ids.shape, n_ctx, generator=g).cuda())  # noqa: E731
+    profile, pos, neg = mk(p_x), mk(o_x[:, :L]), mk(o_x[:, L:])
+    y_true = torch.cat([(p_x != 0).int(), torch.zeros(B, L, dtype=torch.int32)], 1).cuda()
+    losses = []
+    for _ in range(2):
+        torch.manual_seed(123)
+        model.zero_grad()
+        y = model(profile=profile, targets=[pos, neg])
+        assert y.shape == (B, 2 * L)
+        loss = BinaryCrossEntropy()(y, y_true, get_mask(o_x.cuda()))
+        loss.backward()
+        losses.append(float(loss))
+    assert losses[0] == losses[1] and losses[0] == losses[0] and losses[0] < 100
+    for name, prm in model.named_parameters():
+        assert prm.grad is not None and bool(torch.isfinite(prm.grad).all()), name
+    assert float(emb.feats_embed.weight.grad.abs().max()) > 0
