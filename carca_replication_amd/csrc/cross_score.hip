@@ -31,7 +31,12 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
                                                                const GroupsDev groups, int ldo, int L, int d, int dh,
                                                                const CarcaCaWeights w, int residual, int training,
                                                                const CarcaCaSave sv_in, const DropCfg dc,
-                                                               unsigned site, int nparts) {
+                                                               unsigned site, int nparts, unsigned long long* stamps) {
+#define CA_STAMP(i)                                                                                \
+  do {                                                                                             \
+    if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+  CA_STAMP(0);
   using G = AttGeom<DPI, DHP, NH>;
   constexpr int NW = 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
     *reinterpret_cast<f32x4*>(Ps + r * G::SI + 4 * c4) = v;
   }
   __syncthreads();
+  CA_STAMP(1);
   if (w.ln_w || p_normed) {
     for (int r = wave; r < L; r += NW) {
       float v0 = lane < d ? Ps[r * G::SI + lane] : 0.f;
@@ -90,6 +96,7 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
     }
     __syncthreads();
   }
+  CA_STAMP(2);
   // ---- B: K and V^T ---------------------------------------------------------------------------------------
   {
     const int nk = G::NF * LT;
@@ -106,6 +113,7 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
     }
   }
   __syncthreads();
+  CA_STAMP(3);
 
   // ---- C: rounds of CROSS_TPR target tiles; job = (tile, head) -----------------------------------------------
   const float sqrt_dh = sqrtf((float)dh);
@@ -183,6 +191,8 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
     }
     __syncthreads();
   }
+  CA_STAMP(4);
+#undef CA_STAMP
 }
 
 template <int DPI, int DHP, int NH>
@@ -211,7 +221,7 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
   const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);  // 1 = one workgroup per user, 2 = always two
   const int nparts = (groups.tile_start[groups.n] > 1 && tune != 1 && (tune == 2 || 2 * B <= num_cus)) ? 2 : 1;
   hipLaunchKernelGGL(kern, dim3(B * nparts), dim3(1024), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L,
-                     d, d / NH, w, residual, training, sv, dc, site, nparts);
+                     d, d / NH, w, residual, training, sv, dc, site, nparts, carca_debug_buffer());
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
