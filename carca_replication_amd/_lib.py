@@ -18,7 +18,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libcarca_hip.so")
 _STAMP = LIB_PATH + ".srchash"
-SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "decoders.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip"]
+SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip"]
 HEADERS = ["carca_common.h", "attn_common.h"]
 
 MAX_SEGS = 4
@@ -218,6 +218,10 @@ SIGNATURES = {
     "carca_slot_decay_scale": (_i, [_fp, _i, _fp, _i, _i, _i, _i, _f, _fp]),
     "carca_l2norm_fwd": (_i, [_fp, _i, _fp, _i, _i, _i, _fp]),
     "carca_l2norm_bwd": (_i, [_fp, _i, _fp, _i, _fp, _i, _i, _i, _fp]),
+    "carca_build_eval_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,
+                                    _fp]),
+    "carca_build_train_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,
+                                     _fp]),
 }
 
 

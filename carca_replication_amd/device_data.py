@@ -1,0 +1,105 @@
+"""Batch construction on the device (reference: src/data.py:53-192).
+
+`DeviceInteractions` keeps the interaction log in HBM (CSR over users: item ids + the context row of every
+interaction) and builds whole evaluation / training batches with one kernel launch each
+(csrc/batch_build.hip: leave-one-out windows, left padding, negative sampling, context assignment).  Batches are
+ids + context only; pair it with `AllEmbedding.register_attr_table(load_attrs(...))` so that the model gathers the
+attribute rows itself.  The deterministic parts equal `data.get_train_sequences / get_test_sequences` (and so the
+reference, fixture G5) exactly; the negatives have the reference's distribution but come from a counter-based hash,
+reproducible per seed.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib, ops
+from ._lib import CarcaHipError
+
+_MODES = ("train", "val", "test")
+
+
+def split_constants(mode: str, test: bool) -> Tuple[int, int]:
+    """(held_out, floor) of pad_profile for a split (data.py:53-74)."""
+    if mode not in _MODES:
+        raise ValueError(f"Invalid mode: {mode}")
+    held_out = {"train": 2 if test else 1, "val": 1 if test else 0, "test": 0}[mode]
+    return held_out, _MODES.index(mode) + 1
+
+
+class DeviceInteractions:
+    def __init__(self, profiles: Dict[int, Sequence[int]], ctx: Dict[Tuple[int, int], np.ndarray], n_items: int,
+                 device: str = "cuda"):
+        """profiles / ctx exactly as data.load_profiles / data.load_ctx return them; n_items = attrs.shape[0] (pad row
+        included), the exclusive upper bound of the negatives (data.py:83)."""
+        self.user_ids = list(profiles.keys())
+        lens = np.array([len(profiles[u]) for u in self.user_ids], dtype=np.int64)
+        offs = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        hist = np.zeros(int(offs[-1]), dtype=np.int32)
+        n_ctx = int(next(iter(ctx.values())).shape[0]) if ctx else 0
+        hctx = np.zeros((int(offs[-1]), n_ctx), dtype=np.float32)
+        for i, u in enumerate(self.user_ids):
+            items = profiles[u]
+            hist[offs[i]: offs[i + 1]] = items
+            for j, it in enumerate(items):
+                if n_ctx:
+                    hctx[offs[i] + j] = ctx[(u, int(it))]
+        self.lens = lens
+        self.n_items, self.n_ctx = int(n_items), n_ctx
+        self.max_len = int(lens.max()) if len(lens) else 0
+        self.hist = torch.from_numpy(hist).to(device)
+        self.offs = torch.from_numpy(offs).to(device)
+        self.hctx = torch.from_numpy(hctx).to(device)
+        self.device = self.hist.device
+
+    def valid_users(self, mode: str, test: bool = True) -> Tensor:
+        """Indices (into this log) of the users that have a window in the split (CARCADataset.valid_user_ids)."""
+        _, floor = split_constants(mode, test)
+        return torch.from_numpy(np.nonzero(self.lens > floor)[0].astype(np.int32)).to(self.device)
+
+    def _check(self, users: Tensor, n_neg: int) -> Tensor:
+        if users.device != self.device:
+            raise CarcaHipError("user indices must live on the interaction log's device")
+        if self.n_items - 1 - self.max_len < n_neg:
+            raise CarcaHipError(f"cannot draw {n_neg} distinct negatives outside a history of up to {self.max_len} items "
+                                f"from {self.n_items - 1} ids")
+        return users.to(torch.int32).contiguous()
+
+    def eval_batch(self, users: Tensor, L: int, N: int, mode: str, test: bool = True, seed: int = 0):
+        """-> (p_x [B,L] i32, p_c [B,L,n_ctx], o_x [B,1+N] i32, o_c [B,1+N,n_ctx], y_true [B,1+N] i32)."""
+        lib = _lib.load()
+        users = self._check(users, N)
+        B, nc, dev = users.numel(), self.n_ctx, self.device
+        held_out, floor = split_constants(mode, test)
+        p_x = torch.empty(B, L, dtype=torch.int32, device=dev)
+        p_c = torch.empty(B, L, nc, dtype=torch.float32, device=dev)
+        o_x = torch.empty(B, 1 + N, dtype=torch.int32, device=dev)
+        o_c = torch.empty(B, 1 + N, nc, dtype=torch.float32, device=dev)
+        y = torch.empty(B, 1 + N, dtype=torch.int32, device=dev)
+        _lib.check(lib.carca_build_eval_batch(self.hist.data_ptr(), self.offs.data_ptr(), self.hctx.data_ptr(),
+                                              users.data_ptr(), B, L, N, nc, self.n_items, held_out, floor,
+                                              int(seed) & (2 ** 64 - 1), p_x.data_ptr(), p_c.data_ptr(), o_x.data_ptr(),
+                                              o_c.data_ptr(), y.data_ptr(), ops._stream()), "build_eval_batch")
+        return p_x, p_c, o_x, o_c, y
+
+    def train_batch(self, users: Tensor, L: int, test: bool = True, seed: int = 0):
+        """-> (p_x [B,L], p_c [B,L,n_ctx], o_x [B,2L] = positives | negatives, o_c [B,2L,n_ctx], y_true [B,2L])."""
+        lib = _lib.load()
+        users = self._check(users, L)
+        B, nc, dev = users.numel(), self.n_ctx, self.device
+        held_out, floor = split_constants("train", test)
+        p_x = torch.empty(B, L, dtype=torch.int32, device=dev)
+        p_c = torch.empty(B, L, nc, dtype=torch.float32, device=dev)
+        o_x = torch.empty(B, 2 * L, dtype=torch.int32, device=dev)
+        o_c = torch.empty(B, 2 * L, nc, dtype=torch.float32, device=dev)
+        y = torch.empty(B, 2 * L, dtype=torch.int32, device=dev)
+        _lib.check(lib.carca_build_train_batch(self.hist.data_ptr(), self.offs.data_ptr(), self.hctx.data_ptr(),
+                                               users.data_ptr(), B, L, nc, self.n_items, held_out, floor,
+                                               int(seed) & (2 ** 64 - 1), p_x.data_ptr(), p_c.data_ptr(),
+                                               o_x.data_ptr(), o_c.data_ptr(), y.data_ptr(), ops._stream()),
+                   "build_train_batch")
+        return p_x, p_c, o_x, o_c, y

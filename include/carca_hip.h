@@ -311,6 +311,26 @@ int carca_l2norm_bwd(const float* x, int ldx, const float* dy, int ld_dy, float*
  * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
 int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);
 
+/* ---- f1: batch construction on the device (data.py:53-192) ---------------------------------------------------
+ * The interaction log lives in HBM as CSR: user u owns hist[offs[u] .. offs[u+1]) (item ids in interaction order) and
+ * the context rows hctx[offs[u] ..] of those interactions (hctx[pos] = ctx[(user, hist[pos])], data.py:17-25).
+ * `users` selects the batch; held_out / floor_ are pad_profile's split constants (data.py:53-74):
+ *   train: held_out = 2 if a test split exists else 1, floor_ = 1;  val: 1 or 0, floor_ = 2;  test: 0, floor_ = 3.
+ * Negatives are distinct ids in [1, n_items-1] outside the user's whole history (data.py:77-87), drawn by rejection
+ * from a counter-based hash of (seed, user, attempt): reproducible per seed, not python's `random` stream.
+ * carca_build_eval_batch = get_test_sequences (data.py:140-192): p_x [B,L] left-padded history, p_c [B,L,n_ctx],
+ *   o_x [B,1+N] = held-out item then N negatives, o_c [B,1+N,n_ctx] = the held-out interaction's context for every
+ *   candidate, y_true [B,1+N] = one-hot at column 0.  N <= 2048.
+ * carca_build_train_batch = get_train_sequences (data.py:90-137): o_x [B,2L] = successors | negatives aligned with the
+ *   history slots, o_c [B,2L,n_ctx] = the successor's context for both, y_true [B,2L] = (p_x > 0) | 0.
+ * Attribute rows are NOT materialised: AllEmbedding.register_attr_table gathers them inside the feature GEMM. */
+int carca_build_eval_batch(const int32_t* hist, const int64_t* offs, const float* hctx, const int32_t* users, int B, int L,
+                           int N, int n_ctx, int n_items, int held_out, int floor_, uint64_t seed, int32_t* p_x,
+                           float* p_c, int32_t* o_x, float* o_c, int32_t* y_true, void* stream);
+int carca_build_train_batch(const int32_t* hist, const int64_t* offs, const float* hctx, const int32_t* users, int B,
+                            int L, int n_ctx, int n_items, int held_out, int floor_, uint64_t seed, int32_t* p_x,
+                            float* p_c, int32_t* o_x, float* o_c, int32_t* y_true, void* stream);
+
 /* ---- a7: CARCA.forward (carca.py:411-431), inference path, as ONE host call -----------------------------
  * Issues the whole launch sequence -- gather, feature GEMM, joint GEMM, every SelfAttentionBlock, final norm +
  * grouped cross-attention scoring -- on `stream` without returning to the caller in between, so that a slow

@@ -1,0 +1,137 @@
+"""f1: batches built on the device (csrc/batch_build.hip) against the host pipeline of
+carca_replication_amd/data.py -- which tests/test_data_host.py pins to the reference's outputs (fixture G5).
+
+Integer / index work: the deterministic parts (windows, padding, positives, contexts, labels) must be EXACTLY those of
+get_train_sequences / get_test_sequences; the negatives are checked through the properties the reference guarantees
+(data.py:77-87: distinct, inside [1, n_items-1], outside the user's whole history) plus seeding and uniformity.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _log(n_users=37, n_items=90, n_ctx=3, seed=0):
+    rng = np.random.default_rng(seed)
+    profiles, ctx = {}, {}
+    for u in range(n_users):
+        n = int(rng.integers(1, 30)) if u > 3 else u + 1  # users 0..3: the shortest histories (1..4 interactions)
+        items = [int(v) for v in rng.integers(1, n_items, size=n)]
+        profiles[100 + u] = items
+        for it in set(items):
+            ctx[(100 + u, it)] = rng.random(n_ctx, dtype=np.float32)
+    attrs = rng.random((n_items, 5), dtype=np.float32)
+    attrs[0] = 0
+    return profiles, ctx, attrs
+
+
+@pytest.mark.parametrize("mode,test", [("val", True), ("test", True), ("val", False), ("test", False)])
+def test_eval_batches_match_host_pipeline(mode, test):
+    from carca_replication_amd import data as D
+    from carca_replication_amd.device_data import DeviceInteractions
+
+    profiles, ctx, attrs = _log()
+    L, N = 6, 20
+    log = DeviceInteractions(profiles, ctx, attrs.shape[0])
+    users = log.valid_users(mode, test)
+    want_users = [u for u, p in profiles.items() if len(D.pad_profile(p, L, mode, test)) > 0]
+    assert [log.user_ids[i] for i in users.cpu().tolist()] == want_users
+    p_x, p_c, o_x, o_c, y = (t.cpu() for t in log.eval_batch(users, L, N, mode, test, seed=7))
+    for b, uid in enumerate(want_users):
+        random.seed(b)
+        hp_x, hp_c, ho_x, ho_c, hy = D.get_test_sequences(uid, profiles[uid], L, N, attrs, ctx, mode, test,
+                                                          with_attrs=False)
+        assert np.array_equal(p_x[b].numpy(), hp_x) and np.array_equal(p_c[b].numpy(), hp_c)
+        assert int(o_x[b, 0]) == int(ho_x[0])                       # the held-out item
+        assert np.array_equal(o_c[b].numpy(), ho_c)                 # its context on every candidate
+        assert np.array_equal(y[b].numpy(), hy)
+        neg = o_x[b, 1:].numpy()
+        assert len(set(neg.tolist())) == N and neg.min() >= 1 and neg.max() <= attrs.shape[0] - 1
+        assert not (set(neg.tolist()) & set(profiles[uid]))
+
+
+@pytest.mark.parametrize("test", [True, False])
+def test_train_batches_match_host_pipeline(test):
+    from carca_replication_amd import data as D
+    from carca_replication_amd.device_data import DeviceInteractions
+
+    profiles, ctx, attrs = _log(seed=1)
+    L = 8
+    log = DeviceInteractions(profiles, ctx, attrs.shape[0])
+    users = log.valid_users("train", test)
+    uids = [log.user_ids[i] for i in users.cpu().tolist()]
+    assert uids == [u for u, p in profiles.items() if len(D.pad_profile(p, L, "train", test)) > 0]
+    p_x, p_c, o_x, o_c, y = (t.cpu() for t in log.train_batch(users, L, test, seed=3))
+    for b, uid in enumerate(uids):
+        random.seed(b)
+        hp_x, hp_c, ho_x, ho_c, hy = D.get_train_sequences(uid, profiles[uid], L, attrs, ctx, test, with_attrs=False)
+        assert np.array_equal(p_x[b].numpy(), hp_x) and np.array_equal(p_c[b].numpy(), hp_c)
+        assert np.array_equal(o_x[b, :L].numpy(), ho_x[:L])         # positives: the successors
+        assert np.array_equal(o_c[b].numpy(), ho_c)                 # negatives carry the positive's context
+        assert np.array_equal(y[b].numpy(), hy)
+        on = hp_x > 0
+        neg = o_x[b, L:].numpy()
+        assert np.array_equal(neg == 0, ~on)                        # negatives aligned with the history slots
+        live = neg[on]
+        assert len(set(live.tolist())) == len(live) and not (set(live.tolist()) & set(profiles[uid]))
+        assert live.size == 0 or (live.min() >= 1 and live.max() <= attrs.shape[0] - 1)
+
+
+def test_negative_sampling_is_seeded_and_uniform():
+    from carca_replication_amd.device_data import DeviceInteractions
+
+    n_items, N = 41, 10
+    profiles = {u: [1, 2, 3, 4, 5, 6] for u in range(64)}
+    ctx = {(u, it): np.zeros(1, np.float32) for u in profiles for it in profiles[u]}
+    log = DeviceInteractions(profiles, ctx, n_items)
+    users = log.valid_users("test")
+    a = log.eval_batch(users, 4, N, "test", seed=11)[2]
+    b = log.eval_batch(users, 4, N, "test", seed=11)[2]
+    c = log.eval_batch(users, 4, N, "test", seed=12)[2]
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # users differ from each other under one seed, and over many seeds every admissible id is drawn about equally often
+    assert len({tuple(r.tolist()) for r in a[:, 1:].cpu()}) > 32
+    counts = torch.zeros(n_items, dtype=torch.int64)
+    for seed in range(60):
+        neg = log.eval_batch(users, 4, N, "test", seed=seed)[2][:, 1:].reshape(-1).cpu().long()
+        counts += torch.bincount(neg, minlength=n_items)
+    assert int(counts[:7].sum()) == 0                      # the pad id and the six history items never appear
+    adm = counts[7:].double()
+    expect = 60 * 64 * N / (n_items - 7)
+    assert float(((adm - expect) ** 2 / expect).sum()) < 2.0 * (n_items - 7)  # chi-square far inside 2 dof-multiples
+
+
+def test_device_batches_feed_the_model_like_host_batches():
+    """Same ids and contexts => same scores: the device batch + registered attribute table equals the dense host batch."""
+    from carca_replication_amd import data as D
+    from carca_replication_amd.device_data import DeviceInteractions
+    from tests.model_util import build_model
+
+    profiles, ctx, attrs = _log(n_users=12, n_items=70, seed=2)
+    L, N = 6, 9
+    log = DeviceInteractions(profiles, ctx, attrs.shape[0])
+    users = log.valid_users("test")
+    p_x, p_c, o_x, o_c, y = log.eval_batch(users, L, N, "test", seed=5)
+    torch.manual_seed(0)
+    model = build_model(dict(d=64, H=2, n_blocks=1), attrs.shape[0], 32, 3, attrs.shape[1], L).cuda().eval()
+    table = torch.from_numpy(attrs).cuda()
+    with torch.no_grad():
+        dense = model(profile=(p_x, table[p_x.long()], p_c), targets=[(o_x, table[o_x.long()], o_c)])
+        model.embeds.register_attr_table(table)
+        ids_only = model(profile=(p_x, None, p_c), targets=[(o_x, None, o_c)])
+    assert float((dense - ids_only).abs().max()) < 1e-6
+    assert dense.shape == (users.numel(), 1 + N) and bool(y[:, 0].all())
+
+
+def test_too_few_items_for_the_negatives_is_an_error():
+    from carca_replication_amd import CarcaHipError
+    from carca_replication_amd.device_data import DeviceInteractions
+
+    profiles = {0: list(range(1, 9))}
+    ctx = {(0, it): np.zeros(1, np.float32) for it in profiles[0]}
+    log = DeviceInteractions(profiles, ctx, 12)
+    with pytest.raises(CarcaHipError):
+        log.eval_batch(log.valid_users("test"), 4, 5, "test")
