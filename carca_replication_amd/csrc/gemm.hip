@@ -507,6 +507,7 @@ struct WgradDev {
   CarcaWgradDesc d;
   int chunk_start[CARCA_MAX_SEGS + 1];  // 32-row chunks per segment, prefix sums
   int nnb, nkb, nkb0, nsplit, chunks_per_split;
+  int diag_plain_store;  // diagnostic (tuning key 3): overwrite instead of atomicAdd, to time the kernel without atomics
 };
 
 template <int BNO, int BKO, int BR, bool BUF = false>
@@ -654,7 +655,12 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < D.N) atomicAdd(&D.dw[(size_t)n * D.ldw + kcol], acc[t][r]);
+        if (n < D.N) {
+          if (args.diag_plain_store)
+            D.dw[(size_t)n * D.ldw + kcol] = acc[t][r];
+          else
+            atomicAdd(&D.dw[(size_t)n * D.ldw + kcol], acc[t][r]);
+        }
       }
   }
   if (D.db && kb == 0 && tid < BNO && n0 + tid < D.N) atomicAdd(&D.db[n0 + tid], bsum);
@@ -797,11 +803,13 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   g.nkb0 = (desc->K + BKO - 1) / BKO;
   g.nkb = g.nkb0 + (desc->K1 + BKO - 1) / BKO;
   // row splits: fill the chip's 4 x 256 resident slots in ONE round (119 registers -> 4 blocks per CU;
-  // measured at C2: 512 slots 1017 us, 768 972, 1024 809, 1536 865), but keep >= 4 chunks (128 rows) per split
+  // measured at C2: 512 slots 1017 us, 768 972, 1024 809, 1536 865), but keep >= 2 chunks (64 rows) per split
   const int tiles = g.nnb * g.nkb;
   const int slots = carca_tuning(CARCA_TUNE_WGRAD_SLOTS) > 0 ? carca_tuning(CARCA_TUNE_WGRAD_SLOTS) : 1024;
   int nsplit = tiles >= slots ? 1 : slots / tiles;
-  nsplit = max(1, min(nsplit, (chunks + 3) / 4));
+  const int min_chunks = carca_tuning(4) > 0 ? carca_tuning(4) : 2;  // (measured on the d x d products: 4 -> 21 us, 2 -> 18 us, 1 -> 23 us)
+  nsplit = max(1, min(nsplit, (chunks + min_chunks - 1) / min_chunks));
+  g.diag_plain_store = carca_tuning(3);
   g.chunks_per_split = (chunks + nsplit - 1) / nsplit;
   g.nsplit = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;
   // buffer loads when every operand offset provably fits 32 bits of bytes (a gather table's size must be stated)
