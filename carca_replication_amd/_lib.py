@@ -193,6 +193,7 @@ SIGNATURES = {
     "carca_embed_fwd": (_i, [C.POINTER(RowSeg), _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     "carca_gemm_rows": (_i, [C.POINTER(GemmDesc), _fp]),
     "carca_gemm_wgrad": (_i, [C.POINTER(WgradDesc), _fp]),
+    "carca_gemm_wgrad_group": (_i, [C.POINTER(WgradDesc), _i, _fp]),
     "carca_sa_block_fwd": (_i, [_fp, _i, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SaWeights), _i, C.POINTER(SaSave),
                                 C.POINTER(Dropout), _fp]),
     "carca_cross_score_fwd": (_i, [_fp, _i, _fp, _fp, C.POINTER(TargetGroup), _i, _i, _i, _i, _i, _i,

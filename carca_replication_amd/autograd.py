@@ -58,7 +58,7 @@ def _attn_param_grads(packs: _Packs, attn, grads_by_param):
     packs.g.unpack_into(real, accumulate=True)
 
 
-def _cross_decoder_backward(model, st, ys, dys, gbp, dev):
+def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after):
     """Backward of the sigmoid/ffn head + cross-attention (carca.py:340-347): returns (d p_normed, [d o_g])."""
     dec = model.decoder
     d, H = model.embeds.d, dec.attn.H
@@ -94,12 +94,11 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, dev):
     des_t = ops.gemm_rows([dict(a0=dqhs[gi], rowscale=dls[gi] if dec.residual else None, ids=o_ids[gi])
                            for gi in range(ngroups)], wq_t, d, dpo, dpi,
                           colvec=ffn_w_plain if dec.residual else None, mask_rows=True)
-    ops.gemm_wgrad([dict(dy=dqhs[gi], x=o_rows[gi]) for gi in range(ngroups)], dpo, d, cp.g.view(0),
-                   cp.g.view(3).view(-1))
+    wg.add([dict(dy=dqhs[gi], x=o_rows[gi]) for gi in range(ngroups)], dpo, d, cp.g.view(0), cp.g.view(3).view(-1))
     pn = st["p_normed"].view(-1, st["p_normed"].shape[-1])
-    ops.gemm_wgrad([dict(dy=dkh, x=pn)], dpo, d, cp.g.view(1), cp.g.view(4).view(-1))
-    ops.gemm_wgrad([dict(dy=dvh, x=pn)], dpo, d, cp.g.view(2), cp.g.view(5).view(-1))
-    _attn_param_grads(cp, dec.attn, gbp)
+    wg.add([dict(dy=dkh, x=pn)], dpo, d, cp.g.view(1), cp.g.view(4).view(-1))
+    wg.add([dict(dy=dvh, x=pn)], dpo, d, cp.g.view(2), cp.g.view(5).view(-1))
+    after.append(lambda: _attn_param_grads(cp, dec.attn, gbp))
     (dp,) = ops.gemm_rows([dict(a0=dkh, a1=dvh)], wk_t, d, dpo, dpi, bt1=wv_t, K1=dpo)
     return dp, des_t
 
@@ -178,8 +177,10 @@ class _CarcaFn(torch.autograd.Function):
         ys = ctx.saved_tensors
         ngroups = st["ngroups"]
         dys = [dys[gi].contiguous() if dys[gi] is not None else torch.zeros_like(ys[gi]) for gi in range(ngroups)]
+        # the small weight-gradient products feed nothing downstream: collected, then issued as ONE grouped launch
+        wg, after = ops.WgradGroup(), []
         if st["is_ca"]:
-            dp, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, dev)
+            dp, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after)
         else:
             dp, des_t = dec.score_backward(dys, st["dsave"], B, L, d, dpi)
         # final LayerNorm (carca.py:421)
@@ -202,11 +203,9 @@ class _CarcaFn(torch.autograd.Function):
             dyf = ops.mask_mul(dy, sv["m_ffn2"], bscale, d, dpi) if bp_ > 0 else dy
             (dh1pre,) = ops.gemm_rows([dict(a0=dyf, gate=sv["h1"])], w2_t, d, d, dpi, gate_slope=0.01,
                                       gate_scale=bscale, gate_zero_drops=bp_ > 0)
-            ops.gemm_wgrad([dict(dy=dyf, x=sv["h1"])], d, d, gbp[id(blk.ffn_2.weight)].view(d, d),
-                           gbp[id(blk.ffn_2.bias)])
+            wg.add([dict(dy=dyf, x=sv["h1"])], d, d, gbp[id(blk.ffn_2.weight)].view(d, d), gbp[id(blk.ffn_2.bias)])
             (ds,) = ops.gemm_rows([dict(a0=dh1pre, add=dy if blk.residual else None)], w1_t, d, d, dpi)
-            ops.gemm_wgrad([dict(dy=dh1pre, x=sv["s2"])], d, d, gbp[id(blk.ffn_1.weight)].view(d, d),
-                           gbp[id(blk.ffn_1.bias)])
+            wg.add([dict(dy=dh1pre, x=sv["s2"])], d, d, gbp[id(blk.ffn_1.weight)].view(d, d), gbp[id(blk.ffn_1.bias)])
             # s = LayerNorm2(r), r = attention (+ q)
             dr = ops.layernorm_bwd(ds, sv["r"], blk.norm2.weight.detach(), d, dpi, dgamma=gbp[id(blk.norm2.weight)],
                                    dbeta=gbp[id(blk.norm2.bias)])
@@ -215,10 +214,10 @@ class _CarcaFn(torch.autograd.Function):
             bq_t, bk_t, bv_t = bp.wT.view(0), bp.wT.view(1), bp.wT.view(2)
             (dqn,) = ops.gemm_rows([dict(a0=dqh, add=dr if blk.residual else None)], bq_t, d, dpo, dpi)
             (dx_kv,) = ops.gemm_rows([dict(a0=dkh_b, a1=dvh_b)], bk_t, d, dpo, dpi, bt1=bv_t, K1=dpo)
-            ops.gemm_wgrad([dict(dy=dqh, x=sv["qn"])], dpo, d, bp.g.view(0), bp.g.view(3).view(-1))
-            ops.gemm_wgrad([dict(dy=dkh_b, x=x_in)], dpo, d, bp.g.view(1), bp.g.view(4).view(-1))
-            ops.gemm_wgrad([dict(dy=dvh_b, x=x_in)], dpo, d, bp.g.view(2), bp.g.view(5).view(-1))
-            _attn_param_grads(bp, blk.attn, gbp)
+            wg.add([dict(dy=dqh, x=sv["qn"])], dpo, d, bp.g.view(0), bp.g.view(3).view(-1))
+            wg.add([dict(dy=dkh_b, x=x_in)], dpo, d, bp.g.view(1), bp.g.view(4).view(-1))
+            wg.add([dict(dy=dvh_b, x=x_in)], dpo, d, bp.g.view(2), bp.g.view(5).view(-1))
+            after.append(lambda bp=bp, blk=blk: _attn_param_grads(bp, blk.attn, gbp))
             # q = LayerNorm1(x); K, V from x itself
             dx = ops.layernorm_bwd(dqn, x_in, blk.norm1.weight.detach(), d, dpi, addend=dx_kv,
                                    dgamma=gbp[id(blk.norm1.weight)], dbeta=gbp[id(blk.norm1.bias)])
@@ -227,6 +226,9 @@ class _CarcaFn(torch.autograd.Function):
         if st["p_emb"] > 0:  # CARCA.dropout on the profile embedding (carca.py:416)
             dx = ops.mask_mul(dx, st["m_embed"], 1.0 / (1.0 - st["p_emb"]), d, dpi)
         des = [dx] + des_t                      # d e per segment, [rows, dpi]; profile rows still unmasked
+        wg.launch()
+        for fn in after:  # head-padded staging buffers -> the real WQ/WK/WV gradients
+            fn()
         emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi)
         ctx.st = None
         return (None, None, None) + tuple(grads)

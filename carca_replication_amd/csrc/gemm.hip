@@ -510,8 +510,8 @@ struct WgradDev {
   int diag_plain_store;  // diagnostic (tuning key 3): overwrite instead of atomicAdd, to time the kernel without atomics
 };
 
-template <int BNO, int BKO, int BR, bool BUF = false>
-__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
+template <int BNO, int BKO, int BR, bool BUF>
+__device__ __forceinline__ void wgrad_body(const WgradDev& args, int b) {
   static_assert(BNO == 96 && BKO == 128 && BR == 32, "tile shape baked into the lane maps below");
   constexpr int NT = 256;
   __shared__ __attribute__((aligned(16))) float Ys[BR * BNO];  // dY tile [row][n]
@@ -519,7 +519,6 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
 
   const CarcaWgradDesc& D = args.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int b = blockIdx.x;
   const int kb = b % args.nkb;
   b /= args.nkb;
   const int nb = b % args.nnb;
@@ -666,6 +665,27 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
   if (D.db && kb == 0 && tid < BNO && n0 + tid < D.N) atomicAdd(&D.db[n0 + tid], bsum);
 }
 
+template <int BNO, int BKO, int BR, bool BUF = false>
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradDev args) {
+  wgrad_body<BNO, BKO, BR, BUF>(args, blockIdx.x);
+}
+
+// Several independent products in ONE launch: the d x d weight gradients of a backward pass are ~20 us latency-bound
+// launches of ~100 blocks each; side by side they fill the chip and cost one launch.  Block -> (problem, local block).
+constexpr int WGRAD_GROUP_MAX = 32;
+struct WgradGroupIndex {
+  int n;
+  int block_start[WGRAD_GROUP_MAX + 1];
+};
+template <int BNO, int BKO, int BR>
+__global__ __launch_bounds__(256) void gemm_wgrad_group_kernel(const WgradDev* __restrict__ devs,
+                                                               const WgradGroupIndex idx) {
+  int p = 0;
+  for (int i = 1; i < idx.n; ++i)
+    if ((int)blockIdx.x >= idx.block_start[i]) p = i;
+  wgrad_body<BNO, BKO, BR, true>(devs[p], (int)blockIdx.x - idx.block_start[p]);
+}
+
 }  // namespace
 
 template <int BM, int BN, int BK, int PF, bool BUF = false>
@@ -765,8 +785,7 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
 
 int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream);  // wgrad_cu.hip
 
-extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int wgrad_check(const CarcaWgradDesc* desc) {
   CARCA_CHECK_ARG(desc && desc->nseg >= 1 && desc->nseg <= CARCA_MAX_SEGS, "gemm_wgrad: bad segment count");
   CARCA_CHECK_ARG(desc->dw && desc->N >= 1 && desc->K >= 1 && desc->K1 >= 0 && desc->ldw >= desc->K + desc->K1 &&
                       desc->ld_dy >= desc->N && desc->ld_x >= desc->K && (desc->K1 == 0 || desc->ld_x1 >= desc->K1),
@@ -778,22 +797,17 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
     CARCA_CHECK_ARG(sg.T >= 1 || (!sg.x_bstride && !sg.x1_bstride), "gemm_wgrad: segment %d needs T >= 1", s);
     CARCA_CHECK_ARG(!(sg.x_gather && !sg.ids), "gemm_wgrad: segment %d gathers without ids", s);
   }
-  // the big product (dW of feats_embed) goes to the persistent one-block-per-CU kernel; tuning variant 4 / 5 = never
-  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
-  if (variant != 4 && variant != 5) {
-    const int r = carca_wgrad_cu_try(desc, stream);
-    if (r != 1) return r;
-  }
+  return CARCA_OK;
+}
+
+// tiling / row splits of the tiled kernel for one product; returns the grid size; *fits: buffer loads are safe
+static int wgrad_prepare(const CarcaWgradDesc* desc, WgradDev& g, bool* fits_out, int slot_budget = 0) {
   constexpr int BNO = 96, BKO = 128, BR = 32;
-  WgradDev g{};
+  g = WgradDev{};
   g.d = *desc;
   int chunks = 0;
   for (int s = 0; s < desc->nseg; ++s) {
     const CarcaWgradSeg& sg = desc->seg[s];
-    CARCA_CHECK_ARG(sg.rows >= 1 && sg.dy && sg.x && !(desc->mask_rows && !sg.ids) && (desc->K1 == 0 || sg.x1),
-                    "gemm_wgrad: segment %d malformed", s);
-    CARCA_CHECK_ARG(sg.T >= 1 || (!sg.x_bstride && !sg.x1_bstride), "gemm_wgrad: segment %d needs T >= 1", s);
-    CARCA_CHECK_ARG(!(sg.x_gather && !sg.ids), "gemm_wgrad: segment %d gathers without ids", s);
     if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
     g.chunk_start[s] = chunks;
     chunks += (sg.rows + BR - 1) / BR;
@@ -805,7 +819,8 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   // row splits: fill the chip's 4 x 256 resident slots in ONE round (119 registers -> 4 blocks per CU;
   // measured at C2: 512 slots 1017 us, 768 972, 1024 809, 1536 865), but keep >= 2 chunks (64 rows) per split
   const int tiles = g.nnb * g.nkb;
-  const int slots = carca_tuning(CARCA_TUNE_WGRAD_SLOTS) > 0 ? carca_tuning(CARCA_TUNE_WGRAD_SLOTS) : 1024;
+  const int slots = slot_budget > 0 ? slot_budget
+                    : carca_tuning(CARCA_TUNE_WGRAD_SLOTS) > 0 ? carca_tuning(CARCA_TUNE_WGRAD_SLOTS) : 1024;
   int nsplit = tiles >= slots ? 1 : slots / tiles;
   const int min_chunks = carca_tuning(4) > 0 ? carca_tuning(4) : 2;  // (measured on the d x d products: 4 -> 21 us, 2 -> 18 us, 1 -> 23 us)
   nsplit = max(1, min(nsplit, (chunks + min_chunks - 1) / min_chunks));
@@ -827,10 +842,95 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
                                          : (uint64_t)(sg.rows - 1) * desc->ld_x1;
     fits = lx + desc->K < lim && lx1 + desc->K1 < lim && (uint64_t)sg.rows * desc->ld_dy < lim;
   }
+  *fits_out = fits;
+  return tiles * g.nsplit;
+}
+
+extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int rc = wgrad_check(desc)) return rc;
+  // the big product (dW of feats_embed) goes to the persistent one-block-per-CU kernel; tuning variant 4 / 5 = never
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
+  if (variant != 4 && variant != 5) {
+    const int r = carca_wgrad_cu_try(desc, stream);
+    if (r != 1) return r;
+  }
+  constexpr int BNO = 96, BKO = 128, BR = 32;
+  WgradDev g;
+  bool fits = false;
+  const int grid = wgrad_prepare(desc, g, &fits);
   if (fits)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR, true>), dim3(tiles * g.nsplit), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR, true>), dim3(grid), dim3(256), 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR>), dim3(tiles * g.nsplit), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR>), dim3(grid), dim3(256), 0, stream, g);
   CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+// Grouped launch: the kernel reads its descriptors from a pinned, device-mapped host ring (one slot per launch, guarded
+// by an event); products that are big enough for the persistent kernel, or whose offsets do not fit the buffer-load
+// path, are issued one by one instead.
+namespace {
+constexpr int GROUP_RING = 16;
+WgradDev* g_group_host = nullptr;  // [GROUP_RING][WGRAD_GROUP_MAX] pinned, mapped into the device's address space
+WgradDev* g_group_dev = nullptr;   // the device's view of the same memory (no copy command: a small async H2D copy
+                                   // turned out to stall the issuing thread until the stream had drained)
+hipEvent_t g_group_ev[GROUP_RING];
+bool g_group_used[GROUP_RING] = {false};
+int g_group_next = 0;
+}  // namespace
+
+extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(descs && n >= 1, "gemm_wgrad_group: no products");
+  for (int i = 0; i < n; ++i)
+    if (int rc = wgrad_check(&descs[i])) return rc;
+  if (!g_group_host) {
+    if (hipHostMalloc(&g_group_host, sizeof(WgradDev) * GROUP_RING * WGRAD_GROUP_MAX, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&g_group_dev, g_group_host, 0) != hipSuccess) {
+      g_group_host = nullptr;
+      carca_set_error("gemm_wgrad_group: cannot allocate the descriptor ring");
+      return CARCA_ERR_BADARG;
+    }
+    for (int i = 0; i < GROUP_RING; ++i) (void)hipEventCreateWithFlags(&g_group_ev[i], hipEventDisableTiming);
+  }
+  constexpr int BNO = 96, BKO = 128, BR = 32;
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
+  int done = 0;
+  while (done < n) {
+    const int slot = g_group_next;
+    g_group_next = (g_group_next + 1) % GROUP_RING;
+    if (g_group_used[slot]) (void)hipEventSynchronize(g_group_ev[slot]);  // normally long complete
+    WgradDev* host = g_group_host + (size_t)slot * WGRAD_GROUP_MAX;
+    WgradGroupIndex idx{};
+    int blocks = 0;
+    while (done < n && idx.n < WGRAD_GROUP_MAX) {
+      bool fits = false;
+      WgradDev g;
+      // row-split budget per product (tuning key 5; 0 = the single-product default).  A/B at C2, interleaved in one
+      // process (tools/ab_train.py): ungrouped 2.341 ms/step, grouped 2.229, grouped with 64 / 85 / 128 slots per
+      // product 2.223 / 2.263 / 2.220 -- the budget does not matter, the single launch does
+      const int budget = carca_tuning(5) > 0 ? carca_tuning(5) : 0;
+      const int grid = wgrad_prepare(&descs[done], g, &fits, budget);
+      const bool big = (long)descs[done].N * (descs[done].K + descs[done].K1) > 96 * 1024;  // single-product path decides
+      if (!fits || big || variant == 6) {  // (variant 6: never group -- A/B switch)
+        if (int rc = carca_gemm_wgrad(&descs[done], stream_)) return rc;
+        ++done;
+        continue;
+      }
+      host[idx.n] = g;
+      idx.block_start[idx.n] = blocks;
+      blocks += grid;
+      ++idx.n;
+      ++done;
+    }
+    if (idx.n == 0) continue;
+    idx.block_start[idx.n] = blocks;
+    WgradDev* dev = g_group_dev + (size_t)slot * WGRAD_GROUP_MAX;
+    hipLaunchKernelGGL((gemm_wgrad_group_kernel<BNO, BKO, BR>), dim3(blocks), dim3(256), 0, stream, dev, idx);
+    (void)hipEventRecord(g_group_ev[slot], stream);
+    g_group_used[slot] = true;
+    CARCA_LAUNCH_CHECK();
+  }
   return CARCA_OK;
 }

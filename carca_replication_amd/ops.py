@@ -520,6 +520,33 @@ def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, ma
     strided); optional x1 likewise for dw[:, K:K+K1]; optional ids.  dw is a 2-D fp32 view (unit inner stride).
     """
     lib = _lib.load()
+    D, _keep = _wgrad_desc(segs, N, K, dw, db, mask_rows, K1)
+    _lib.check(lib.carca_gemm_wgrad(C.byref(D), _stream()), "gemm_wgrad")
+
+
+class WgradGroup:
+    """Collects independent weight-gradient products (same arguments as gemm_wgrad) and issues them with ONE launch
+    (carca_gemm_wgrad_group): the d x d products of a backward pass are latency-bound launches of ~100 blocks each."""
+
+    def __init__(self):
+        self.descs, self.keep = [], []
+
+    def add(self, segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, mask_rows: bool = False,
+            K1: int = 0) -> None:
+        D, keep = _wgrad_desc(segs, N, K, dw, db, mask_rows, K1)
+        self.descs.append(D)
+        self.keep.append((keep, segs, dw, db))  # every operand stays referenced until launch() has been issued
+
+    def launch(self) -> None:
+        if not self.descs:
+            return
+        lib = _lib.load()
+        arr = (_lib.WgradDesc * len(self.descs))(*self.descs)
+        _lib.check(lib.carca_gemm_wgrad_group(arr, len(self.descs), _stream()), "gemm_wgrad_group")
+        self.descs, self.keep = [], []
+
+
+def _wgrad_desc(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor], mask_rows: bool, K1: int):
     D = _lib.WgradDesc()
     D.nseg = len(segs)
     keep = []
@@ -568,7 +595,7 @@ def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, ma
         raise CarcaHipError("gemm_wgrad: dw must be a 2-D fp32 view with unit inner stride")
     D.ld_dy, D.ld_x, D.ld_x1, D.N, D.K, D.K1 = ld_dy, ld_x, ld_x1 or 0, N, K, K1
     D.dw, D.ldw, D.db, D.mask_rows = dw.data_ptr(), dw.stride(0), _ptr(db), int(mask_rows)
-    _lib.check(lib.carca_gemm_wgrad(C.byref(D), _stream()), "gemm_wgrad")
+    return D, keep
 
 
 # --------------------------------------------------------------------------------------------------

@@ -145,6 +145,10 @@ typedef struct CarcaWgradDesc {
   int32_t mask_rows;
 } CarcaWgradDesc;
 int carca_gemm_wgrad(const CarcaWgradDesc* desc /*host*/, void* stream);
+/* n independent products in ONE launch (the d x d weight gradients of a backward pass are ~20 us latency-bound
+ * launches; side by side they fill the chip).  Same semantics as n calls of carca_gemm_wgrad in any order; products
+ * with more than 96 x 1024 outputs are passed on to carca_gemm_wgrad one by one. */
+int carca_gemm_wgrad_group(const CarcaWgradDesc* descs /*host, [n]*/, int n, void* stream);
 
 /* ---- a1 + a2 + a9: AllEmbedding.forward over several row segments ---------------------------
  * Replaces get_mask (utils.py:6-7) + AllEmbedding.forward (carca.py:85-95) + the additive

@@ -166,3 +166,26 @@ def test_gemm_wgrad_kernel_choices(gemm_variant, rows, T, N, K, K1, how):
     _close(dw[:, :K + K1], want_w, tol=5e-5)
     _close(db, want_b, tol=5e-5)
     assert float(dw[:, K + K1:].abs().max()) == 0.0
+
+
+def test_gemm_wgrad_group_equals_single_launches():
+    """carca_gemm_wgrad_group: several independent products in one launch give what one launch each gives."""
+    from carca_replication_amd import ops
+
+    shapes = [(640, 96, 96), (1300, 90, 90), (257, 33, 130), (640, 96, 540)]
+    ins = [(_rand(r, n + 2, seed=3 * i).cuda(), _rand(r, k + 1, seed=3 * i + 1).cuda()) for i, (r, n, k) in enumerate(shapes)]
+    single, grouped = [], []
+    wg = ops.WgradGroup()
+    for (r, n, k), (dy, x) in zip(shapes, ins):
+        dw1, db1 = torch.zeros(n, k, device="cuda"), torch.zeros(n, device="cuda")
+        ops.gemm_wgrad([dict(dy=dy[:, :n], x=x[:, :k])], n, k, dw1, db1)
+        single.append((dw1, db1))
+        dw2, db2 = torch.zeros(n, k, device="cuda"), torch.zeros(n, device="cuda")
+        wg.add([dict(dy=dy[:, :n], x=x[:, :k])], n, k, dw2, db2)
+        grouped.append((dw2, db2))
+    wg.launch()
+    for (r, n, k), (dy, x), (dw1, db1), (dw2, db2) in zip(shapes, ins, single, grouped):
+        want = dy[:, :n].double().T @ x[:, :k].double()
+        _close(dw2, want.cpu(), tol=5e-5)
+        _close(db2, dy[:, :n].double().sum(0).cpu(), tol=5e-5)
+        _close(dw2, dw1.double().cpu(), tol=1e-5)
