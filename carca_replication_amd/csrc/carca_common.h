@@ -101,7 +101,8 @@ __device__ __forceinline__ int unpad_feature(int fp, int dh, int dhp) {
 #define CARCA_ERR_BADARG (-2)
 
 void carca_set_error(const char* fmt, ...);
-// tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice
+// tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice.
+// Keys 3..5 are used by number (see include/carca_hip.h).
 enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_COUNT = 8 };
 int carca_tuning(int key);
 unsigned long long* carca_debug_buffer();  // device buffer for in-kernel phase stamps (diagnostic runs), or null

@@ -7,17 +7,20 @@
 // the model's flops at n_attrs = 4096) and every input-gradient product of the backward pass;
 // gemm_wgrad produces every weight gradient (the feats_embed one is as large as the forward GEMM).
 //
-// gemm_rows:  block tile 128 x 96, K step 32, 4 waves, wave w owns rows 32w..32w+31 x all 96
-//   columns (3 accumulator tiles).  Operands are staged global -> registers -> LDS with rows padded
-//   to 36 floats so that the 16-byte fragment reads are bank-conflict free; the next K tile's global
-//   loads are in flight while the current one is multiplied.  144 registers per lane -> 3 blocks per
-//   CU, which is what C2's 755 blocks want (256 CUs x 3 = 768 slots: one resident round).
-//   Blocks that share an A row block are numbered so that they land on the same XCD under round-robin
-//   placement: the A tile is fetched from HBM once and re-read from that XCD's L2 by the other column
-//   blocks (a speed choice only, never correctness).
-// gemm_wgrad: block tile 96 (n) x 128 (k), 32 rows per step; both operands are read from their
-//   row-major LDS tiles TRANSPOSED (lane = n resp. k, one ds_read_b32 per MFMA operand), so neither
-//   dY nor X is ever transposed in memory.  Row splits combine through fp32 atomics.
+// Kernels in this file (the launchers at the bottom pick one from the shape):
+//   gemm_rows_cu_kernel      ONE 384 x 96 block per CU, hand-scheduled K step: the feature GEMM (see its own comment)
+//   gemm_rows_kernel<128,96> block tile 128 x 96, K step 32, 4 waves, wave w owns rows 32w..32w+31 x all 96 columns
+//                            (3 accumulator tiles), 3 blocks per CU: large products whose grid does not suit the
+//                            one-block-per-CU kernel
+//   gemm_rows_kernel<128,32> 32-column blocks + a 4-deep register prefetch ring: narrow outputs (joint embedding,
+//                            every d-wide product of the backward pass)
+//   gemm_wgrad_kernel        block tile 96 (n) x 128 (k), 32 rows per step; both operands are read from their
+//                            row-major LDS tiles TRANSPOSED (lane = n resp. k), so neither dY nor X is ever transposed
+//                            in memory; row splits combine through fp32 atomics.  gemm_wgrad_group_kernel runs several
+//                            such products in one launch.  (The feats_embed weight gradient: wgrad_cu.hip.)
+// Common: operands staged global -> registers -> LDS with rows padded to 36 floats (conflict-free 16-byte fragment
+// reads), buffer loads with 32-bit offsets wherever they provably fit, blocks that share an A row block numbered so
+// that they land on the same XCD (the A tile is fetched from HBM once and re-read from that XCD's L2).
 #include "carca_common.h"
 #include <type_traits>
 #include "../../include/carca_hip.h"

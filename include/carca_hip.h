@@ -40,7 +40,13 @@ extern "C" {
 #define CARCA_EMBED_ALL 7
 
 int carca_abi_version(void);
-/* Kernel-variant knobs for tuning runs (tools/): key 0 row GEMM, key 1 attention kernels; 0 = shipped. */
+/* Kernel-variant knobs for tuning runs and A/B tests (tools/, tests/); 0 = the shipped choice everywhere.
+ *   key 0  row / weight-gradient GEMM: 1 force 128x96 tiles, 2 force the one-block-per-CU kernels, 3 = 2 + in-kernel
+ *          stamps, 4 no buffer loads, 5 tiled weight gradient only, 6 never group weight gradients
+ *   key 1  attention kernels: 1 one workgroup per user, 2 always two
+ *   key 2  weight gradient: row-split slot target      key 4  minimum 32-row chunks per split
+ *   key 3  weight gradient: plain stores instead of atomics (timing diagnostic, wrong results)
+ *   key 5  grouped weight gradient: row-split slot target per product */
 int carca_set_tuning(int key, int value);
 /* Diagnostic runs only: device buffer (>= 16 x #workgroups uint64) that the attention kernels fill with
  * s_memtime stamps at their phase boundaries; NULL (default) disables stamping. */
