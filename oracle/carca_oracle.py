@@ -427,6 +427,9 @@ def synth_eval_batch(B: int, L: int, N: int, n_items: int, n_attrs: int, n_ctx: 
     """
     import numpy as np
 
+    if n_items - 1 < L + N:
+        raise ValueError(f"synth_eval_batch: {n_items - 1} item ids cannot give {N - 1} distinct negatives outside a "
+                         f"profile of up to {L} items")
     rng = np.random.default_rng(seed)
     if attrs_table is None:
         attrs_table = rng.random((n_items, n_attrs), dtype=np.float32)
