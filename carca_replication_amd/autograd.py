@@ -28,6 +28,7 @@ def _zeros_like_params(params):
         offs.append(total)
         total += (p.numel() + 3) // 4 * 4
     flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+    # (dist.allreduce_gradients recognises this layout by storage and offsets and reduces the flat buffer itself)
     return [flat[o: o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
 
 

@@ -16,6 +16,16 @@ from .modules import BinaryCrossEntropy, get_mask
 _loss_fn = BinaryCrossEntropy()
 
 
+SPARSE_TABLE_BYTES = 64 * 2 ** 20  # item tables above this exchange (row ids, row gradients) instead of the dense grad
+
+
+def _sparse_tables(model, p_x, o_x):
+    emb = getattr(getattr(model, "embeds", None), "items_embed", None)
+    if emb is None or emb.weight.numel() * emb.weight.element_size() < SPARSE_TABLE_BYTES:
+        return None
+    return {emb.weight: torch.cat([p_x.reshape(-1), o_x.reshape(-1)])}
+
+
 def train_step(model, optim, batch, sharded: bool = False) -> torch.Tensor:
     """batch = (p_x, p_a, p_c, o_x, o_a, o_c, y_true) as the reference's DataLoader yields (train.py:84).
 
@@ -33,7 +43,7 @@ def train_step(model, optim, batch, sharded: bool = False) -> torch.Tensor:
     loss = _loss_fn(y, y_true, get_mask(o_x), denom=denom)
     loss.backward()
     if sharded:
-        cdist.allreduce_gradients(model.parameters())
+        cdist.allreduce_gradients(model.parameters(), sparse_rows=_sparse_tables(model, p_x, o_x))
     optim.step()
     return loss.detach()
 

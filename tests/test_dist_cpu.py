@@ -78,7 +78,35 @@ def _worker(rank, world, port, ret):
                     else float((p.grad - ref).abs().max()))
     sums = torch.tensor([float(rank + 1), 2.0])
     cdist.allreduce_sums(sums)
-    ret[rank] = (worst, sums.tolist())
+    # (a) gradients that are views of one flat buffer (what the HIP backward hands out) are reduced in place
+    shapes = [(5, 3), (7,), (2, 2, 2)]
+    tot = sum((torch.Size(sh).numel() + 3) // 4 * 4 for sh in shapes)
+    flat = torch.arange(tot, dtype=torch.float32) * (rank + 1)
+    ps, off = [], 0
+    for sh in shapes:
+        n = torch.Size(sh).numel()
+        p = torch.nn.Parameter(torch.zeros(sh))
+        p.grad = flat[off: off + n].view(sh)
+        ps.append(p)
+        off += (n + 3) // 4 * 4
+    assert cdist._shared_flat([p.grad for p in ps]) is not None
+    cdist.allreduce_gradients(ps, bucket_mb=1e-5)  # several chunks of the flat buffer
+    ok_flat = bool(torch.equal(flat, torch.arange(tot, dtype=torch.float32) * 3.0))
+    # (b) an embedding table's gradient exchanged as (row ids, row gradients) equals the dense all-reduce
+    g = torch.Generator().manual_seed(10 + rank)
+    table = torch.nn.Parameter(torch.zeros(50, 6))
+    ids = torch.randint(0, 50, (4, 9), generator=g)
+    ids[0, :3] = 0
+    dense = torch.zeros(50, 6)
+    dense.index_add_(0, ids.reshape(-1), torch.randn(36, 6, generator=g))
+    dense[0] = 0  # the pad row never gets a gradient (nn.Embedding(padding_idx=0))
+    other = torch.nn.Parameter(torch.zeros(3))
+    table.grad, other.grad = dense.clone(), torch.full((3,), float(rank + 1))
+    want = dense.clone()
+    dist.all_reduce(want)
+    cdist.allreduce_gradients([table, other], sparse_rows={table: ids})
+    ok_sparse = bool(torch.allclose(table.grad, want, atol=1e-6)) and bool(torch.equal(other.grad, torch.full((3,), 3.0)))
+    ret[rank] = (worst, sums.tolist(), ok_flat, ok_sparse)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,6 +120,7 @@ def test_two_rank_gloo_gradient_allreduce_equals_full_batch():
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
-        worst, sums = ret[rank]
+        worst, sums, ok_flat, ok_sparse = ret[rank]
         assert worst < 1e-4, worst
         assert sums == [3.0, 4.0]
+        assert ok_flat and ok_sparse
