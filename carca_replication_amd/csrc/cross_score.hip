@@ -30,7 +30,7 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
                                                                float* __restrict__ p_normed,
                                                                const GroupsDev groups, int ldo, int L, int d, int dh,
                                                                const CarcaCaWeights w, int residual, int training,
-                                                               const CarcaCaSave sv_in, const DropCfg dc,
+                                                               const CarcaCaSave sv, const DropCfg dc,
                                                                unsigned site, int nparts, unsigned long long* stamps) {
 #define CA_STAMP(i)                                                                                \
   do {                                                                                             \
@@ -48,12 +48,8 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
   // With fewer users than CUs a user's target tiles are shared by TWO workgroups; both build the same final-norm /
   // K / V^T images (nothing passes between them), the first one writes the copies kept for the backward pass.
   const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
-  CarcaCaSave sv = sv_in;
-  if (part != 0) {
-    sv.kh = nullptr;
-    sv.vh = nullptr;
-    p_normed = nullptr;
-  }
+  const bool saver = part == 0;
+  if (!saver) p_normed = nullptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it (jobs, tiles, heads) is uniform
   const int LT = (L + 15) >> 4;
@@ -106,10 +102,10 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
       const int ft = jj / LT, st = jj - ft * LT;
       if (!isv)
         proj_tile_feat_major<DPI>(w.wk, w.bk, Ps, G::SI, Ks, G::SO, ft, st, lane,
-                                  sv.kh ? sv.kh + ubase * G::DPO : nullptr, G::DPO, L);
+                                  (saver && sv.kh) ? sv.kh + ubase * G::DPO : nullptr, G::DPO, L);
       else
         proj_tile_slot_major<DPI>(w.wv, w.bv, Ps, G::SI, Vt, ATT_SK, ft, st, lane,
-                                  sv.vh ? sv.vh + ubase * G::DPO : nullptr, G::DPO, L);
+                                  (saver && sv.vh) ? sv.vh + ubase * G::DPO : nullptr, G::DPO, L);
     }
   }
   __syncthreads();
@@ -149,25 +145,27 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
           okbits |= (ok ? 1u : 0u) << (4 * kt + r);
         }
       const int nkt = training ? min(LT, qt + 1) : LT;
-      f32x4 oh[G::NFH], p[ATT_LT];
-      const unsigned midx = (unsigned)((((size_t)u * NH + h) * grp.N + (in_range ? n : 0)) * L);
-      attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, nkt, okbits, sqrt_dh, oh, p, lane,
-                                (sv.qh[gi] && in_range) ? sv.qh[gi] + row * G::DPO : nullptr, &dc, site + gi, midx,
-                                (sv.m_attn[gi] && in_range) ? sv.m_attn[gi] + midx : nullptr, L);
+      // the residual part of the logit (w . o, once per target) first: it is the last use of the target row's
+      // fragments outside the Q projection, so they die early instead of living through the whole head
       float ypart = 0.f;
-#pragma unroll
-      for (int ft = 0; ft < G::NFH; ++ft) {
-        const f32x4 wp = gload4(w.ffn_w_pad, h * DHP + 16 * ft + 4 * mq);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ypart += wp[r] * oh[ft][r];
-      }
-      if (residual && h == 0) {  // w . o, once per target
+      if (residual && h == 0) {
 #pragma unroll
         for (int kg = 0; kg < G::NKG; ++kg) {
           const f32x4 wv = gload4(w.ffn_w, 16 * kg + 4 * mq);
 #pragma unroll
           for (int r = 0; r < 4; ++r) ypart += wv[r] * qfrag[kg][r];
         }
+      }
+      f32x4 oh[G::NFH], p[ATT_LT];
+      const unsigned midx = (unsigned)((((size_t)u * NH + h) * grp.N + (in_range ? n : 0)) * L);
+      attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, nkt, okbits, sqrt_dh, oh, p, lane,
+                                (sv.qh[gi] && in_range) ? sv.qh[gi] + row * G::DPO : nullptr, &dc, site + gi, midx,
+                                (sv.m_attn[gi] && in_range) ? sv.m_attn[gi] + midx : nullptr, L);
+#pragma unroll
+      for (int ft = 0; ft < G::NFH; ++ft) {
+        const f32x4 wp = gload4(w.ffn_w_pad, h * DHP + 16 * ft + 4 * mq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ypart += wp[r] * oh[ft][r];
       }
       ypart = quad4_sum(ypart);
       if (mq == 0) Yp[(tl * NH + h) * 16 + ln] = ypart;
