@@ -45,9 +45,9 @@ def build_inputs(c, seed, device):
     """SURVEY.md 8d synthetic inputs, generated on the host with numpy, moved to HBM once."""
     import torch
 
-    from oracle.carca_oracle import synth_eval_batch  # input generator only (test infrastructure)
+    from carca_replication_amd.synth import eval_batch
 
-    profile, target, _ = synth_eval_batch(c["B"], c["L"], c["N"], c["n_items"], c["n_attrs"], c["n_ctx"], seed=seed)
+    profile, target, _ = eval_batch(c["B"], c["L"], c["N"], c["n_items"], c["n_attrs"], c["n_ctx"], seed=seed)
     to = lambda t: tuple(x.to(device) for x in t)  # noqa: E731
     return profile, target, to(profile), to(target)
 
@@ -55,11 +55,13 @@ def build_inputs(c, seed, device):
 def build_model(c, device):
     import torch
 
-    from tests.model_util import build_model as bm
+    from carca_replication_amd import modules as M
 
-    torch.manual_seed(0)
-    model = bm(dict(d=c["d"], H=c["H"], n_blocks=c["n_blocks"]), c["n_items"], c["g"], c["n_ctx"], c["n_attrs"], c["L"])
-    return model.eval().to(device)
+    torch.manual_seed(0)  # the reference's factories (training.py:76-100, 165-172), random-init weights
+    emb = M.AllEmbedding(c["n_items"], c["d"], c["g"], c["n_ctx"], c["n_attrs"], M.IdentityEncoding())
+    blocks = torch.nn.ModuleList([M.SelfAttentionBlock(c["d"], c["H"], 0.0, True) for _ in range(c["n_blocks"])])
+    dec = M.CrossAttentionBlock(c["d"], c["H"], 0.0, True)
+    return M.CARCA(d=c["d"], p=0.0, emb=emb, enc=blocks, dec=dec).eval().to(device)
 
 
 def host_cores():
@@ -111,10 +113,10 @@ def measure_train(c, model, rank, world, device, steps):
     import torch.distributed as dist
 
     from carca_replication_amd import engine
-    from oracle.carca_oracle import synth_eval_batch
+    from carca_replication_amd.synth import eval_batch
 
     L = c["L"]
-    profile, pos, _ = synth_eval_batch(c["B"], L, L, c["n_items"], c["n_attrs"], c["n_ctx"], seed=4321 + rank)
+    profile, pos, _ = eval_batch(c["B"], L, L, c["n_items"], c["n_attrs"], c["n_ctx"], seed=4321 + rank)
     px = profile[0]
     o_x = torch.cat([pos[0] * (px != 0), pos[0].flip(1) * (px != 0)], dim=1)
     o_a = torch.cat([pos[1], pos[1].flip(1)], dim=1)
