@@ -314,10 +314,15 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
   }
 }
 
-// lazily grown device workspace for the row tables (one process drives one GPU; launches are stream-ordered and the
-// table of a launch is consumed by that launch only, so a single buffer per process is enough)
-unsigned* g_tab = nullptr;
-size_t g_tab_elems = 0;
+// Lazily grown device workspaces for the row tables: a small ring, one slot per launch, each guarded by an event
+// recorded behind its consumer -- consecutive launches never share a table, whatever streams they are issued on.
+constexpr int TAB_RING = 4;
+unsigned* g_tab[TAB_RING] = {nullptr};
+size_t g_tab_elems[TAB_RING] = {0};
+hipEvent_t g_tab_ev[TAB_RING];
+bool g_tab_used[TAB_RING] = {false};
+bool g_tab_init = false;
+int g_tab_next = 0;
 int g_num_cus = 0;
 
 }  // namespace
@@ -374,22 +379,31 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   g.per = (int)((total + g_num_cus - 1) / g_num_cus);
   const int grid = (int)((total + g.per - 1) / g.per);
   g.V = chunks * WG_BR;
-  if ((size_t)3 * g.V > g_tab_elems) {
-    if (g_tab) (void)hipFree(g_tab);  // (synchronises: earlier launches that used the old buffer are done)
-    g_tab = nullptr;
-    g_tab_elems = (size_t)3 * g.V * 2;
-    if (hipMalloc(&g_tab, g_tab_elems * sizeof(unsigned)) != hipSuccess) {
-      g_tab_elems = 0;
+  if (!g_tab_init) {
+    for (int i = 0; i < TAB_RING; ++i) (void)hipEventCreateWithFlags(&g_tab_ev[i], hipEventDisableTiming);
+    g_tab_init = true;
+  }
+  const int slot = g_tab_next;
+  g_tab_next = (g_tab_next + 1) % TAB_RING;
+  if (g_tab_used[slot]) (void)hipEventSynchronize(g_tab_ev[slot]);  // its last consumer: normally long finished
+  if ((size_t)3 * g.V > g_tab_elems[slot]) {
+    if (g_tab[slot]) (void)hipFree(g_tab[slot]);
+    g_tab[slot] = nullptr;
+    g_tab_elems[slot] = (size_t)3 * g.V * 2;
+    if (hipMalloc(&g_tab[slot], g_tab_elems[slot] * sizeof(unsigned)) != hipSuccess) {
+      g_tab_elems[slot] = 0;
       return 1;
     }
   }
-  g.tab = g_tab;
-  hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((g.V + 255) / 256), dim3(256), 0, stream, g, g_tab);
+  g.tab = g_tab[slot];
+  hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((g.V + 255) / 256), dim3(256), 0, stream, g, g_tab[slot]);
   g.dbg = carca_debug_buffer();
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 3 && g.dbg)
     hipLaunchKernelGGL(gemm_wgrad_cu_kernel<1>, dim3(grid), dim3(WG_NT), 0, stream, g);
   else
     hipLaunchKernelGGL(gemm_wgrad_cu_kernel<0>, dim3(grid), dim3(WG_NT), 0, stream, g);
+  (void)hipEventRecord(g_tab_ev[slot], stream);
+  g_tab_used[slot] = true;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     carca_set_error("HIP launch failed: %s", hipGetErrorString(e));
