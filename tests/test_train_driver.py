@@ -29,12 +29,13 @@ def _write_dataset(tmp, n_users=40, n_items=60, n_attrs=12, n_ctx=3, seed=0):
         fh.write("\n".join(lines) + "\n")
 
 
-def test_training_script_wiring_end_to_end(tmp_path, monkeypatch):
+@pytest.mark.parametrize("decoder", ["ca", "dot"])  # --decoder ca, and the CLI default --decoder dot (training.py:60)
+def test_training_script_wiring_end_to_end(tmp_path, monkeypatch, decoder):
     import torch.nn as nn
     from torch.optim import Adam
     from torch.utils.data import DataLoader
 
-    from src.carca import CARCA, AllEmbedding, CrossAttentionBlock, IdentityEncoding, SelfAttentionBlock
+    from src.carca import CARCA, AllEmbedding, CrossAttentionBlock, DotProduct, IdentityEncoding, SelfAttentionBlock
     from src.data import CARCADataset, load_attrs, load_ctx, load_profiles, set_datapath
     from src.train import evaluate, train
 
@@ -54,7 +55,8 @@ def test_training_script_wiring_end_to_end(tmp_path, monkeypatch):
     d, g, H, p = 64, 48, 2, 0.2
     emb = AllEmbedding(n_items, d, g, n_ctx, n_attrs, IdentityEncoding())
     enc = nn.ModuleList([SelfAttentionBlock(d, H, p, True) for _ in range(2)])
-    model = CARCA(d=d, p=p, emb=emb, enc=enc, dec=CrossAttentionBlock(d, H, p, True)).to("cuda")
+    dec = CrossAttentionBlock(d, H, p, True) if decoder == "ca" else DotProduct()
+    model = CARCA(d=d, p=p, emb=emb, enc=enc, dec=dec).to("cuda")
     optim = Adam(model.parameters(), lr=1e-3, weight_decay=0.0, betas=(0.9, 0.98))
     hr0, ndcg0, loss0 = evaluate(model, val_loader, "cuda", 10)
     model = train(model=model, train_loader=train_loader, val_loader=val_loader, test_loader=test_loader, device="cuda",
