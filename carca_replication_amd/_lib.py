@@ -219,6 +219,7 @@ SIGNATURES = {
     "carca_slot_decay_scale": (_i, [_fp, _i, _fp, _i, _i, _i, _i, _f, _fp]),
     "carca_l2norm_fwd": (_i, [_fp, _i, _fp, _i, _i, _i, _fp]),
     "carca_l2norm_bwd": (_i, [_fp, _i, _fp, _i, _fp, _i, _i, _i, _fp]),
+    "carca_knn_score": (_i, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _i, _fp, _i, _i, _i, _i, _fp]),
     "carca_build_eval_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,
                                     _fp]),
     "carca_build_train_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,

@@ -4,6 +4,8 @@
 //                                                  y = sigmoid(p' . o) or (p' . o + 1) / 2
 // plus the stand-alone final LayerNorm (carca.py:421) that the cross-attention kernel otherwise fuses.
 // One wave per row, two features per lane (d <= 128): HBM/latency-bound row work, nothing to tile.
+// Also here, because it is the same row-dot shape: the reference's KNN baseline model (knn.py:8-21),
+//   y[b][t] = attrs(last profile slot of b) . attrs(target t)   over n_attrs features, no link, no parameters.
 #include "attn_common.h"
 #include "../../include/carca_hip.h"
 
@@ -119,6 +121,54 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
   }
 }
 
+// KNN.forward (knn.py:13-19): one wave per target row; the user's last profile row is re-read by its T targets out of
+// L1/L2 (16 KB at n_attrs = 4096), the target rows stream from HBM exactly once: HBM-bound, B*T*F*4 bytes.
+// table_rows > 0: rows are gathered from the attribute table by id (ids outside the table read as zero rows).
+template <bool VEC>
+__global__ __launch_bounds__(256) void knn_score_kernel(const float* __restrict__ p_a, long p_bstride,
+                                                        const float* __restrict__ o_a, long o_bstride,
+                                                        const int32_t* __restrict__ p_x, const int32_t* __restrict__ o_x,
+                                                        int table_rows, float* __restrict__ y, int B, int L, int T, int F) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < B * T; row += gridDim.x * 4) {
+    const int b = row / T;
+    const float *pr, *orow;
+    bool live = true;
+    if (table_rows > 0) {
+      const int pi = p_x[(size_t)b * L + L - 1], oi = o_x[row];
+      live = pi >= 0 && pi < table_rows && oi >= 0 && oi < table_rows;
+      pr = p_a + (size_t)(live ? pi : 0) * F;
+      orow = p_a + (size_t)(live ? oi : 0) * F;
+    } else {
+      pr = p_a + (size_t)b * p_bstride + (size_t)(L - 1) * F;
+      orow = o_a + (size_t)b * o_bstride + (size_t)(row - b * T) * F;
+    }
+    float s = 0.f;
+    if (VEC) {
+      const float4* p4 = reinterpret_cast<const float4*>(pr);
+      const float4* o4 = reinterpret_cast<const float4*>(orow);
+      const int n4 = F >> 2;
+      int i = lane;
+      for (; i + 192 < n4; i += 256) {  // 4 independent 16-byte loads per operand in flight
+        const float4 a0 = o4[i], a1 = o4[i + 64], a2 = o4[i + 128], a3 = o4[i + 192];
+        const float4 c0 = p4[i], c1 = p4[i + 64], c2 = p4[i + 128], c3 = p4[i + 192];
+        s += a0.x * c0.x + a0.y * c0.y + a0.z * c0.z + a0.w * c0.w;
+        s += a1.x * c1.x + a1.y * c1.y + a1.z * c1.z + a1.w * c1.w;
+        s += a2.x * c2.x + a2.y * c2.y + a2.z * c2.z + a2.w * c2.w;
+        s += a3.x * c3.x + a3.y * c3.y + a3.z * c3.z + a3.w * c3.w;
+      }
+      for (; i < n4; i += 64) {
+        const float4 a0 = o4[i], c0 = p4[i];
+        s += a0.x * c0.x + a0.y * c0.y + a0.z * c0.z + a0.w * c0.w;
+      }
+    } else {
+      for (int i = lane; i < F; i += 64) s += pr[i] * orow[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[row] = live ? s : 0.f;
+  }
+}
+
 inline int row_blocks(int rows) { return min((rows + 3) / 4, 4096); }
 
 }  // namespace
@@ -154,6 +204,28 @@ extern "C" int carca_dot_score_bwd(const float* p, int ldp, const float* o, int 
   CARCA_CHECK_SUPPORTED(d <= 128 && ld_do <= 128, "dot_score_bwd: d=%d / ld_do=%d > 128", d, ld_do);
   hipLaunchKernelGGL(dot_score_bwd_kernel, dim3(row_blocks(B * T)), dim3(256), 0, (hipStream_t)stream_, p, ldp, o, ldo, y,
                      dy, dp, ld_dp, d_o, ld_do, B, L, T, d, slotwise, link);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_knn_score(const float* p_a, int64_t p_bstride, const float* o_a, int64_t o_bstride,
+                               const int32_t* p_x, const int32_t* o_x, int table_rows, float* y, int B, int L, int T,
+                               int F, void* stream_) {
+  CARCA_CHECK_ARG(p_a && y && B >= 1 && L >= 1 && T >= 1 && F >= 1 && table_rows >= 0, "knn_score: bad arguments");
+  CARCA_CHECK_ARG(table_rows > 0 || (p_bstride >= (int64_t)L * F && o_bstride >= (int64_t)T * F),
+                  "knn_score: user strides %lld / %lld shorter than a user's rows", (long long)p_bstride,
+                  (long long)o_bstride);
+  CARCA_CHECK_ARG(table_rows > 0 ? (p_x && o_x) : o_a != nullptr, "knn_score: %s", table_rows > 0 ? "table mode needs p_x and o_x" : "dense mode needs o_a");
+  CARCA_CHECK_SUPPORTED((long long)B * T < (1ll << 31), "knn_score: B*T=%lld rows", (long long)B * T);
+  const bool vec = F % 4 == 0 && ((uintptr_t)p_a & 15) == 0 &&
+                   (table_rows > 0 || (((uintptr_t)o_a & 15) == 0 && p_bstride % 4 == 0 && o_bstride % 4 == 0));
+  const dim3 grid(min((B * T + 3) / 4, 16384));
+  if (vec)
+    hipLaunchKernelGGL(knn_score_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream_, p_a, (long)p_bstride, o_a,
+                       (long)o_bstride, p_x, o_x, table_rows, y, B, L, T, F);
+  else
+    hipLaunchKernelGGL(knn_score_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream_, p_a, (long)p_bstride, o_a,
+                       (long)o_bstride, p_x, o_x, table_rows, y, B, L, T, F);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

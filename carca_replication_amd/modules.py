@@ -920,6 +920,36 @@ class CARCA(_PackedModule, Model):
 
 
 # ------------------------------------------------------------------------------------------------
+# KNN baseline (knn.py:8-21)
+# ------------------------------------------------------------------------------------------------
+
+
+class KNN(Model):
+    """The reference's attribute-similarity baseline: score = attrs(last profile item) . attrs(target), no parameters.
+    Extension: register_attr_table(attrs) lets profile/target attribute tensors be None (rows gathered by id on the
+    device), as for AllEmbedding."""
+
+    def __init__(self):
+        super().__init__()
+        self._attr_table: Optional[Tensor] = None
+
+    def register_attr_table(self, attrs: Optional[Tensor]) -> None:
+        self._attr_table = None if attrs is None else attrs.detach().to(torch.float32).contiguous()
+
+    def forward(self, profile: Tuple[Tensor, Tensor, Tensor], targets: List[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
+        p_x, p_a, p_c = profile
+        ys = []
+        for o_x, o_a, o_c in targets:
+            if p_a is None or o_a is None:
+                if self._attr_table is None:
+                    raise ValueError("KNN: attribute tensors are None and no table is registered (register_attr_table)")
+                ys.append(ops.knn_score(None, None, p_x, o_x, table=self._attr_table))
+            else:
+                ys.append(ops.knn_score(p_a, o_a))
+        return torch.cat(ys, dim=-1)  # knn.py:21
+
+
+# ------------------------------------------------------------------------------------------------
 # loss (carca.py:437-444)
 # ------------------------------------------------------------------------------------------------
 

@@ -664,6 +664,45 @@ def dot_score_bwd(p: Tensor, o: Tensor, y: Tensor, dy: Tensor, dp: Tensor, B: in
     return d_o
 
 
+def _user_rows(t: Tensor, name: str) -> Tensor:
+    """[B, T, F] fp32 with contiguous rows per user (any user stride): as is; anything else: one contiguous copy."""
+    _need_cuda(t)
+    if t.dtype != torch.float32:
+        raise CarcaHipError(f"{name}: expected float32, got {t.dtype}")
+    if t.dim() != 3:
+        raise ValueError(f"{name}: expected [B, T, F], got {tuple(t.shape)}")
+    ok = t.stride(2) == 1 and t.stride(1) == t.shape[2] and t.stride(0) >= t.shape[1] * t.shape[2]
+    return t if ok or t.numel() == 0 else t.contiguous()
+
+
+def knn_score(p_a: Optional[Tensor], o_a: Optional[Tensor], p_x: Optional[Tensor] = None, o_x: Optional[Tensor] = None,
+              table: Optional[Tensor] = None) -> Tensor:
+    """KNN.forward for one target group (knn.py:13-19): y [B, T] = attrs(last profile slot) . attrs(target).
+    Dense: p_a [B, L, F], o_a [B, T, F] (views with a user stride, e.g. torch.split halves, are read in place).
+    Table: `table` [rows, F] with p_x [B, L], o_x [B, T] int32 ids."""
+    lib = _lib.load()
+    if table is not None:
+        _need_cuda(table, p_x, o_x)
+        table, p_x, o_x = _f32(table), _ids32(p_x), _ids32(o_x)
+        B, L = p_x.shape
+        T, F = o_x.shape[1], table.shape[1]
+        y = torch.empty(B, T, dtype=torch.float32, device=table.device)
+        args = (table.data_ptr(), 0, None, 0, p_x.data_ptr(), o_x.data_ptr(), table.shape[0])
+    else:
+        p_a, o_a = _user_rows(p_a, "knn_score: p_a"), _user_rows(o_a, "knn_score: o_a")
+        B, L, F = p_a.shape
+        T = o_a.shape[1]
+        if o_a.shape[0] != B or o_a.shape[2] != F:
+            raise ValueError(f"knn_score: targets {tuple(o_a.shape)} do not match profile {tuple(p_a.shape)}")
+        y = torch.empty(B, T, dtype=torch.float32, device=p_a.device)
+        args = (p_a.data_ptr(), p_a.stride(0), o_a.data_ptr(), o_a.stride(0), None, None, 0)
+    if B * T and L and F:
+        _lib.check(lib.carca_knn_score(*args, y.data_ptr(), B, L, T, F, _stream()), "knn_score")
+    elif B * T:
+        y.zero_()
+    return y
+
+
 def slot_decay_scale(x: Tensor, B: int, L: int, d: int, gamma: float, out_ld: int) -> Tensor:
     """out[b][t] = x[b][t] * sum_{j<=t} gamma^j (WeightedDotProduct's history weights; its own backward); [B*L, out_ld]."""
     lib = _lib.load()

@@ -317,6 +317,16 @@ int carca_slot_decay_scale(const float* x, int ldx, float* out, int ldo, int B, 
 int carca_l2norm_fwd(const float* x, int ldx, float* y, int ldy, int rows, int d, void* stream);
 int carca_l2norm_bwd(const float* x, int ldx, const float* dy, int ld_dy, float* dx, int ld_dx, int rows, int d,
                      void* stream);
+/* KNN.forward (knn.py:13-19), the reference's attribute-similarity baseline model: y[b][t] = p_last(b) . o(b, t) over
+ * the F attribute features, p_last = the LAST profile slot's attribute row (knn.py:14); raw dot product, no link.
+ *   table_rows == 0: p_a is the dense [B, L, F] profile attributes, o_a the dense [B, T, F] target attributes, rows
+ *                    contiguous, user b at p_a + b*p_bstride / o_a + b*o_bstride floats (so the two train groups may
+ *                    be the halves of one [B, 2L, F] tensor, train.py:86-88); p_x / o_x unused, may be NULL;
+ *   table_rows  > 0: p_a is the attribute table [table_rows, F] (o_a unused); rows are p_x[b][L-1] and o_x[b][t]
+ *                    (p_x [B, L], o_x [B*T], both contiguous; strides unused); ids outside the table score 0.
+ * HBM-bound: B*T*F*4 bytes streamed once. */
+int carca_knn_score(const float* p_a, int64_t p_bstride, const float* o_a, int64_t o_bstride, const int32_t* p_x,
+                    const int32_t* o_x, int table_rows, float* y, int B, int L, int T, int F, void* stream);
 /* Inverse of carca_pack_weights for gradients: real[r][c] (+)= packed[rp][cp] (same descriptor fields:
  * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
 int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);

@@ -172,6 +172,15 @@ def dot_decoder(cfg: CarcaConfig, o: Tensor, p: Tensor, training: bool) -> Tenso
 
 
 # --------------------------------------------------------------------------- #
+# f4: KNN baseline model                                          knn.py:8-21 #
+# --------------------------------------------------------------------------- #
+def knn_forward(profile: Tuple[Tensor, Tensor, Tensor], targets: List[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
+    """score = attribute row of the LAST profile slot (knn.py:14) . attribute row of each target (knn.py:18)."""
+    last = profile[1][:, -1:, :]
+    return torch.cat([(last * o_a).sum(dim=-1) for _, o_a, _ in targets], dim=-1)
+
+
+# --------------------------------------------------------------------------- #
 # a3: MultiHeadAttention.forward                            carca.py:228-265  #
 # --------------------------------------------------------------------------- #
 def layer_norm(x: Tensor, w: Tensor, b: Tensor) -> Tensor:

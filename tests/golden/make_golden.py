@@ -20,6 +20,9 @@ seeded inputs and storing inputs, weights and outputs as small .npz files:
   g9_<variant>.npz ablation embeddings (attrctx, attr, id, mlpid) and decoders (dot, wdot, wdot + l2 norm):
                  eval scores + loss, train-mode scores + loss + all grads   (carca.py:98-198,352-399)
 
+  g10_knn.npz    the KNN baseline model's scores (knn.py:8-21): eval shape with one group, train shape with two groups,
+                 attribute widths 32 (vector path) and 37 (ragged)
+
 Only data is written: inputs and the reference's outputs.
 """
 import os
@@ -355,9 +358,32 @@ def main_g9():
         save("g9_" + vname, cfg, dims, model.state_dict(), ins, outs)
 
 
+def main_g10():
+    from src.knn import KNN  # the reference's
+
+    model = KNN().eval()
+    ins, outs = {}, {}
+    for tag, n_attrs in (("f32", 32), ("f37", 37)):
+        B, L, N, n_items, n_ctx = 6, 12, 21, 300, 3
+        x = make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed=31, distinct=True)
+        xt = make_inputs(B, L, N, n_items, n_attrs, n_ctx, seed=32, train_shape=True)
+        with torch.no_grad():
+            y = model.forward(profile=(x["p_x"], x["p_a"], x["p_c"]), targets=[(x["o_x"], x["o_a"], x["o_c"])])
+            pos = tuple(xt[k][:, :L] for k in ("o_x", "o_a", "o_c"))
+            neg = tuple(xt[k][:, L:] for k in ("o_x", "o_a", "o_c"))
+            yt = model.forward(profile=(xt["p_x"], xt["p_a"], xt["p_c"]), targets=[pos, neg])
+        ins.update({f"{tag}/{k}": v for k, v in x.items()})
+        ins.update({f"{tag}/train/{k}": v for k, v in xt.items()})
+        outs[f"{tag}/y"] = y
+        outs[f"{tag}/train/y"] = yt
+    save("g10_knn", {}, dict(B=6, L=12, N=21), {}, ins, outs)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g9":
-        main_g9()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "main"):
         main()
+    if which in ("all", "g9"):
         main_g9()
+    if which in ("all", "g10"):
+        main_g10()

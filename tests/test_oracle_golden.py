@@ -157,6 +157,21 @@ def test_g9_ablation_embeddings_and_decoders(name):
     _check_train(fx, in_prefix="train/", out_prefix="train/")
 
 
+@pytest.mark.parametrize("tag", ["f32", "f37"])
+def test_g10_knn_baseline(tag):
+    """The KNN baseline model (knn.py:8-21): one eval group and the two train groups."""
+    fx = load("g10_knn")
+    L = fx.dim["L"]
+    i = {k[len(tag) + 1:]: v for k, v in fx.ins.items() if k.startswith(tag + "/")}
+    y = O.knn_forward((i["p_x"], i["p_a"], i["p_c"]), [(i["o_x"], i["o_a"], i["o_c"])])
+    assert y.shape == fx.outs[tag + "/y"].shape
+    assert torch.allclose(y, fx.outs[tag + "/y"], atol=1e-5, rtol=1e-6)
+    pos = tuple(i["train/" + k][:, :L] for k in ("o_x", "o_a", "o_c"))
+    neg = tuple(i["train/" + k][:, L:] for k in ("o_x", "o_a", "o_c"))
+    yt = O.knn_forward((i["train/p_x"], i["train/p_a"], i["train/p_c"]), [pos, neg])
+    assert torch.allclose(yt, fx.outs[tag + "/train/y"], atol=1e-5, rtol=1e-6)
+
+
 def test_g8_ranking_after_training():
     fx = load("g8_ranking")
     cfg = oracle_config(fx.cfg)
