@@ -124,7 +124,9 @@ def measure_train(c, model, rank, world, device, steps):
     y_true = torch.cat([(px != 0).int(), torch.zeros_like(px)], dim=1)
     batch = tuple(t.to(device) for t in (profile[0], profile[1], profile[2], o_x, o_a, o_c, y_true))
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98), fused=True)  # training.py:174, one launch
+    from carca_replication_amd.optim import Adam
+
+    opt = Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))  # training.py:174's update, one launch for all tensors
     for _ in range(2):
         engine.train_step(model, opt, batch, sharded=world > 1)
     torch.cuda.synchronize()

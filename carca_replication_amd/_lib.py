@@ -18,7 +18,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libcarca_hip.so")
 _STAMP = LIB_PATH + ".srchash"
-SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip"]
+SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip", "optim.hip"]
 HEADERS = ["carca_common.h", "attn_common.h"]
 
 MAX_SEGS = 4
@@ -154,6 +154,10 @@ class CrossBwdGroup(C.Structure):
                 ("N", C.c_int32)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("n", C.c_int64)]
+
+
 class SaWeights(C.Structure):
     _fields_ = [(n, _fp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wk", "wv", "bq", "bk", "bv", "w1", "w2",
                                    "b1", "b2")]
@@ -220,6 +224,8 @@ SIGNATURES = {
     "carca_l2norm_fwd": (_i, [_fp, _i, _fp, _i, _i, _i, _fp]),
     "carca_l2norm_bwd": (_i, [_fp, _i, _fp, _i, _fp, _i, _i, _i, _fp]),
     "carca_knn_score": (_i, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _i, _fp, _i, _i, _i, _i, _fp]),
+    "carca_adam_step": (_i, [C.POINTER(AdamTensor), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i,
+                        _fp]),
     "carca_build_eval_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,
                                     _fp]),
     "carca_build_train_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,

@@ -82,10 +82,11 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after):
     g_ffn_w, g_ffn_b = gbp[id(dec.ffn.weight)], gbp[id(dec.ffn.bias)]
     o_rows = [st["es"][gi + 1].view(-1, dpi) for gi in range(ngroups)]
     o_ids = [st["segs"][gi + 1][0] for gi in range(ngroups)]
-    for gi in range(ngroups):
-        ops.colsum(dls[gi].view(-1, 1), 1, g_ffn_b)                       # d ffn.bias = sum dlogit
-        if dec.residual:
-            ops.colsum(o_rows[gi], d, g_ffn_w, rowscale=dls[gi])          # residual part of d ffn.weight
+    if dec.residual:  # d ffn.bias = sum dlogit; residual part of d ffn.weight = dlogit^T . o: a 1 x d product of the group
+        wg.add([dict(dy=dls[gi].view(-1, 1), x=o_rows[gi]) for gi in range(ngroups)], 1, d, g_ffn_w.view(1, d), g_ffn_b)
+    else:
+        for gi in range(ngroups):
+            ops.colsum(dls[gi].view(-1, 1), 1, g_ffn_b)
     wp_item = ops.PackedWeights([ops.PackItem(dec.ffn.weight, 1, dpo, col_heads=(dh, dhp))], dev)
     wp_item.buf.copy_(d_wpad)                                             # attention part, head-padded
     wp_item.unpack_into([g_ffn_w], accumulate=True)
@@ -236,7 +237,9 @@ class _CarcaFn(torch.autograd.Function):
 
 
 def carca_forward_with_grad(model, profile, targets) -> List[Tensor]:
-    params = [p for p in model.parameters()]
+    from .modules import cached_parameters
+
+    params = cached_parameters(model)
     if any(t is not None and t.requires_grad for t in profile) or \
             any(t is not None and t.requires_grad for grp in targets for t in grp):
         raise CarcaHipError("gradients with respect to the input tensors (ids/attrs/ctx) are not produced")

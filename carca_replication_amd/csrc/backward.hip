@@ -30,30 +30,44 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   const float g0 = ok0 ? gamma[c0] : 0.f, g1 = ok1 ? gamma[c1] : 0.f;
   const float inv_d = 1.0f / (float)d;
   float dg0 = 0.f, dg1 = 0.f, db0 = 0.f, db1 = 0.f;
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const float* xr = x + (size_t)row * ld_x;
-    const float* dr = dy + (size_t)row * ld_dy;
-    const float x0 = ok0 ? xr[c0] : 0.f, x1 = ok1 ? xr[c1] : 0.f;
-    const float y0 = ok0 ? dr[c0] : 0.f, y1 = ok1 ? dr[c1] : 0.f;
-    const float mean = wave_sum(x0 + x1) * inv_d;
-    const float e0 = ok0 ? x0 - mean : 0.f, e1 = ok1 ? x1 - mean : 0.f;
-    const float rstd = 1.0f / sqrtf(wave_sum(e0 * e0 + e1 * e1) * inv_d + 1e-5f);
-    const float h0 = e0 * rstd, h1 = e1 * rstd;
-    const float a0 = y0 * g0, a1 = y1 * g1;
-    const float m1 = wave_sum(a0 + a1) * inv_d;
-    const float m2 = wave_sum(a0 * h0 + a1 * h1) * inv_d;
-    float o0 = rstd * (a0 - m1 - h0 * m2), o1 = rstd * (a1 - m1 - h1 * m2);
-    if (addend) {
-      const float* ar = addend + (size_t)row * ld_add;
-      if (ok0) o0 += ar[c0];
-      if (ok1) o1 += ar[c1];
+  // RPW rows per wave and pass, all their loads issued before the first reduction: the four wave reductions of a row
+  // are a ~1 us dependent chain, and rows are independent (one row per pass read 16 us at 6400 rows, four 6 us)
+  constexpr int RPW = 4;
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += gridDim.x * 4 * RPW) {
+    float xv0[RPW], xv1[RPW], yv0[RPW], yv1[RPW], av0[RPW], av1[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = min(row0 + i, rows - 1);
+      const float* xr = x + (size_t)row * ld_x;
+      const float* dr = dy + (size_t)row * ld_dy;
+      xv0[i] = ok0 ? xr[c0] : 0.f;
+      xv1[i] = ok1 ? xr[c1] : 0.f;
+      yv0[i] = ok0 ? dr[c0] : 0.f;
+      yv1[i] = ok1 ? dr[c1] : 0.f;
+      av0[i] = av1[i] = 0.f;
+      if (addend) {
+        const float* ar = addend + (size_t)row * ld_add;
+        av0[i] = ok0 ? ar[c0] : 0.f;
+        av1[i] = ok1 ? ar[c1] : 0.f;
+      }
     }
-    dg0 += y0 * h0;
-    dg1 += y1 * h1;
-    db0 += y0;
-    db1 += y1;
-    float* outr = dx + (size_t)row * ld_dx;
-    {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      if (row0 + i >= rows) break;
+      const float x0 = xv0[i], x1 = xv1[i], y0 = yv0[i], y1 = yv1[i];
+      const float mean = wave_sum(x0 + x1) * inv_d;
+      const float e0 = ok0 ? x0 - mean : 0.f, e1 = ok1 ? x1 - mean : 0.f;
+      const float rstd = 1.0f / sqrtf(wave_sum(e0 * e0 + e1 * e1) * inv_d + 1e-5f);
+      const float h0 = e0 * rstd, h1 = e1 * rstd;
+      const float a0 = y0 * g0, a1 = y1 * g1;
+      const float m1 = wave_sum(a0 + a1) * inv_d;
+      const float m2 = wave_sum(a0 * h0 + a1 * h1) * inv_d;
+      const float o0 = rstd * (a0 - m1 - h0 * m2) + av0[i], o1 = rstd * (a1 - m1 - h1 * m2) + av1[i];
+      dg0 += y0 * h0;
+      dg1 += y1 * h1;
+      db0 += y0;
+      db1 += y1;
+      float* outr = dx + (size_t)(row0 + i) * ld_dx;
       if (c0 < ncols_out) outr[c0] = ok0 ? o0 : 0.f;
       if (c1 < ncols_out) outr[c1] = ok1 ? o1 : 0.f;
     }
@@ -575,7 +589,9 @@ extern "C" int carca_layernorm_bwd(const float* dy, int ld_dy, const float* x, i
   CARCA_CHECK_SUPPORTED(d <= 128, "layernorm_bwd: d=%d > 128", d);
   CARCA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
   CARCA_CHECK_ARG(ncols_out <= ld_dx && ncols_out <= 128 && ld_dy >= d && ld_x >= d, "layernorm_bwd: bad strides");
-  const int blocks = min((rows + 31) / 32, 256);  // >= 8 rows per wave: few blocks contend on dgamma/dbeta
+  // few blocks: every block ends with 2d atomics on the SAME dgamma / dbeta addresses, which serialise in L2
+  // (6400 rows: 400 blocks 18.7 us, 200 blocks one row per pass 16 us)
+  const int blocks = min((rows + 63) / 64, 128);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, ld_dy, x, ld_x, gamma, rows, d,
                      addend, ld_add, dx, ld_dx, ncols_out, dgamma, dbeta);
   CARCA_LAUNCH_CHECK();

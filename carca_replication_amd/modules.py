@@ -553,6 +553,25 @@ class MultiHeadAttention(nn.Module):
                             "call the block instead")
 
 
+def cached_parameters(module: nn.Module) -> List[nn.Parameter]:
+    """list(module.parameters()) without walking the module tree on every call (0.25 ms per train step at C2).
+    The cached list is revalidated against the tree it was built from -- every _parameters / _modules dict of the
+    subtree must still hold the same objects -- so replacing a parameter or a sub-module is picked up."""
+    c = module.__dict__.get("_param_cache")
+    if c is not None:
+        sizes, checks, params = c
+        if all(len(d) == n for d, n in sizes) and all(d.get(k) is o for d, k, o in checks):
+            return params
+    sizes, checks = [], []
+    for m in module.modules():
+        for d in (m._parameters, m._modules):
+            sizes.append((d, len(d)))
+            checks.extend((d, k, o) for k, o in d.items())
+    params = list(module.parameters())
+    module.__dict__["_param_cache"] = (sizes, checks, params)
+    return params
+
+
 class _PackedModule:
     """Mixin: (re)packs this module's parameters into the kernels' layout when any of them changed."""
 
@@ -572,7 +591,7 @@ class _PackedModule:
 
     def __getstate__(self):  # torch.save(model) pickles whole modules (train.py:124): drop the ctypes caches
         state = dict(super().__getstate__())
-        for k in ("_pack_cache", "_final_norm_params", "_plan", "_fold_cache"):
+        for k in ("_pack_cache", "_final_norm_params", "_plan", "_fold_cache", "_param_cache"):
             state.pop(k, None)
         return state
 
@@ -596,7 +615,7 @@ class SelfAttentionBlock(_PackedModule, Encoder):
 
     # -- packing -------------------------------------------------------------------------------
     def _pack_params(self):
-        return list(self.parameters())
+        return cached_parameters(self)
 
     def _pack_shape(self):
         return (self.attn.d, self.attn.H)
@@ -654,7 +673,7 @@ class CrossAttentionBlock(_PackedModule, Decoder):
 
     def _pack_params(self):
         extra = list(self.__dict__.get("_final_norm_params", ()))
-        return list(self.parameters()) + extra
+        return cached_parameters(self) + extra
 
     def _pack_shape(self):
         return (self.attn.d, self.attn.H, len(self.__dict__.get("_final_norm_params", ())))
@@ -755,7 +774,7 @@ class CARCA(_PackedModule, Model):
 
     def forward(self, profile: Tuple[Tensor, Tensor, Tensor], targets: List[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
         self._check_built()
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in cached_parameters(self))
         if needs_grad:
             from .autograd import carca_forward_with_grad
 

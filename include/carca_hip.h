@@ -331,6 +331,21 @@ int carca_knn_score(const float* p_a, int64_t p_bstride, const float* o_a, int64
  * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
 int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);
 
+/* ---- f3: the optimizer step of the train driver (training.py:174, train.py:96) -------------------------------
+ * torch.optim.Adam's update (no amsgrad; weight_decay added to the gradient) for every tensor of the table in one
+ * launch: g += wd*p; m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+ * `tensors` is a HOST array of n entries (device pointers, n elements each, fp32); step = t >= 1.  The scalar
+ * hyper-parameters arrive as doubles and are combined in double before one rounding to fp32, as torch does. */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} CarcaAdamTensor;
+int carca_adam_step(const CarcaAdamTensor* tensors, int n, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int step, void* stream);
+
 /* ---- f1: batch construction on the device (data.py:53-192) ---------------------------------------------------
  * The interaction log lives in HBM as CSR: user u owns hist[offs[u] .. offs[u+1]) (item ids in interaction order) and
  * the context rows hctx[offs[u] ..] of those interactions (hctx[pos] = ctx[(user, hist[pos])], data.py:17-25).

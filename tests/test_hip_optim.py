@@ -1,0 +1,93 @@
+"""carca_replication_amd.optim.Adam (one launch per step, carca_adam_step) against torch.optim.Adam, the optimizer
+scripts/training.py:174 builds.  Same formula, fp32: trajectories agree to a few ulp per step (torch's fused / foreach
+kernels contract multiply-adds differently), bound written below."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    return a, b
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_adam_matches_torch(wd):
+    from carca_replication_amd.optim import Adam
+
+    shapes = [(1,), (3, 5), (1024,), (1025,), (90, 540), (7, 1, 13), (300000,)]
+    a, b = _pair(shapes, 3)
+    ours = Adam(a, lr=1e-3, betas=(0.9, 0.98), weight_decay=wd)
+    ref = torch.optim.Adam(b, lr=1e-3, betas=(0.9, 0.98), weight_decay=wd)
+    g = torch.Generator().manual_seed(4)
+    for step in range(6):
+        for p, q in zip(a, b):
+            grad = (torch.randn(p.shape, generator=g) * (0.1 + step)).cuda()
+            p.grad, q.grad = grad.clone(), grad.clone()
+        ours.step()
+        ref.step()
+        for p, q in zip(a, b):
+            # every step moves a weight by <= lr; the two implementations differ by rounding only
+            assert float((p - q).abs().max()) <= 2e-6 * (step + 1), (step, tuple(p.shape))
+    for p, q in zip(a, b):
+        so, sr = ours.state[p], ref.state[q]
+        assert float(so["step"]) == float(sr["step"]) == 6
+        # gradients reach 5: rounding of the cancelling terms is ~1e-6 absolute on m, relative on v
+        assert torch.allclose(so["exp_avg"], sr["exp_avg"], rtol=1e-5, atol=2e-6)
+        assert torch.allclose(so["exp_avg_sq"], sr["exp_avg_sq"], rtol=1e-5, atol=1e-7)
+
+
+def test_adam_state_dict_interchangeable_with_torch():
+    from carca_replication_amd.optim import Adam
+
+    a, b = _pair([(17, 9), (130,)], 5)
+    ours = Adam(a, lr=2e-3, betas=(0.9, 0.98))
+    for p in a:
+        p.grad = torch.ones_like(p)
+    ours.step()
+    ours.step()
+    ref = torch.optim.Adam(b, lr=2e-3, betas=(0.9, 0.98))
+    ref.load_state_dict(copy.deepcopy(ours.state_dict()))          # ours -> torch (deep copy: load shares tensors)
+    for p, q in zip(a, b):
+        q.data.copy_(p.data)
+        p.grad = torch.full_like(p, 0.5)
+        q.grad = torch.full_like(q, 0.5)
+    ours.step()
+    ref.step()
+    for p, q in zip(a, b):
+        assert float((p - q).abs().max()) <= 1e-6
+    a2, _ = _pair([(17, 9), (130,)], 5)
+    back = Adam(a2, lr=2e-3, betas=(0.9, 0.98))
+    back.load_state_dict(copy.deepcopy(ref.state_dict()))          # torch -> ours: step counts carry over
+    for p2, q in zip(a2, b):
+        p2.data.copy_(q.data)
+        p2.grad = torch.full_like(p2, -0.25)
+        q.grad = torch.full_like(q, -0.25)
+    back.step()
+    ref.step()
+    for p2, q in zip(a2, b):
+        assert float(back.state[p2]["step"]) == 4
+        assert float((p2 - q).abs().max()) <= 1e-6
+
+
+def test_adam_skips_parameters_without_gradient_and_rejects_bad_input():
+    from carca_replication_amd.optim import Adam
+    from carca_replication_amd.ops import CarcaHipError
+
+    a, _ = _pair([(8,), (8,)], 6)
+    before = a[1].detach().clone()
+    opt = Adam(a, lr=1e-2)
+    a[0].grad = torch.ones_like(a[0])
+    opt.step()
+    assert torch.equal(a[1], before) and not opt.state[a[1]]
+    with pytest.raises(ValueError):
+        Adam(a, lr=-1.0)
+    cpu = [torch.nn.Parameter(torch.zeros(4))]
+    cpu[0].grad = torch.ones(4)
+    with pytest.raises(CarcaHipError):
+        Adam(cpu).step()
