@@ -102,7 +102,7 @@ _fp = C.c_void_p  # device pointers travel as integers
 class PackDesc(C.Structure):
     _fields_ = [("src", _fp), ("dst", _fp), ("rows", C.c_int32), ("cols", C.c_int32), ("src_ld", C.c_int32),
                 ("dst_rows", C.c_int32), ("dst_cols", C.c_int32), ("row_dh", C.c_int32), ("row_dhp", C.c_int32),
-                ("col_dh", C.c_int32), ("col_dhp", C.c_int32), ("transposed", C.c_int32)]
+                ("col_dh", C.c_int32), ("col_dhp", C.c_int32), ("transposed", C.c_int32), ("frag16", C.c_int32)]
 
 
 class RowSeg(C.Structure):

@@ -52,7 +52,12 @@ __global__ void pack_kernel(const PackArgs pa) {
   const CarcaPackDesc& ds = pa.d[blockIdx.y];
   const int total = ds.dst_rows * ds.dst_cols;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int rp = i / ds.dst_cols, cp = i - rp * ds.dst_cols;
+    int rp = i / ds.dst_cols, cp = i - rp * ds.dst_cols;
+    if (ds.frag16) {  // i = ((tile_row * tiles_per_row + tile_col) * 64 + lane) * 4 + r, lane = 16 * mq + ln
+      const int t = i >> 8, nkg = ds.dst_cols >> 4;
+      rp = 16 * (t / nkg) + ((i >> 2) & 15);
+      cp = 16 * (t % nkg) + 4 * ((i >> 6) & 3) + (i & 3);
+    }
     const int r = ds.row_dh > 0 ? unpad_feature(rp, ds.row_dh, ds.row_dhp) : rp;
     const int c = ds.col_dh > 0 ? unpad_feature(cp, ds.col_dh, ds.col_dhp) : cp;
     float v = 0.f;
@@ -84,6 +89,7 @@ extern "C" int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumul
     const CarcaPackDesc& d = descs[i];
     CARCA_CHECK_ARG(d.src && d.dst && d.rows >= 1 && d.cols >= 1 && d.dst_rows >= 1 && d.dst_cols >= 1,
                     "unpack_grads: descriptor %d malformed", i);
+    CARCA_CHECK_ARG(!d.frag16, "unpack_grads: descriptor %d is in fragment order (forward-only layout)", i);
   }
   for (int base = 0; base < n; base += PACK_CHUNK) {
     PackArgs pa{};
@@ -106,6 +112,8 @@ extern "C" int carca_pack_weights(const CarcaPackDesc* descs, int n, void* strea
     CARCA_CHECK_ARG((d.row_dh == 0) == (d.row_dhp == 0) && (d.col_dh == 0) == (d.col_dhp == 0) &&
                         d.row_dh <= d.row_dhp && d.col_dh <= d.col_dhp,
                     "pack_weights: descriptor %d has inconsistent head padding", i);
+    CARCA_CHECK_ARG(!d.frag16 || (d.dst_rows % 16 == 0 && d.dst_cols % 16 == 0),
+                    "pack_weights: descriptor %d: fragment order needs dst dims that are multiples of 16", i);
   }
   for (int base = 0; base < n; base += PACK_CHUNK) {
     PackArgs pa{};

@@ -55,6 +55,17 @@ __device__ __forceinline__ bool drop_keep(const DropCfg& c, unsigned site, unsig
   return (x >> 8) >= c.thresh;
 }
 
+// Weight matrices reach these kernels in FRAGMENT ORDER (CarcaPackDesc.frag16): element offset of the four k values
+// lane (ln, mq) needs from the 16x16 tile (row tile rt, k group kg) of a matrix with NKG k groups per row.  One wave
+// load = 1 KB contiguous (8 full lines); row-major it was 16 half-used lines and the loads cost 15 k of the 21 k
+// cycles of the K/V phase (measured with the loads / the MFMAs switched off in turn).
+__device__ __forceinline__ int wfrag_off(int rt, int kg, int nkg, int lane) { return ((rt * nkg + kg) * 64 + lane) * 4; }
+
+// Left alone, hipcc (128-VGPR budget of the 1024-thread kernels) sinks most of a tile's weight-fragment loads between
+// its MFMA groups, so that their L2 latencies chain (3 exposed latencies per 24-MFMA tile in the ISA).  A scheduling
+// barrier right after the loads keeps all of them in flight before the first MFMA waits.
+#define CARCA_PIN_LOADS() __builtin_amdgcn_sched_barrier(0)
+
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 glb4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 zero4() {
@@ -84,12 +95,12 @@ __device__ __forceinline__ void proj_tile_feat_major(const float* __restrict__ W
                                                      int lane, float* __restrict__ save = nullptr, int dpo = 0,
                                                      int L = 0) {
   const int ln = lane & 15, mq = lane >> 4;
-  const int woff = (16 * ft + ln) * DPI + 4 * mq;
   const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
   f32x4 wf[DPI / 16];  // all weight fragments first: their latencies overlap instead of chaining
 #pragma unroll
-  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = gload4(Wp, woff + 16 * kg);
+  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = gload4(Wp, wfrag_off(ft, kg, DPI / 16, lane));
   const f32x4 bias = gload4(bp, 16 * ft + 4 * mq);
+  CARCA_PIN_LOADS();
   f32x4 acc = zero4();
 #pragma unroll
   for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(wf[kg], lds4(xrow + 16 * kg), acc);
@@ -107,12 +118,12 @@ __device__ __forceinline__ void proj_tile_slot_major(const float* __restrict__ W
                                                      int lane, float* __restrict__ save = nullptr, int dpo = 0,
                                                      int L = 0) {
   const int ln = lane & 15, mq = lane >> 4;
-  const int woff = (16 * ft + ln) * DPI + 4 * mq;
   const float* xrow = xs + (16 * st + ln) * si + 4 * mq;
   f32x4 wf[DPI / 16];
 #pragma unroll
-  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = gload4(Wp, woff + 16 * kg);
+  for (int kg = 0; kg < DPI / 16; ++kg) wf[kg] = gload4(Wp, wfrag_off(ft, kg, DPI / 16, lane));
   const float bias = gload1(bp, 16 * ft + ln);
+  CARCA_PIN_LOADS();
   f32x4 acc = zero4();
 #pragma unroll
   for (int kg = 0; kg < DPI / 16; ++kg) acc = mfma16_group(lds4(xrow + 16 * kg), wf[kg], acc);
@@ -146,11 +157,11 @@ __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], cons
   f32x4 qt[G::NFH];
 #pragma unroll
   for (int ft = 0; ft < G::NFH; ++ft) {
-    const int woff = (h * DHP + 16 * ft + ln) * DPI + 4 * mq;
     f32x4 wf[G::NKG];
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(wq, woff + 16 * kg);
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(wq, wfrag_off(h * (DHP / 16) + ft, kg, G::NKG, lane));
     const f32x4 bias = gload4(bq, h * DHP + 16 * ft + 4 * mq);
+    CARCA_PIN_LOADS();
     f32x4 acc = zero4();
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], qfrag[kg], acc);

@@ -182,12 +182,12 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
     const int qi = job / G::NKG, ft = job - qi * G::NKG;
     const int qt = own(qi);
     const int q = 16 * qt + ln;
-    const int woff = (16 * ft + ln) * DPI + 4 * mq;
     const float* srow = Xs + q * G::SI + 4 * mq;
     f32x4 wf[G::NKG];
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(w.w1, woff + 16 * kg);
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(w.w1, wfrag_off(ft, kg, G::NKG, lane));
     const f32x4 bias = gload4(w.b1, 16 * ft + 4 * mq);
+    CARCA_PIN_LOADS();
     f32x4 acc = zero4();
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], lds4(srow + 16 * kg), acc);
@@ -213,12 +213,12 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
     const int qi = job / G::NKG, ft = job - qi * G::NKG;
     const int qt = own(qi);
     const int q = 16 * qt + ln;
-    const int woff = (16 * ft + ln) * DPI + 4 * mq;
     const float* hrow = H1 + q * G::SI + 4 * mq;
     f32x4 wf[G::NKG];
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(w.w2, woff + 16 * kg);
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(w.w2, wfrag_off(ft, kg, G::NKG, lane));
     const f32x4 bias = gload4(w.b2, 16 * ft + 4 * mq);
+    CARCA_PIN_LOADS();
     f32x4 acc = zero4();
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], lds4(hrow + 16 * kg), acc);

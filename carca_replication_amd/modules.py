@@ -544,7 +544,7 @@ class MultiHeadAttention(nn.Module):
 
     def pack_items(self, dpi: int, dhp: int, dpo: int) -> List[ops.PackItem]:
         dh = self.d // self.H
-        mats = [ops.PackItem(m.weight, dpo, dpi, row_heads=(dh, dhp)) for m in (self.WQ, self.WK, self.WV)]
+        mats = [ops.PackItem(m.weight, dpo, dpi, row_heads=(dh, dhp), frag16=True) for m in (self.WQ, self.WK, self.WV)]
         vecs = [ops.PackItem(m.bias, 1, dpo, col_heads=(dh, dhp)) for m in (self.WQ, self.WK, self.WV)]
         return mats + vecs
 
@@ -626,7 +626,8 @@ class SelfAttentionBlock(_PackedModule, Encoder):
         vec = lambda t: ops.PackItem(t, 1, dpi)  # noqa: E731
         return ([vec(self.norm1.weight), vec(self.norm1.bias), vec(self.norm2.weight), vec(self.norm2.bias)]
                 + self.attn.pack_items(dpi, dhp, dpo)
-                + [ops.PackItem(self.ffn_1.weight[:, :, 0], dpi, dpi), ops.PackItem(self.ffn_2.weight[:, :, 0], dpi, dpi),
+                + [ops.PackItem(self.ffn_1.weight[:, :, 0], dpi, dpi, frag16=True),
+                   ops.PackItem(self.ffn_2.weight[:, :, 0], dpi, dpi, frag16=True),
                    vec(self.ffn_1.bias), vec(self.ffn_2.bias)])
 
     def weights_struct(self, device) -> "_lib.SaWeights":

@@ -160,6 +160,7 @@ class PackItem:
     row_heads: Tuple[int, int] = (0, 0)  # (dh, dhp) when rows are output features split into heads
     col_heads: Tuple[int, int] = (0, 0)
     transposed: bool = False  # pack src^T (dst_rows/dst_cols and the head maps refer to the transposed matrix)
+    frag16: bool = False      # MFMA-fragment order (CarcaPackDesc.frag16): the attention kernels' operand layout
 
 
 class PackedWeights:
@@ -179,6 +180,8 @@ class PackedWeights:
 
     def view(self, i: int) -> Tensor:
         it = self.items[i]
+        if it.frag16:
+            raise CarcaHipError("PackedWeights.view: item is in fragment order, not a row-major matrix")
         return self.buf[self.offsets[i]: self.offsets[i] + it.dst_rows * it.dst_cols].view(it.dst_rows, it.dst_cols)
 
     def _fill(self, tensors) -> list:
@@ -201,6 +204,7 @@ class PackedWeights:
             d.row_dh, d.row_dhp = it.row_heads
             d.col_dh, d.col_dhp = it.col_heads
             d.transposed = int(it.transposed)
+            d.frag16 = int(it.frag16)
         return keep
 
     def pack(self) -> None:

@@ -75,6 +75,10 @@ typedef struct CarcaPackDesc {
   int32_t row_dh, row_dhp; /* 0,0 = plain rows */
   int32_t col_dh, col_dhp; /* 0,0 = plain cols */
   int32_t transposed;      /* 1: logical element (r, c) lives at src[c * src_ld + r] (rows/cols are logical) */
+  int32_t frag16;          /* 1: dst is written in MFMA-fragment order instead of row-major (dst_rows, dst_cols multiples
+                            * of 16): packed element (rp, cp) lives at
+                            *   (((rp/16) * (dst_cols/16) + cp/16) * 64 + ((cp%16)/4) * 16 + rp%16) * 4 + cp%4,
+                            * i.e. the 64 lanes x 4 floats one wave loads for one 16x16 tile are 1 KB contiguous */
 } CarcaPackDesc;
 int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream);
 
@@ -186,12 +190,15 @@ int carca_embed_fwd(const CarcaRowSeg* segs /*host*/, int nseg, int n_attrs, int
  * Replaces SelfAttentionBlock.forward (carca.py:297-318) incl. MultiHeadAttention.forward
  * (carca.py:228-265) with causal=0, in eval mode / dropout p = 0.  One workgroup per user.
  * Pointers in CarcaSaWeights are PACKED (carca_pack_weights): projections [DPO, DPI] with
- * head-padded rows, biases [DPO] head-padded, ffn matrices [DPI, DPI], LayerNorm vectors [DPI]. */
+ * head-padded rows, biases [DPO] head-padded, ffn matrices [DPI, DPI], LayerNorm vectors [DPI].
+ * The five matrices are in FRAGMENT ORDER (CarcaPackDesc.frag16 = 1): a wave's operand load for one 16x16 tile is
+ * then eight full cache lines instead of sixteen half-used ones (row-major cost 15 k of the 21 k cycles of the
+ * K/V projection phase at C2). */
 typedef struct CarcaSaWeights {
   const float *ln1_w, *ln1_b, *ln2_w, *ln2_b; /* [DPI] */
-  const float *wq, *wk, *wv;                  /* [DPO, DPI] */
+  const float *wq, *wk, *wv;                  /* [DPO, DPI], fragment order */
   const float *bq, *bk, *bv;                  /* [DPO] */
-  const float *w1, *w2;                       /* [DPI, DPI] */
+  const float *w1, *w2;                       /* [DPI, DPI], fragment order */
   const float *b1, *b2;                       /* [DPI] */
 } CarcaSaWeights;
 /* Training-mode dropout (nn.Dropout sites carca.py:258,309,312,416): element e of a site is kept iff
@@ -229,7 +236,7 @@ int carca_sa_block_fwd(const float* x /*[B*L, ldx]*/, int ldx, const int32_t* id
  * One workgroup per user.  y_out[g] is [B, N_g] dense. */
 typedef struct CarcaCaWeights {
   const float *ln_w, *ln_b; /* final norm [DPI]; both NULL = p_raw is already normed (standalone decoder) */
-  const float *wq, *wk, *wv; /* [DPO, DPI] */
+  const float *wq, *wk, *wv; /* [DPO, DPI], fragment order (CarcaPackDesc.frag16) */
   const float *bq, *bk, *bv; /* [DPO] */
   const float* ffn_w_pad;    /* decoder.ffn.weight in head-padded order [DPO] */
   const float* ffn_w;        /* decoder.ffn.weight plain, zero-padded [DPI] */
