@@ -87,6 +87,19 @@ __device__ __forceinline__ void row_layernorm(float& v0, float& v1, int lane, in
   v1 = lane + 64 < d ? d1 * rstd * w[lane + 64] + b[lane + 64] : 0.f;
 }
 
+// The same LayerNorm with the affine pair already in registers (rows_in_flight below holds several rows per wave).
+__device__ __forceinline__ void row_layernorm_regs(float& v0, float& v1, int lane, int d, float w0, float w1, float b0,
+                                                   float b1) {
+  const float inv_d = 1.0f / (float)d;
+  const float mean = wave_sum(v0 + v1) * inv_d;
+  const float d0 = lane < d ? v0 - mean : 0.f;
+  const float d1 = lane + 64 < d ? v1 - mean : 0.f;
+  const float var = wave_sum(d0 * d0 + d1 * d1) * inv_d;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  v0 = lane < d ? d0 * rstd * w0 + b0 : 0.f;
+  v1 = lane + 64 < d ? d1 * rstd * w1 + b1 : 0.f;
+}
+
 // K^T-style projection tile: out[slot][16ft + 4mq + r] = sum_k W[16ft + 4mq + r][k] X[slot][k] + bias
 // (A = packed weight rows from global, Bt = slot rows from LDS); written as one 16-B LDS store per lane.
 template <int DPI>
@@ -143,7 +156,7 @@ __device__ __forceinline__ void proj_tile_slot_major(const float* __restrict__ W
 //                 query may attend key 16kt + 4mq + r
 //   returns o[ft] = O^T tile rows (head-padded features 16ft + 4mq + r of head h) for the lane's query,
 //   and (optionally) leaves the probabilities in p[kt].
-template <int DPI, int DHP, int NH>
+template <int DPI, int DHP, int NH, bool HOIST_WQ = false>
 __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], const float* __restrict__ wq,
                                             const float* __restrict__ bq, const float* Ks, const float* Vt, int h,
                                             int nkt, unsigned okbits, float sqrt_dh,
@@ -153,20 +166,41 @@ __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], cons
                                             int nkeys = 0) {
   using G = AttGeom<DPI, DHP, NH>;
   const int ln = lane & 15, mq = lane >> 4;
-  // Q^T tiles of this head
+  // Q^T tiles of this head.  HOIST_WQ (callers with registers to spare: the self-attention block; the scoring kernel
+  // spills with it) and few enough fragments (<= 12 x 16 B per lane): ALL of the head's weight loads are issued before
+  // the first chain, so one L2 latency is exposed per head instead of one per feature tile.
   f32x4 qt[G::NFH];
+  if constexpr (HOIST_WQ && G::NFH * G::NKG <= 12) {
+    f32x4 wf[G::NFH][G::NKG], bias[G::NFH];
 #pragma unroll
-  for (int ft = 0; ft < G::NFH; ++ft) {
-    f32x4 wf[G::NKG];
+    for (int ft = 0; ft < G::NFH; ++ft) {
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(wq, wfrag_off(h * (DHP / 16) + ft, kg, G::NKG, lane));
-    const f32x4 bias = gload4(bq, h * DHP + 16 * ft + 4 * mq);
+      for (int kg = 0; kg < G::NKG; ++kg) wf[ft][kg] = gload4(wq, wfrag_off(h * (DHP / 16) + ft, kg, G::NKG, lane));
+      bias[ft] = gload4(bq, h * DHP + 16 * ft + 4 * mq);
+    }
     CARCA_PIN_LOADS();
-    f32x4 acc = zero4();
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], qfrag[kg], acc);
-    qt[ft] = acc + bias;
-    if (qh_row) *reinterpret_cast<f32x4*>(qh_row + h * DHP + 16 * ft + 4 * mq) = qt[ft];  // saved for backward
+    for (int ft = 0; ft < G::NFH; ++ft) {
+      f32x4 acc = zero4();
+#pragma unroll
+      for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[ft][kg], qfrag[kg], acc);
+      qt[ft] = acc + bias[ft];
+      if (qh_row) *reinterpret_cast<f32x4*>(qh_row + h * DHP + 16 * ft + 4 * mq) = qt[ft];  // saved for backward
+    }
+  } else {
+#pragma unroll
+    for (int ft = 0; ft < G::NFH; ++ft) {
+      f32x4 wf[G::NKG];
+#pragma unroll
+      for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4(wq, wfrag_off(h * (DHP / 16) + ft, kg, G::NKG, lane));
+      const f32x4 bias = gload4(bq, h * DHP + 16 * ft + 4 * mq);
+      CARCA_PIN_LOADS();
+      f32x4 acc = zero4();
+#pragma unroll
+      for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], qfrag[kg], acc);
+      qt[ft] = acc + bias;
+      if (qh_row) *reinterpret_cast<f32x4*>(qh_row + h * DHP + 16 * ft + 4 * mq) = qt[ft];  // saved for backward
+    }
   }
   // scores^T tiles: rows = keys, cols = queries
 #pragma unroll
@@ -183,13 +217,16 @@ __device__ __forceinline__ void attend_head(const f32x4 (&qfrag)[DPI / 16], cons
   // masked softmax over keys: (mask + QK^T) / sqrt(dh) -> softmax -> * mask   (carca.py:251-256).
   // A masked score is -2^32/sqrt(dh) in the reference and underflows to an exact 0 weight next to
   // any unmasked score; a row with no unmasked key becomes all zeros.  Same thing, said directly:
+  // (the scale is applied as a multiplication by 1/sqrt(dh): an fp32 division is ~10 instructions per score, and this
+  // wave's instruction stream IS the critical path; 1 ulp on the score, exact for dh = 16 and 64)
+  const float inv_sqrt_dh = 1.0f / sqrt_dh;
   float mx = -3.0e38f;
 #pragma unroll
   for (int kt = 0; kt < ATT_LT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = (okbits >> (4 * kt + r)) & 1u;
-      const float sc = p[kt][r] / sqrt_dh;
+      const float sc = p[kt][r] * inv_sqrt_dh;
       p[kt][r] = sc;
       mx = ok ? fmaxf(mx, sc) : mx;
     }

@@ -162,13 +162,14 @@ __global__ void mask_mul_kernel(const float* __restrict__ x, int ld_x, const uin
 
 // scale + masked softmax of a lane's score registers (same arithmetic as attend_head)
 __device__ __forceinline__ void masked_softmax(f32x4 (&p)[ATT_LT], unsigned okbits, float sqrt_dh) {
+  const float inv_sqrt_dh = 1.0f / sqrt_dh;
   float mx = -3.0e38f;
 #pragma unroll
   for (int kt = 0; kt < ATT_LT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = (okbits >> (4 * kt + r)) & 1u;
-      const float sc = p[kt][r] / sqrt_dh;
+      const float sc = p[kt][r] * inv_sqrt_dh;
       p[kt][r] = sc;
       mx = ok ? fmaxf(mx, sc) : mx;
     }
@@ -244,10 +245,11 @@ __device__ __forceinline__ void attn_bwd_phase1(const float* Qs, const float* Ks
     for (int r = 0; r < 4; ++r) dot += p[kt][r] * dp[kt][r];
   dot = quad4_sum(dot);
   f32x4 ds[ATT_LT];
+  const float inv_sqrt_dh = 1.0f / sqrt_dh;
 #pragma unroll
   for (int kt = 0; kt < ATT_LT; ++kt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ds[kt][r] = p[kt][r] * (dp[kt][r] - dot) / sqrt_dh;
+    for (int r = 0; r < 4; ++r) ds[kt][r] = p[kt][r] * (dp[kt][r] - dot) * inv_sqrt_dh;
   if (mrow) {  // from here on p means P * M (what multiplied V in the forward)
 #pragma unroll
     for (int kt = 0; kt < ATT_LT; ++kt)

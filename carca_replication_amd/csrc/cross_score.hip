@@ -58,36 +58,43 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
   const size_t ubase = (size_t)u * L;
   const int ln = lane & 15, mq = lane >> 4;
 
-  // ---- A0: rows -> LDS; A1: final norm (wave per row) ------------------------------------------------------
-  constexpr int V4 = DPI / 4;
-  const bool vec_ok = (ldp % 4 == 0) && ldp >= DPI;
-  for (int i = tid; i < 16 * LT * V4; i += 1024) {
-    const int r = i / V4, c4 = i - r * V4;
-    f32x4 v = zero4();
-    if (r < L) {
-      const float* xr = p_raw + (ubase + r) * ldp + 4 * c4;
-      if (vec_ok) {
-        v = gload4(p_raw, (int)((ubase + r) * ldp) + 4 * c4);
-      } else {
+  // ---- A: rows -> final norm -> LDS.  A wave takes rows wave, wave+16, ... straight from HBM (lane = column, two per
+  // lane), all of them in flight before the first reduction, and normalises them interleaved: a row's two wave
+  // reductions are a ~1 k-cycle dependent chain (one row at a time through LDS read 2.8 k + 4.8 k cycles).
+  {
+    constexpr int RPW = ATT_LMAX / NW;
+    float v0[RPW], v1[RPW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = 4 * c4 + e < d ? xr[e] : 0.f;
+    for (int j = 0; j < RPW; ++j) {
+      const int r = wave + NW * j;
+      const int off = (int)((ubase + (r < L ? r : 0)) * ldp);
+      const float a = gload1(p_raw, off + (lane < d ? lane : 0)), b = gload1(p_raw, off + (lane + 64 < d ? lane + 64 : 0));
+      v0[j] = (r < L && lane < d) ? a : 0.f;
+      v1[j] = (r < L && lane + 64 < d) ? b : 0.f;
+    }
+    CA_STAMP(1);
+    if (w.ln_w) {
+      const float w0 = lane < d ? w.ln_w[lane] : 0.f, w1 = lane + 64 < d ? w.ln_w[lane + 64] : 0.f;
+      const float b0 = lane < d ? w.ln_b[lane] : 0.f, b1 = lane + 64 < d ? w.ln_b[lane + 64] : 0.f;
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {  // (rows >= L are normalised too, branch-free, and zeroed again below)
+        row_layernorm_regs(v0[j], v1[j], lane, d, w0, w1, b0, b1);
+        const bool live = wave + NW * j < L;
+        v0[j] = live ? v0[j] : 0.f;
+        v1[j] = live ? v1[j] : 0.f;
       }
     }
-    *reinterpret_cast<f32x4*>(Ps + r * G::SI + 4 * c4) = v;
-  }
-  __syncthreads();
-  CA_STAMP(1);
-  if (w.ln_w || p_normed) {
-    for (int r = wave; r < L; r += NW) {
-      float v0 = lane < d ? Ps[r * G::SI + lane] : 0.f;
-      float v1 = lane + 64 < d ? Ps[r * G::SI + lane + 64] : 0.f;
-      if (w.ln_w) row_layernorm(v0, v1, lane, d, w.ln_w, w.ln_b);
-      if (lane < DPI) Ps[r * G::SI + lane] = v0;
-      if (lane + 64 < DPI) Ps[r * G::SI + lane + 64] = v1;
-      if (p_normed) {
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int r = wave + NW * j;
+      if (r < 16 * LT) {
+        if (lane < DPI) Ps[r * G::SI + lane] = v0[j];
+        if (lane + 64 < DPI) Ps[r * G::SI + lane + 64] = v1[j];
+      }
+      if (p_normed && r < L) {
         float* pr = p_normed + (ubase + r) * ldp;
-        if (lane < ldp) pr[lane] = v0;
-        if (lane + 64 < ldp) pr[lane + 64] = v1;
+        if (lane < ldp) pr[lane] = v0[j];
+        if (lane + 64 < ldp) pr[lane + 64] = v1[j];
       }
     }
     __syncthreads();

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
       }
     f32x4 oh[G::NFH], p[ATT_LT];
     const unsigned midx = (unsigned)((((size_t)u * NH + h) * L + (q < L ? q : 0)) * L);
-    attend_head<DPI, DHP, NH>(qfrag, w.wq, w.bq, Ks, Vt, h, qt + 1, okbits, sqrt_dh, oh, p, lane,
+    attend_head<DPI, DHP, NH, true>(qfrag, w.wq, w.bq, Ks, Vt, h, qt + 1, okbits, sqrt_dh, oh, p, lane,
                               (sv.qh && q < L) ? sv.qh + (ubase + q) * G::DPO : nullptr, &dc, site, midx,
                               (sv.m_attn && q < L) ? sv.m_attn + midx : nullptr, L);
     // r = attention (+ q): plain feature order, into the dead x image (pad columns stay 0)
