@@ -189,3 +189,26 @@ def test_gemm_wgrad_group_equals_single_launches():
         _close(dw2, want.cpu(), tol=5e-5)
         _close(db2, dy[:, :n].double().sum(0).cpu(), tol=5e-5)
         _close(dw2, dw1.double().cpu(), tol=1e-5)
+
+
+def test_pack_weights_fragment_order_layout():
+    """CarcaPackDesc.frag16: element (rp, cp) of the padded matrix sits where lane (cp % 16 / 4, rp % 16) of the wave that
+    loads tile (rp / 16, cp / 16) reads it -- checked against the index formula of include/carca_hip.h, with head padding."""
+    from carca_replication_amd import ops
+
+    d, H = 90, 3
+    dpi, dhp, dpo = ops.padded_dims(d, H)
+    dh = d // H
+    w = torch.arange(d * d, dtype=torch.float32, device="cuda").view(d, d) + 1.0
+    pw = ops.PackedWeights([ops.PackItem(w, dpo, dpi, row_heads=(dh, dhp), frag16=True),
+                            ops.PackItem(w, dpo, dpi, row_heads=(dh, dhp))], "cuda")
+    pw.pack()
+    frag = pw.buf[pw.offsets[0]: pw.offsets[0] + dpo * dpi].cpu()
+    plain = pw.view(1).cpu()  # row-major head-padded [dpo, dpi]
+    rp = torch.arange(dpo).view(-1, 1).expand(dpo, dpi)
+    cp = torch.arange(dpi).view(1, -1).expand(dpo, dpi)
+    idx = (((rp // 16) * (dpi // 16) + cp // 16) * 64 + ((cp % 16) // 4) * 16 + rp % 16) * 4 + cp % 4
+    assert torch.equal(frag[idx.reshape(-1)].view(dpo, dpi), plain)
+    assert float(plain[dh, 0]) == 0.0 and float(plain[dhp, 0]) == float(w[dh, 0])  # pad rows are zero, heads shifted
+    with pytest.raises(ops.CarcaHipError):
+        pw.view(0)
