@@ -822,8 +822,11 @@ static int wgrad_prepare(const CarcaWgradDesc* desc, WgradDev& g, bool* fits_out
   // row splits: fill the chip's 4 x 256 resident slots in ONE round (119 registers -> 4 blocks per CU;
   // measured at C2: 512 slots 1017 us, 768 972, 1024 809, 1536 865), but keep >= 2 chunks (64 rows) per split
   const int tiles = g.nnb * g.nkb;
+  // Products of a few tiles (joint embedding: 5) pay for every split with a full tile of atomics: 384 slots there
+  // (N = 90, K = 540, 19328 rows: 1024 slots 74.5 us, 768 65.8, 640 61.6, 512 59.6, 384 57.5, 256 67.6)
   const int slots = slot_budget > 0 ? slot_budget
-                    : carca_tuning(CARCA_TUNE_WGRAD_SLOTS) > 0 ? carca_tuning(CARCA_TUNE_WGRAD_SLOTS) : 1024;
+                    : carca_tuning(CARCA_TUNE_WGRAD_SLOTS) > 0 ? carca_tuning(CARCA_TUNE_WGRAD_SLOTS)
+                    : tiles >= 64 ? 1024 : 384;
   int nsplit = tiles >= slots ? 1 : slots / tiles;
   const int min_chunks = carca_tuning(4) > 0 ? carca_tuning(4) : 2;  // (measured on the d x d products: 4 -> 21 us, 2 -> 18 us, 1 -> 23 us)
   nsplit = max(1, min(nsplit, (chunks + min_chunks - 1) / min_chunks));
@@ -913,7 +916,10 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
       // row-split budget per product (tuning key 5; 0 = the single-product default).  A/B at C2, interleaved in one
       // process (tools/ab_train.py): ungrouped 2.341 ms/step, grouped 2.229, grouped with 64 / 85 / 128 slots per
       // product 2.223 / 2.263 / 2.220 -- the budget does not matter, the single launch does
-      const int budget = carca_tuning(5) > 0 ? carca_tuning(5) : 0;
+      // Second look with the kernel trace (tools/train_trace.sh, 13 products of a C2 backward pass in one launch):
+      // 1024 slots per product (100 two-chunk splits each) 105 us, 64 -> 72 us, 48 -> 73, 40 -> 76, 32 -> 76, 24 -> 92,
+      // 16 -> 108: every split ends with a 96 x 128 tile of atomics, so fewer, longer splits win until the chip runs dry
+      const int budget = carca_tuning(5) > 0 ? carca_tuning(5) : 64;
       const int grid = wgrad_prepare(&descs[done], g, &fits, budget);
       const bool big = (long)descs[done].N * (descs[done].K + descs[done].K1) > 96 * 1024;  // single-product path decides
       if (!fits || big || variant == 6) {  // (variant 6: never group -- A/B switch)

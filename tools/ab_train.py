@@ -24,7 +24,8 @@ px = profile[0]
 o_x = torch.cat([pos[0] * (px != 0), pos[0].flip(1) * (px != 0)], dim=1)
 batch = tuple(t.cuda() for t in (profile[0], profile[1], profile[2], o_x, torch.cat([pos[1], pos[1].flip(1)], 1),
                                   torch.cat([pos[2], pos[2]], 1), torch.cat([(px != 0).int(), torch.zeros_like(px)], 1)))
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98), fused=True)
+from carca_replication_amd.optim import Adam as _Adam  # noqa: E402
+opt = _Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))
 lib = _lib.load()
 res = {s: [] for s in settings}
 for rnd in range(4):
