@@ -196,6 +196,7 @@ SIGNATURES = {
     "carca_pack_weights": (_i, [C.POINTER(PackDesc), _i, _fp]),
     "carca_embed_fwd": (_i, [C.POINTER(RowSeg), _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     "carca_gemm_rows": (_i, [C.POINTER(GemmDesc), _fp]),
+    "carca_gemm_rows_group": (_i, [C.POINTER(GemmDesc), _i, _fp]),
     "carca_gemm_wgrad": (_i, [C.POINTER(WgradDesc), _fp]),
     "carca_gemm_wgrad_group": (_i, [C.POINTER(WgradDesc), _i, _fp]),
     "carca_sa_block_fwd": (_i, [_fp, _i, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SaWeights), _i, C.POINTER(SaSave),

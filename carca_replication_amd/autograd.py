@@ -18,24 +18,45 @@ from . import ops
 from ._lib import CarcaHipError
 
 
-def _zeros_like_params(params):
+def _zeros_like_params(params, extra: int = 0):
     """One zero-filled flat buffer cut into per-parameter views (one fill launch instead of one per parameter; every
-    view starts on a 16-byte boundary)."""
+    view starts on a 16-byte boundary), plus `extra` zeroed floats behind them for the backward's staging areas.
+    Returns (views, tail)."""
     if not params:
-        return []
+        return [], None
     offs, total = [], 0
     for p in params:
         offs.append(total)
         total += (p.numel() + 3) // 4 * 4
-    flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+    flat = torch.zeros(total + extra, dtype=params[0].dtype, device=params[0].device)
     # (dist.allreduce_gradients recognises this layout by storage and offsets and reduces the flat buffer itself)
-    return [flat[o: o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+    return [flat[o: o + p.numel()].view(p.shape) for o, p in zip(offs, params)], flat[total:]
+
+
+class _Tail:
+    """Hands out zeroed slices of the flat buffer's tail (16-byte aligned sizes)."""
+
+    def __init__(self, buf):
+        self.buf, self.pos = buf, 0
+
+    def take(self, n: int):
+        n4 = (n + 3) // 4 * 4
+        if self.buf is None or self.pos + n4 > self.buf.numel():
+            return None  # caller allocates (and zeroes) its own
+        out = self.buf[self.pos: self.pos + n4]
+        self.pos += n4
+        return out
 
 
 class _Packs:
     """Transposed / head-padded weight copies and gradient staging buffers of one attention-bearing module."""
 
-    def __init__(self, attn, extra_fwd: List[ops.PackItem], device):
+    @staticmethod
+    def staging_floats(attn) -> int:
+        _, _, dpo = ops.padded_dims(attn.d, attn.H)
+        return 3 * ((dpo * attn.d + 3) // 4 * 4) + 3 * ((dpo + 3) // 4 * 4)
+
+    def __init__(self, attn, extra_fwd: List[ops.PackItem], device, tail: "_Tail" = None):
         d, H = attn.d, attn.H
         self.d, self.H = d, H
         self.dpi, self.dhp, self.dpo = ops.padded_dims(d, H)
@@ -49,8 +70,10 @@ class _Packs:
         # head-padded staging for d WQ/WK/WV [DPO, d] and their biases [DPO]
         gitems = [ops.PackItem(m.weight, self.dpo, d, row_heads=hp) for m in (attn.WQ, attn.WK, attn.WV)]
         gitems += [ops.PackItem(m.bias, 1, self.dpo, col_heads=hp) for m in (attn.WQ, attn.WK, attn.WV)]
-        self.g = ops.PackedWeights(gitems, device)
-        self.g.buf.zero_()
+        zeroed = tail.take(ops.PackedWeights.size_of(gitems)) if tail is not None else None
+        self.g = ops.PackedWeights(gitems, device, buf=zeroed)
+        if zeroed is None:
+            self.g.buf.zero_()
 
 
 def _attn_param_grads(packs: _Packs, attn, grads_by_param):
@@ -59,7 +82,7 @@ def _attn_param_grads(packs: _Packs, attn, grads_by_param):
     packs.g.unpack_into(real, accumulate=True)
 
 
-def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after):
+def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after, tail):
     """Backward of the sigmoid/ffn head + cross-attention (carca.py:340-347): returns (d p_normed, [d o_g])."""
     dec = model.decoder
     d, H = model.embeds.d, dec.attn.H
@@ -68,8 +91,9 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after):
     B, L = st["B"], st["L"]
     p_x = st["p_x"]
     ngroups = st["ngroups"]
-    cp = _Packs(dec.attn, [], dev)
-    d_wpad = torch.zeros(dpo, dtype=torch.float32, device=dev)
+    cp = _Packs(dec.attn, [], dev, tail)
+    d_wpad = tail.take(dpo)
+    d_wpad = d_wpad[:dpo] if d_wpad is not None else torch.zeros(dpo, dtype=torch.float32, device=dev)
     bgroups = []
     for gi in range(ngroups):
         bgroups.append((st["csave"]["qh"][gi], ys[gi], dys[gi], st["segs"][gi + 1][0]))
@@ -93,15 +117,18 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after):
     # d o_g = dQ_g . W_Q (+ dlogit (x) w), masked like e * mask (carca.py:94)
     wq_t, wk_t, wv_t = cp.wT.view(0), cp.wT.view(1), cp.wT.view(2)
     ffn_w_plain = dec.ffn.weight.detach().reshape(-1)
-    des_t = ops.gemm_rows([dict(a0=dqhs[gi], rowscale=dls[gi] if dec.residual else None, ids=o_ids[gi])
-                           for gi in range(ngroups)], wq_t, d, dpo, dpi,
-                          colvec=ffn_w_plain if dec.residual else None, mask_rows=True)
+    # d o_g and d p_normed do not depend on each other: one launch (the two ~150-block products side by side)
+    des_t, (dp,) = ops.gemm_rows_group([
+        dict(segs=[dict(a0=dqhs[gi], rowscale=dls[gi] if dec.residual else None, ids=o_ids[gi])
+                   for gi in range(ngroups)], bt0=wq_t, N=d, K0=dpo, out_ld=dpi,
+             colvec=ffn_w_plain if dec.residual else None, mask_rows=True),
+        dict(segs=[dict(a0=dkh, a1=dvh)], bt0=wk_t, N=d, K0=dpo, out_ld=dpi, bt1=wv_t,
+             K1=dpo)])
     wg.add([dict(dy=dqhs[gi], x=o_rows[gi]) for gi in range(ngroups)], dpo, d, cp.g.view(0), cp.g.view(3).view(-1))
     pn = st["p_normed"].view(-1, st["p_normed"].shape[-1])
     wg.add([dict(dy=dkh, x=pn)], dpo, d, cp.g.view(1), cp.g.view(4).view(-1))
     wg.add([dict(dy=dvh, x=pn)], dpo, d, cp.g.view(2), cp.g.view(5).view(-1))
     after.append(lambda: _attn_param_grads(cp, dec.attn, gbp))
-    (dp,) = ops.gemm_rows([dict(a0=dkh, a1=dvh)], wk_t, d, dpo, dpi, bt1=wv_t, K1=dpo)
     return dp, des_t
 
 
@@ -174,7 +201,15 @@ class _CarcaFn(torch.autograd.Function):
         B, L = st["B"], st["L"]
         p_x = st["p_x"]
         dev = p_x.device
-        grads = _zeros_like_params(params)
+        # staging areas that must start at zero (head-padded dW / db of every attention module, d ffn.weight) ride
+        # behind the gradients in the same fill
+        from .modules import CrossAttentionBlock
+
+        extra = sum(_Packs.staging_floats(blk.attn) for blk in model.encoder)
+        if isinstance(dec, CrossAttentionBlock):
+            extra += _Packs.staging_floats(dec.attn) + (ops.padded_dims(d, dec.attn.H)[2] + 3) // 4 * 4
+        grads, tail_buf = _zeros_like_params(params, extra)
+        tail = _Tail(tail_buf)
         gbp = {id(p): g for p, g in zip(params, grads)}
         ys = ctx.saved_tensors
         ngroups = st["ngroups"]
@@ -182,7 +217,7 @@ class _CarcaFn(torch.autograd.Function):
         # the small weight-gradient products feed nothing downstream: collected, then issued as ONE grouped launch
         wg, after = ops.WgradGroup(), []
         if st["is_ca"]:
-            dp, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after)
+            dp, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after, tail)
         else:
             dp, des_t = dec.score_backward(dys, st["dsave"], B, L, d, dpi)
         # final LayerNorm (carca.py:421)
@@ -195,7 +230,7 @@ class _CarcaFn(torch.autograd.Function):
             _, _, dpo = ops.padded_dims(d, blk.attn.H)
             extra = [ops.PackItem(blk.ffn_1.weight[:, :, 0], dpi, dpi, transposed=True),
                      ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi, dpi, transposed=True)]
-            bp = _Packs(blk.attn, extra, dev)
+            bp = _Packs(blk.attn, extra, dev, tail)
             w1_t, w2_t = bp.wT.view(3), bp.wT.view(4)
             x_in = sv["x_in"].view(-1, dpi)
             dy = dx
@@ -214,8 +249,9 @@ class _CarcaFn(torch.autograd.Function):
             dqh, dkh_b, dvh_b = ops.sa_attn_bwd(sv["qh"], sv["kh"], sv["vh"], dr, p_x, B, L, d, blk.attn.H,
                                                 m_attn=sv.get("m_attn") if bp_ > 0 else None, drop_scale=bscale)
             bq_t, bk_t, bv_t = bp.wT.view(0), bp.wT.view(1), bp.wT.view(2)
-            (dqn,) = ops.gemm_rows([dict(a0=dqh, add=dr if blk.residual else None)], bq_t, d, dpo, dpi)
-            (dx_kv,) = ops.gemm_rows([dict(a0=dkh_b, a1=dvh_b)], bk_t, d, dpo, dpi, bt1=bv_t, K1=dpo)
+            (dqn,), (dx_kv,) = ops.gemm_rows_group([  # independent: one launch
+                dict(segs=[dict(a0=dqh, add=dr if blk.residual else None)], bt0=bq_t, N=d, K0=dpo, out_ld=dpi),
+                dict(segs=[dict(a0=dkh_b, a1=dvh_b)], bt0=bk_t, N=d, K0=dpo, out_ld=dpi, bt1=bv_t, K1=dpo)])
             wg.add([dict(dy=dqh, x=sv["qn"])], dpo, d, bp.g.view(0), bp.g.view(3).view(-1))
             wg.add([dict(dy=dkh_b, x=x_in)], dpo, d, bp.g.view(1), bp.g.view(4).view(-1))
             wg.add([dict(dy=dvh_b, x=x_in)], dpo, d, bp.g.view(2), bp.g.view(5).view(-1))

@@ -35,7 +35,7 @@ struct GemmDev {
 };
 
 template <int BM, int BN, int BK, int PF = 1, bool BUF = false>
-__global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev args) {
+__device__ __forceinline__ void gemm_rows_body(const GemmDev& args, const int id) {
   constexpr int NW = BM / 32, NT = NW * 64, LS = BK + 4, TN = BN / 32;
   constexpr int C4 = BK / 4;  // float4 slots per tile row
   constexpr int A_SLOTS = BM * C4, B_SLOTS = BN * C4;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
   // ---- block id -> (row block, col block): ids that are equal mod 8 land on one XCD under round-robin placement;
   // renumber them contiguously per XCD (bijective for any grid size, no phantom blocks: a padded grid can push real
   // blocks into a second round when the grid is sized to the chip) so that the column blocks of a row block share an L2
-  const int id = blockIdx.x, total = args.nrb * args.ncb;
+  const int total = args.nrb * args.ncb;
   const int xcd = id & 7, q8 = total >> 3, r8 = total & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
   const int rb = wg / args.ncb, cb = wg - rb * args.ncb;
@@ -237,6 +237,29 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev
       sg.c[(size_t)row * D.ldc + n] = v;
     }
   }
+}
+
+template <int BM, int BN, int BK, int PF = 1, bool BUF = false>
+__global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_kernel(const GemmDev args) {
+  gemm_rows_body<BM, BN, BK, PF, BUF>(args, (int)blockIdx.x);
+}
+
+// Independent narrow products of a backward pass (dQ.W_Q beside dK.W_K + dV.W_V) are ~150-block, 15 us launches that
+// leave half the chip idle: side by side in ONE launch they cost one.  Descriptors travel by value (kernel arguments);
+// block -> (product, local block id); one body instantiation, so LDS and registers are those of the single kernel.
+constexpr int GEMM_GROUP_MAX = 4;
+struct GemmGroup {
+  GemmDev g[GEMM_GROUP_MAX];
+  int block_start[GEMM_GROUP_MAX + 1];
+  int n;
+};
+template <int BM, int BN, int BK, int PF, bool BUF>
+__global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_group_kernel(const GemmGroup grp) {
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_GROUP_MAX; ++i)
+    if (i < grp.n && (int)blockIdx.x >= grp.block_start[i]) p = i;
+  gemm_rows_body<BM, BN, BK, PF, BUF>(grp.g[p], (int)blockIdx.x - grp.block_start[p]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -729,8 +752,10 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream) {
   return CARCA_OK;
 }
 
-extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+enum GemmChoice { GEMM_NARROW_BUF, GEMM_NARROW, GEMM_CU, GEMM_CU_STAMPS, GEMM_TILED_BUF, GEMM_TILED };
+
+// argument checks + kernel selection of one product
+static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice) {
   CARCA_CHECK_ARG(desc && desc->nseg >= 1 && desc->nseg <= CARCA_MAX_SEGS, "gemm_rows: bad segment count");
   CARCA_CHECK_ARG(desc->bt0 && desc->K0 >= 1 && desc->N >= 1 && desc->ldc >= desc->N && desc->lda0 >= desc->K0 &&
                       desc->ldb0 >= desc->K0,
@@ -773,17 +798,84 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   }
   if (variant == 4) fits = false;
   const bool narrow = variant != 1 && rb128 * ((desc->ncols_out + 95) / 96) < 384;
-  if (narrow) return fits ? launch_gemm_rows<128, 32, 32, 4, true>(desc, stream) : launch_gemm_rows<128, 32, 32, 4>(desc, stream);
+  if (narrow) {
+    *choice = fits ? GEMM_NARROW_BUF : GEMM_NARROW;
+    return CARCA_OK;
+  }
   // One 384 x 96 block per CU when the grid fills the chip's 256 CUs about as well as the 128 x 96 blocks (3 per CU)
   // would: compare rounds x tiles per block.
   if (fits && desc->K0 >= 64 && variant != 1) {
     const int ncb = (desc->ncols_out + 95) / 96;
     const long units_cu = (long)((rb384 * ncb + 255) / 256) * 36, units_3 = (long)((rb128 * ncb + 255) / 256) * 12;
-    if (variant == 3) return launch_gemm_rows_cu<1>(desc, stream);
-    if (variant == 2 || units_cu <= units_3) return launch_gemm_rows_cu<0>(desc, stream);
+    if (variant == 3 || variant == 2 || units_cu <= units_3) {
+      *choice = variant == 3 ? GEMM_CU_STAMPS : GEMM_CU;
+      return CARCA_OK;
+    }
   }
-  if (fits) return launch_gemm_rows<128, 96, 32, 1, true>(desc, stream);
-  return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
+  *choice = fits ? GEMM_TILED_BUF : GEMM_TILED;
+  return CARCA_OK;
+}
+
+extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GemmChoice c;
+  if (int rc = gemm_rows_choose(desc, &c)) return rc;
+  switch (c) {
+    case GEMM_NARROW_BUF: return launch_gemm_rows<128, 32, 32, 4, true>(desc, stream);
+    case GEMM_NARROW: return launch_gemm_rows<128, 32, 32, 4>(desc, stream);
+    case GEMM_CU: return launch_gemm_rows_cu<0>(desc, stream);
+    case GEMM_CU_STAMPS: return launch_gemm_rows_cu<1>(desc, stream);
+    case GEMM_TILED_BUF: return launch_gemm_rows<128, 96, 32, 1, true>(desc, stream);
+    default: return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
+  }
+}
+
+// n independent products; those that select the narrow buffer-load kernel share launches (GEMM_GROUP_MAX per launch),
+// the rest are issued one by one.  Same results as n carca_gemm_rows calls: the products must not depend on each other.
+extern "C" int carca_gemm_rows_group(const CarcaGemmDesc* descs, int n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(descs && n >= 1, "gemm_rows_group: no products");
+  constexpr int BM = 128, BN = 32;
+  GemmGroup grp{};
+  int blocks = 0;
+  auto flush = [&]() -> int {
+    if (grp.n == 0) return CARCA_OK;
+    grp.block_start[grp.n] = blocks;
+    if (grp.n == 1) {
+      hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, 32, 4, true>), dim3(blocks), dim3(256), 0, stream, grp.g[0]);
+    } else {
+      hipLaunchKernelGGL((gemm_rows_group_kernel<BM, BN, 32, 4, true>), dim3(blocks), dim3(256), 0, stream, grp);
+    }
+    CARCA_LAUNCH_CHECK();
+    grp.n = 0;
+    blocks = 0;
+    return CARCA_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    GemmChoice c;
+    if (int rc = gemm_rows_choose(&descs[i], &c)) return rc;
+    if (c != GEMM_NARROW_BUF || carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 6) {  // (variant 6: never group -- A/B switch)
+      if (int rc = carca_gemm_rows(&descs[i], stream_)) return rc;
+      continue;
+    }
+    GemmDev& g = grp.g[grp.n];
+    g = GemmDev{};
+    g.d = descs[i];
+    int rb = 0;
+    for (int s = 0; s < descs[i].nseg; ++s) {
+      if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
+      g.rb_start[s] = rb;
+      rb += (descs[i].seg[s].rows + BM - 1) / BM;
+    }
+    g.rb_start[descs[i].nseg] = rb;
+    g.nrb = rb;
+    g.ncb = (descs[i].ncols_out + BN - 1) / BN;
+    grp.block_start[grp.n] = blocks;
+    blocks += rb * g.ncb;
+    if (++grp.n == GEMM_GROUP_MAX)
+      if (int rc = flush()) return rc;
+  }
+  return flush();
 }
 
 int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream);  // wgrad_cu.hip

@@ -166,14 +166,24 @@ class PackItem:
 class PackedWeights:
     """One device buffer holding every packed matrix, plus the offsets of each item."""
 
-    def __init__(self, items: Sequence[PackItem], device):
+    def __init__(self, items: Sequence[PackItem], device, buf: Optional[Tensor] = None):
+        """buf: optional caller-provided storage of at least size_of(items) floats (e.g. a zeroed slice of a bigger
+        buffer, so that several staging areas share one fill launch)."""
         self.items = list(items)
-        sizes = [((it.dst_rows * it.dst_cols + 3) // 4) * 4 for it in self.items]
         self.offsets = [0]
-        for s in sizes:
-            self.offsets.append(self.offsets[-1] + s)
-        self.buf = torch.empty(max(self.offsets[-1], 4), dtype=torch.float32, device=device)
+        for it in self.items:
+            self.offsets.append(self.offsets[-1] + ((it.dst_rows * it.dst_cols + 3) // 4) * 4)
+        need = max(self.offsets[-1], 4)
+        if buf is None:
+            buf = torch.empty(need, dtype=torch.float32, device=device)
+        elif buf.numel() < need or buf.dtype != torch.float32 or not buf.is_contiguous():
+            raise CarcaHipError("PackedWeights: provided buffer too small / not contiguous fp32")
+        self.buf = buf
         self._descs = (_lib.PackDesc * len(self.items))()
+
+    @staticmethod
+    def size_of(items: Sequence[PackItem]) -> int:
+        return max(sum(((it.dst_rows * it.dst_cols + 3) // 4) * 4 for it in items), 4)
 
     def ptr(self, i: int) -> int:
         return self.buf.data_ptr() + 4 * self.offsets[i]
@@ -434,19 +444,34 @@ def _ptr(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
-def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[Tensor] = None, K1: int = 0,
-              bias: Optional[Tensor] = None, pos: Optional[Tensor] = None, colvec: Optional[Tensor] = None,
-              gate_slope: float = 0.01, mask_rows: bool = False, ncols_out: Optional[int] = None,
-              gate_scale: float = 1.0, gate_zero_drops: bool = False, alpha: float = 1.0) -> List[Tensor]:
-    """C_s[m][n] = sum_k A_s[m][k] Bt[n][k] (+ epilogue) for every row segment s.
+def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, **kw) -> List[Tensor]:
+    """One row GEMM (arguments: _gemm_desc); returns the output tensors of its segments."""
+    D, outs, _keep = _gemm_desc(segs, bt0, N, K0, out_ld, **kw)
+    _lib.check(_lib.load().carca_gemm_rows(C.byref(D), _stream()), "gemm_rows")
+    return outs
+
+
+def gemm_rows_group(calls) -> List[List[Tensor]]:
+    """Several INDEPENDENT row GEMMs in one call (carca_gemm_rows_group: narrow products share a launch).
+    calls: [dict(segs=..., bt0=..., N=..., K0=..., out_ld=..., **gemm_rows keywords)]; returns each product's outputs."""
+    built = [_gemm_desc(**c) for c in calls]
+    arr = (_lib.GemmDesc * len(built))(*[b[0] for b in built])
+    _lib.check(_lib.load().carca_gemm_rows_group(arr, len(built), _stream()), "gemm_rows_group")
+    return [b[1] for b in built]
+
+
+def _gemm_desc(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[Tensor] = None, K1: int = 0,
+               bias: Optional[Tensor] = None, pos: Optional[Tensor] = None, colvec: Optional[Tensor] = None,
+               gate_slope: float = 0.01, mask_rows: bool = False, ncols_out: Optional[int] = None,
+               gate_scale: float = 1.0, gate_zero_drops: bool = False, alpha: float = 1.0):
+    """C_s[m][n] = sum_k A_s[m][k] Bt[n][k] (+ epilogue) for every row segment s: builds the descriptor.
 
     segs: list of dicts with keys a0 [rows, lda0] and optionally a1, ids, add, gate, rowscale, T, add_pos, out.
     All 2-D operands are row-major views whose LAST stride is 1; their row stride is taken from .stride(0).
     a0 / a1 may also be [B, T, K] views whose users are strided (o_a[:, :L] of train.py:86-88): walked in place.
     a0_gather=True: a0 is a TABLE [n, lda0] and row r reads a0[ids[r]] (then `rows` must be given by ids).
-    Returns the output tensors [rows, out_ld] (allocated here unless the segment brings 'out').
+    Returns (descriptor, output tensors [rows, out_ld] -- allocated here unless the segment brings 'out' --, keep-alive).
     """
-    lib = _lib.load()
     if not 1 <= len(segs) <= _lib.MAX_SEGS:
         raise CarcaHipError("gemm_rows: 1..4 segments")
     D = _lib.GemmDesc()
@@ -520,8 +545,8 @@ def gemm_rows(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[
     D.bias, D.pos, D.colvec = _ptr(bias), _ptr(pos), _ptr(colvec)
     D.ld_add, D.ld_gate, D.gate_slope, D.mask_rows = ld_add or 0, ld_gate or 0, gate_slope, int(mask_rows)
     D.gate_scale, D.gate_zero_drops, D.alpha = gate_scale, int(gate_zero_drops), alpha
-    _lib.check(lib.carca_gemm_rows(C.byref(D), _stream()), "gemm_rows")
-    return outs
+    keep += [bt0, bt1, bias, pos, colvec]
+    return D, outs, keep
 
 
 def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, mask_rows: bool = False,

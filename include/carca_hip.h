@@ -128,6 +128,9 @@ typedef struct CarcaGemmDesc {
   int32_t gate_zero_drops; /* 1: an exactly-zero saved activation was DROPPED -> gradient 0 (else LeakyReLU'(0) = slope) */
 } CarcaGemmDesc;
 int carca_gemm_rows(const CarcaGemmDesc* desc /*host*/, void* stream);
+/* n INDEPENDENT products (host array): the narrow ones (d-wide input gradients of the backward pass) share launches,
+ * so that two ~150-block products cost one launch instead of two back to back; same results as n single calls. */
+int carca_gemm_rows_group(const CarcaGemmDesc* descs /*host*/, int n, void* stream);
 
 /* ---- building block: weight-gradient GEMM  dW[n][k] += sum_r dY[r][n] * X[r][k] -------------------
  * The contraction runs over ROWS (users x slots), split across workgroups; partial tiles are

@@ -212,3 +212,33 @@ def test_pack_weights_fragment_order_layout():
     assert float(plain[dh, 0]) == 0.0 and float(plain[dhp, 0]) == float(w[dh, 0])  # pad rows are zero, heads shifted
     with pytest.raises(ops.CarcaHipError):
         pw.view(0)
+
+
+def test_gemm_rows_group_equals_single_launches():
+    """carca_gemm_rows_group: independent products in one launch give the bits of their own launches (narrow products
+    share a kernel; a wide one in the same call falls back to its own launch)."""
+    from carca_replication_amd import ops
+
+    a = _rand(6400, 96, seed=1).cuda()
+    b = _rand(6400, 96, seed=2).cuda()
+    c = _rand(12800, 96, seed=3).cuda()
+    wq, wk, wv = (_rand(96, 96, seed=s).cuda() for s in (4, 5, 6))
+    big_w = _rand(540, 96, seed=7).cuda()
+    ids = (torch.arange(12800) % 7 != 0).int().cuda()
+    add = _rand(6400, 96, seed=8).cuda()
+    calls = [dict(segs=[dict(a0=a, add=add)], bt0=wq, N=90, K0=96, out_ld=96),
+             dict(segs=[dict(a0=a, a1=b)], bt0=wk, N=90, K0=96, out_ld=96, bt1=wv, K1=96),
+             dict(segs=[dict(a0=c[:6400], ids=ids[:6400]), dict(a0=c[6400:], ids=ids[6400:])], bt0=wq, N=90, K0=96,
+                  out_ld=96, mask_rows=True),
+             dict(segs=[dict(a0=c)], bt0=big_w, N=540, K0=96, out_ld=540)]
+    singles = [ops.gemm_rows(**{k: v for k, v in cl.items()}) for cl in calls]
+    grouped = ops.gemm_rows_group(calls)
+    for s_outs, g_outs in zip(singles, grouped):
+        assert len(s_outs) == len(g_outs)
+        for s_, g_ in zip(s_outs, g_outs):
+            assert torch.equal(s_, g_)
+    _close(grouped[0][0][:, :90], (a.cpu().double() @ wq.cpu().double().T + add.cpu().double())[:, :90])
+    # five narrow products: more than one launch's worth of descriptors
+    five = ops.gemm_rows_group([calls[0]] * 5)
+    for o in five:
+        assert torch.equal(o[0], singles[0][0])
