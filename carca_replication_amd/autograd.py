@@ -48,41 +48,65 @@ class _Tail:
         return out
 
 
-class _Packs:
-    """Transposed / head-padded weight copies and gradient staging buffers of one attention-bearing module."""
+class _PackPlan:
+    """Every transposed weight copy of a backward pass (ONE pack launch) and every head-padded gradient staging area
+    (zeroed by the gradient buffer's fill, ONE unpack launch at the end)."""
 
-    @staticmethod
-    def staging_floats(attn) -> int:
-        _, _, dpo = ops.padded_dims(attn.d, attn.H)
-        return 3 * ((dpo * attn.d + 3) // 4 * 4) + 3 * ((dpo + 3) // 4 * 4)
+    def __init__(self):
+        self.fw, self.gi, self.greal = [], [], []
 
-    def __init__(self, attn, extra_fwd: List[ops.PackItem], device, tail: "_Tail" = None):
-        d, H = attn.d, attn.H
-        self.d, self.H = d, H
-        self.dpi, self.dhp, self.dpo = ops.padded_dims(d, H)
-        self.dh = d // H
-        hp = (self.dh, self.dhp)
+    def add_attn(self, attn, extra_fwd: List[ops.PackItem]) -> "_Packs":
+        h = _Packs(self, attn, len(self.fw), len(self.gi))
+        hp = (h.dh, h.dhp)
         # Bt operands of the input-gradient GEMMs: Bt[n = input feature][k = head-padded output feature] = W[k][n]
-        items = [ops.PackItem(m.weight, self.dpi, self.dpo, col_heads=hp, transposed=True)
-                 for m in (attn.WQ, attn.WK, attn.WV)]
-        self.wT = ops.PackedWeights(items + extra_fwd, device)
-        self.wT.pack()
+        self.fw += [ops.PackItem(m.weight, h.dpi, h.dpo, col_heads=hp, transposed=True)
+                    for m in (attn.WQ, attn.WK, attn.WV)] + extra_fwd
         # head-padded staging for d WQ/WK/WV [DPO, d] and their biases [DPO]
-        gitems = [ops.PackItem(m.weight, self.dpo, d, row_heads=hp) for m in (attn.WQ, attn.WK, attn.WV)]
-        gitems += [ops.PackItem(m.bias, 1, self.dpo, col_heads=hp) for m in (attn.WQ, attn.WK, attn.WV)]
-        zeroed = tail.take(ops.PackedWeights.size_of(gitems)) if tail is not None else None
-        self.g = ops.PackedWeights(gitems, device, buf=zeroed)
-        if zeroed is None:
-            self.g.buf.zero_()
+        self.gi += [ops.PackItem(m.weight, h.dpo, h.d, row_heads=hp) for m in (attn.WQ, attn.WK, attn.WV)]
+        self.gi += [ops.PackItem(m.bias, 1, h.dpo, col_heads=hp) for m in (attn.WQ, attn.WK, attn.WV)]
+        self.greal += [m.weight for m in (attn.WQ, attn.WK, attn.WV)] + [m.bias for m in (attn.WQ, attn.WK, attn.WV)]
+        return h
+
+    def add_staging(self, item: ops.PackItem, param) -> int:
+        self.gi.append(item)
+        self.greal.append(param)
+        return len(self.gi) - 1
+
+    def staging_floats(self) -> int:
+        return ops.PackedWeights.size_of(self.gi) if self.gi else 0
+
+    def build(self, device, tail: "_Tail") -> None:
+        if self.fw:
+            self.wT = ops.PackedWeights(self.fw, device)
+            self.wT.pack()
+        if self.gi:
+            zeroed = tail.take(self.staging_floats())
+            self.g = ops.PackedWeights(self.gi, device, buf=zeroed)
+            if zeroed is None:
+                self.g.buf.zero_()
+
+    def unpack(self, gbp) -> None:
+        if self.gi:
+            self.g.unpack_into([gbp[id(p)] for p in self.greal], accumulate=True)
 
 
-def _attn_param_grads(packs: _Packs, attn, grads_by_param):
-    real = [grads_by_param[id(m.weight)] for m in (attn.WQ, attn.WK, attn.WV)]
-    real += [grads_by_param[id(m.bias)] for m in (attn.WQ, attn.WK, attn.WV)]
-    packs.g.unpack_into(real, accumulate=True)
+class _Packs:
+    """One attention-bearing module's slice of the plan."""
+
+    def __init__(self, plan: _PackPlan, attn, fw_base: int, g_base: int):
+        self.plan, self.fw_base, self.g_base = plan, fw_base, g_base
+        self.d, self.H = attn.d, attn.H
+        self.dpi, self.dhp, self.dpo = ops.padded_dims(attn.d, attn.H)
+        self.dh = attn.d // attn.H
+
+    def wT(self, i: int) -> Tensor:
+        return self.plan.wT.view(self.fw_base + i)
+
+    def g(self, i: int) -> Tensor:
+        return self.plan.g.view(self.g_base + i)
 
 
-def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after, tail):
+def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, cp, d_wpad):
     """Backward of the sigmoid/ffn head + cross-attention (carca.py:340-347): returns (d p_normed, [d o_g])."""
     dec = model.decoder
     d, H = model.embeds.d, dec.attn.H
@@ -91,9 +115,6 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after, tail):
     B, L = st["B"], st["L"]
     p_x = st["p_x"]
     ngroups = st["ngroups"]
-    cp = _Packs(dec.attn, [], dev, tail)
-    d_wpad = tail.take(dpo)
-    d_wpad = d_wpad[:dpo] if d_wpad is not None else torch.zeros(dpo, dtype=torch.float32, device=dev)
     bgroups = []
     for gi in range(ngroups):
         bgroups.append((st["csave"]["qh"][gi], ys[gi], dys[gi], st["segs"][gi + 1][0]))
@@ -111,11 +132,9 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after, tail):
     else:
         for gi in range(ngroups):
             ops.colsum(dls[gi].view(-1, 1), 1, g_ffn_b)
-    wp_item = ops.PackedWeights([ops.PackItem(dec.ffn.weight, 1, dpo, col_heads=(dh, dhp))], dev)
-    wp_item.buf.copy_(d_wpad)                                             # attention part, head-padded
-    wp_item.unpack_into([g_ffn_w], accumulate=True)
+    # (the attention part of d ffn.weight, head-padded, lands in its staging slice d_wpad: unpacked with the rest)
     # d o_g = dQ_g . W_Q (+ dlogit (x) w), masked like e * mask (carca.py:94)
-    wq_t, wk_t, wv_t = cp.wT.view(0), cp.wT.view(1), cp.wT.view(2)
+    wq_t, wk_t, wv_t = cp.wT(0), cp.wT(1), cp.wT(2)
     ffn_w_plain = dec.ffn.weight.detach().reshape(-1)
     # d o_g and d p_normed do not depend on each other: one launch (the two ~150-block products side by side)
     des_t, (dp,) = ops.gemm_rows_group([
@@ -124,11 +143,10 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after, tail):
              colvec=ffn_w_plain if dec.residual else None, mask_rows=True),
         dict(segs=[dict(a0=dkh, a1=dvh)], bt0=wk_t, N=d, K0=dpo, out_ld=dpi, bt1=wv_t,
              K1=dpo)])
-    wg.add([dict(dy=dqhs[gi], x=o_rows[gi]) for gi in range(ngroups)], dpo, d, cp.g.view(0), cp.g.view(3).view(-1))
+    wg.add([dict(dy=dqhs[gi], x=o_rows[gi]) for gi in range(ngroups)], dpo, d, cp.g(0), cp.g(3).view(-1))
     pn = st["p_normed"].view(-1, st["p_normed"].shape[-1])
-    wg.add([dict(dy=dkh, x=pn)], dpo, d, cp.g.view(1), cp.g.view(4).view(-1))
-    wg.add([dict(dy=dvh, x=pn)], dpo, d, cp.g.view(2), cp.g.view(5).view(-1))
-    after.append(lambda: _attn_param_grads(cp, dec.attn, gbp))
+    wg.add([dict(dy=dkh, x=pn)], dpo, d, cp.g(1), cp.g(4).view(-1))
+    wg.add([dict(dy=dvh, x=pn)], dpo, d, cp.g(2), cp.g(5).view(-1))
     return dp, des_t
 
 
@@ -154,11 +172,16 @@ class _CarcaFn(torch.autograd.Function):
         seed = ops.new_dropout_seed() if model.training else 0
         p_emb = float(model.dropout.p) if model.training else 0.0
         m_embed = ops.dropout_fwd(x, d, p_emb, seed, 1000) if p_emb > 0 else None  # carca.py:416
+        # every module's weights are repacked at a training step: one pack launch for all of them
+        repack: list = []
+        sws = [blk.weights_struct(x.device, repack) for blk in model.encoder]
+        cw = dec.weights_struct(x.device, model.norm, repack) if is_ca else None
+        ops.pack_many(repack)
         blocks = []
         for i, blk in enumerate(model.encoder):
             blk._check_mode()
             bp = blk.drop_p()
-            y, saved = ops.sa_block_fwd(x, p_x, blk.weights_struct(x.device), d, blk.attn.H, blk.residual, save=True,
+            y, saved = ops.sa_block_fwd(x, p_x, sws[i], d, blk.attn.H, blk.residual, save=True,
                                         drop=(bp, seed, 4 * i) if bp > 0 else None)
             saved["x_in"] = x
             saved["p"] = bp
@@ -170,7 +193,6 @@ class _CarcaFn(torch.autograd.Function):
             dec._check_mode()
             H = dec.attn.H
             groups = [(es[gi + 1], segs[gi + 1][0]) for gi in range(len(targets))]
-            cw = dec.weights_struct(x.device, model.norm)
             dp_ = dec.drop_p()
             ys, p_normed, csave = ops.cross_score_fwd(x, p_x, groups, cw, d, H, dec.residual, model.training, save=True,
                                                       drop=(dp_, seed, 2000) if dp_ > 0 else None)
@@ -201,23 +223,31 @@ class _CarcaFn(torch.autograd.Function):
         B, L = st["B"], st["L"]
         p_x = st["p_x"]
         dev = p_x.device
-        # staging areas that must start at zero (head-padded dW / db of every attention module, d ffn.weight) ride
-        # behind the gradients in the same fill
+        # every transposed weight copy and every staging area of this pass: one pack launch, one zero fill (shared with
+        # the gradients), one unpack launch
         from .modules import CrossAttentionBlock
 
-        extra = sum(_Packs.staging_floats(blk.attn) for blk in model.encoder)
+        plan = _PackPlan()
+        cpk, wpad_idx = None, None
         if isinstance(dec, CrossAttentionBlock):
-            extra += _Packs.staging_floats(dec.attn) + (ops.padded_dims(d, dec.attn.H)[2] + 3) // 4 * 4
-        grads, tail_buf = _zeros_like_params(params, extra)
-        tail = _Tail(tail_buf)
+            cpk = plan.add_attn(dec.attn, [])
+            wpad_idx = plan.add_staging(ops.PackItem(dec.ffn.weight, 1, cpk.dpo, col_heads=(cpk.dh, cpk.dhp)),
+                                        dec.ffn.weight)
+        bpks = []
+        for blk in model.encoder:
+            dpi_b = ops.padded_dims(d, blk.attn.H)[0]
+            bpks.append(plan.add_attn(blk.attn, [ops.PackItem(blk.ffn_1.weight[:, :, 0], dpi_b, dpi_b, transposed=True),
+                                                 ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi_b, dpi_b, transposed=True)]))
+        grads, tail_buf = _zeros_like_params(params, plan.staging_floats())
+        plan.build(dev, _Tail(tail_buf))
         gbp = {id(p): g for p, g in zip(params, grads)}
         ys = ctx.saved_tensors
         ngroups = st["ngroups"]
         dys = [dys[gi].contiguous() if dys[gi] is not None else torch.zeros_like(ys[gi]) for gi in range(ngroups)]
         # the small weight-gradient products feed nothing downstream: collected, then issued as ONE grouped launch
-        wg, after = ops.WgradGroup(), []
+        wg = ops.WgradGroup()
         if st["is_ca"]:
-            dp, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, after, tail)
+            dp, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, cpk, plan.g.view(wpad_idx).view(-1))
         else:
             dp, des_t = dec.score_backward(dys, st["dsave"], B, L, d, dpi)
         # final LayerNorm (carca.py:421)
@@ -226,12 +256,9 @@ class _CarcaFn(torch.autograd.Function):
                                dbeta=gbp[id(model.norm.bias)])
 
         # ---------------- encoder blocks, last to first (carca.py:297-318) --------------------------------
-        for blk, sv in zip(reversed(list(model.encoder)), reversed(st["blocks"])):
-            _, _, dpo = ops.padded_dims(d, blk.attn.H)
-            extra = [ops.PackItem(blk.ffn_1.weight[:, :, 0], dpi, dpi, transposed=True),
-                     ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi, dpi, transposed=True)]
-            bp = _Packs(blk.attn, extra, dev, tail)
-            w1_t, w2_t = bp.wT.view(3), bp.wT.view(4)
+        for blk, sv, bp in zip(reversed(list(model.encoder)), reversed(st["blocks"]), reversed(bpks)):
+            dpo = bp.dpo
+            w1_t, w2_t = bp.wT(3), bp.wT(4)
             x_in = sv["x_in"].view(-1, dpi)
             dy = dx
             bp_ = sv["p"]
@@ -248,14 +275,13 @@ class _CarcaFn(torch.autograd.Function):
                                    dbeta=gbp[id(blk.norm2.bias)])
             dqh, dkh_b, dvh_b = ops.sa_attn_bwd(sv["qh"], sv["kh"], sv["vh"], dr, p_x, B, L, d, blk.attn.H,
                                                 m_attn=sv.get("m_attn") if bp_ > 0 else None, drop_scale=bscale)
-            bq_t, bk_t, bv_t = bp.wT.view(0), bp.wT.view(1), bp.wT.view(2)
+            bq_t, bk_t, bv_t = bp.wT(0), bp.wT(1), bp.wT(2)
             (dqn,), (dx_kv,) = ops.gemm_rows_group([  # independent: one launch
                 dict(segs=[dict(a0=dqh, add=dr if blk.residual else None)], bt0=bq_t, N=d, K0=dpo, out_ld=dpi),
                 dict(segs=[dict(a0=dkh_b, a1=dvh_b)], bt0=bk_t, N=d, K0=dpo, out_ld=dpi, bt1=bv_t, K1=dpo)])
-            wg.add([dict(dy=dqh, x=sv["qn"])], dpo, d, bp.g.view(0), bp.g.view(3).view(-1))
-            wg.add([dict(dy=dkh_b, x=x_in)], dpo, d, bp.g.view(1), bp.g.view(4).view(-1))
-            wg.add([dict(dy=dvh_b, x=x_in)], dpo, d, bp.g.view(2), bp.g.view(5).view(-1))
-            after.append(lambda bp=bp, blk=blk: _attn_param_grads(bp, blk.attn, gbp))
+            wg.add([dict(dy=dqh, x=sv["qn"])], dpo, d, bp.g(0), bp.g(3).view(-1))
+            wg.add([dict(dy=dkh_b, x=x_in)], dpo, d, bp.g(1), bp.g(4).view(-1))
+            wg.add([dict(dy=dvh_b, x=x_in)], dpo, d, bp.g(2), bp.g(5).view(-1))
             # q = LayerNorm1(x); K, V from x itself
             dx = ops.layernorm_bwd(dqn, x_in, blk.norm1.weight.detach(), d, dpi, addend=dx_kv,
                                    dgamma=gbp[id(blk.norm1.weight)], dbeta=gbp[id(blk.norm1.bias)])
@@ -265,16 +291,16 @@ class _CarcaFn(torch.autograd.Function):
             dx = ops.mask_mul(dx, st["m_embed"], 1.0 / (1.0 - st["p_emb"]), d, dpi)
         des = [dx] + des_t                      # d e per segment, [rows, dpi]; profile rows still unmasked
         wg.launch()
-        for fn in after:  # head-padded staging buffers -> the real WQ/WK/WV gradients
-            fn()
+        plan.unpack(gbp)  # head-padded staging areas -> the real WQ / WK / WV / ffn gradients
         emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi)
         ctx.st = None
         return (None, None, None) + tuple(grads)
 
 
 def carca_forward_with_grad(model, profile, targets) -> List[Tensor]:
-    from .modules import cached_parameters
+    from .modules import cached_parameters, note_training_forward
 
+    note_training_forward()  # packed-weight caches: see modules._WEIGHT_EPOCH
     params = cached_parameters(model)
     if any(t is not None and t.requires_grad for t in profile) or \
             any(t is not None and t.requires_grad for grp in targets for t in grp):

@@ -204,7 +204,7 @@ class AllEmbedding(Embedding):
         """(W_c [d, ldw], bias_c [d]) with W_c = W_jq W_f and bias_c = W_jq b_f + b_j, composed on the device with
         carca_gemm_rows and cached per weight version (inference only: see CarcaForwardDesc.fold_wc)."""
         prm = (self.feats_embed.weight, self.feats_embed.bias, self.joint_embed.weight, self.joint_embed.bias)
-        key = tuple((p.data_ptr(), p._version) for p in prm)
+        key = (_WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in prm)
         cache = self.__dict__.get("_fold_cache")
         if cache is not None and cache[0] == key:
             return cache[1], cache[2]
@@ -553,6 +553,17 @@ class MultiHeadAttention(nn.Module):
                             "call the block instead")
 
 
+# Packed / composed weight caches are keyed on (data_ptr, _version) of their parameters -- but not every optimizer bumps
+# _version (torch.optim.Adam(fused=True) updates parameters without touching it), so the key also carries an epoch
+# that every training-mode forward advances: a training forward always repacks (weights change every step anyway) and
+# the first inference forward after training repacks once; inference loops keep their caches.
+_WEIGHT_EPOCH = [0]
+
+
+def note_training_forward() -> None:
+    _WEIGHT_EPOCH[0] += 1
+
+
 def cached_parameters(module: nn.Module) -> List[nn.Parameter]:
     """list(module.parameters()) without walking the module tree on every call (0.25 ms per train step at C2).
     The cached list is revalidated against the tree it was built from -- every _parameters / _modules dict of the
@@ -575,8 +586,10 @@ def cached_parameters(module: nn.Module) -> List[nn.Parameter]:
 class _PackedModule:
     """Mixin: (re)packs this module's parameters into the kernels' layout when any of them changed."""
 
-    def _packed(self, items_fn, device) -> ops.PackedWeights:
-        key = (tuple((p.data_ptr(), p._version) for p in self._pack_params()), self._pack_shape(), str(device))
+    def _packed(self, items_fn, device, defer: Optional[list] = None) -> ops.PackedWeights:
+        """defer: a list the caller flushes with ops.pack_many (several modules, one launch); None = pack now."""
+        key = ((_WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in self._pack_params()), self._pack_shape(),
+               str(device))
         cache = self.__dict__.get("_pack_cache")
         if cache is not None and cache[0] == key:
             return cache[1]
@@ -585,7 +598,10 @@ class _PackedModule:
             pw.items = items_fn()
         else:
             pw = ops.PackedWeights(items_fn(), device)
-        pw.pack()
+        if defer is None:
+            pw.pack()
+        else:
+            defer.append(pw)
         self.__dict__["_pack_cache"] = (key, pw)
         return pw
 
@@ -630,8 +646,8 @@ class SelfAttentionBlock(_PackedModule, Encoder):
                    ops.PackItem(self.ffn_2.weight[:, :, 0], dpi, dpi, frag16=True),
                    vec(self.ffn_1.bias), vec(self.ffn_2.bias)])
 
-    def weights_struct(self, device) -> "_lib.SaWeights":
-        pw = self._packed(self._items, device)
+    def weights_struct(self, device, defer: Optional[list] = None) -> "_lib.SaWeights":
+        pw = self._packed(self._items, device, defer)
         w = _lib.SaWeights()
         names = ["ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wk", "wv", "bq", "bk", "bv", "w1", "w2", "b1", "b2"]
         for i, n in enumerate(names):
@@ -690,10 +706,10 @@ class CrossAttentionBlock(_PackedModule, Decoder):
             items.append(ops.PackItem(t, 1, dpi))
         return items
 
-    def weights_struct(self, device, final_norm: Optional[nn.LayerNorm]) -> "_lib.CaWeights":
+    def weights_struct(self, device, final_norm: Optional[nn.LayerNorm], defer: Optional[list] = None) -> "_lib.CaWeights":
         # the final LayerNorm of CARCA (carca.py:421) is fused into this kernel's prologue
         self.__dict__["_final_norm_params"] = (final_norm.weight, final_norm.bias) if final_norm is not None else ()
-        pw = self._packed(self._items, device)
+        pw = self._packed(self._items, device, defer)
         w = _lib.CaWeights()
         for i, n in enumerate(["wq", "wk", "wv", "bq", "bk", "bv", "ffn_w_pad", "ffn_w", "ffn_b"]):
             setattr(w, n, pw.ptr(i))
@@ -871,12 +887,14 @@ class CARCA(_PackedModule, Model):
         else:
             D.fold_wc, D.fold_bias, D.fold_ldwc = None, None, 0
         D.x_work[0], D.x_work[1] = plan["xw"][0].data_ptr(), plan["xw"][1].data_ptr()
+        repack: list = []  # (after a training step every module repacks: one launch for all of them)
         for i, blk in enumerate(self.encoder):
             blk._check_mode()
-            D.sa[i] = blk.weights_struct(dev)
+            D.sa[i] = blk.weights_struct(dev, repack)
             keep.append(blk.__dict__["_pack_cache"])
             D.sa_residual[i] = int(bool(blk.residual))
-        D.ca = dec.weights_struct(dev, self.norm)
+        D.ca = dec.weights_struct(dev, self.norm, repack)
+        ops.pack_many(repack)
         D.ca_residual, D.training = int(bool(dec.residual)), int(bool(self.training))
         ys = []
         for gi, N in enumerate(Ns):

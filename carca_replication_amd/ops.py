@@ -218,10 +218,7 @@ class PackedWeights:
         return keep
 
     def pack(self) -> None:
-        lib = _lib.load()
-        keep = self._fill([it.src for it in self.items])
-        _lib.check(lib.carca_pack_weights(self._descs, len(self.items), _stream()), "pack_weights")
-        del keep
+        pack_many([self])
 
     def unpack_into(self, grads, accumulate: bool = False) -> None:
         """Inverse map for gradients: grads[i] (real shape of items[i].src) (+)= packed item i of this buffer."""
@@ -229,6 +226,26 @@ class PackedWeights:
         keep = self._fill(grads)
         _lib.check(lib.carca_unpack_grads(self._descs, len(self.items), int(accumulate), _stream()), "unpack_grads")
         del keep
+
+
+def pack_many(pws: Sequence[PackedWeights]) -> None:
+    """(Re)fill several PackedWeights buffers with ONE carca_pack_weights call (the modules of a model repack together
+    at every training step)."""
+    if not pws:
+        return
+    keep = [pw._fill([it.src for it in pw.items]) for pw in pws]
+    n = sum(len(pw.items) for pw in pws)
+    if len(pws) == 1:
+        arr = pws[0]._descs
+    else:
+        arr = (_lib.PackDesc * n)()
+        i = 0
+        for pw in pws:
+            for d in pw._descs:
+                C.memmove(C.byref(arr[i]), C.byref(d), C.sizeof(_lib.PackDesc))
+                i += 1
+    _lib.check(_lib.load().carca_pack_weights(arr, n, _stream()), "pack_weights")
+    del keep
 
 
 # --------------------------------------------------------------------------------------------------

@@ -74,6 +74,9 @@ class Adam(torch.optim.Optimizer):
                 a.p, a.g, a.m, a.v, a.n = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), \
                     p.numel()
             torch._foreach_add_(counters, 1.0)
+            # the kernel writes the parameters behind torch's back: bump their version counters, which is what the
+            # modules' packed-weight caches (and autograd's saved-tensor checks) go by
+            torch.autograd.graph.increment_version(live)
             b1, b2 = group["betas"]
             if len(steps) == 1:
                 _lib.check(lib.carca_adam_step(arr, len(live), float(group["lr"]), float(b1), float(b2), float(group["eps"]),

@@ -91,3 +91,74 @@ def test_adam_skips_parameters_without_gradient_and_rejects_bad_input():
     cpu[0].grad = torch.ones(4)
     with pytest.raises(CarcaHipError):
         Adam(cpu).step()
+
+
+def test_adam_step_invalidates_packed_weight_caches():
+    """The kernel updates parameters through raw pointers; the modules repack their weights when a parameter's
+    version changes, so the optimizer has to bump it.  After a step the forward must see the NEW attention weights:
+    same outputs as a fresh model loaded with the updated state_dict."""
+    import copy
+
+    from carca_replication_amd.optim import Adam
+    from tests.golden_util import load
+    from tests.model_util import model_from_fixture
+
+    fx = load("g2_d90h3")
+    model = model_from_fixture(fx).cuda().train()
+    g = lambda k: fx.ins[k].cuda()  # noqa: E731
+    L = fx.ins["p_x"].shape[1]
+    pos = tuple(g(k)[:, :L].contiguous() for k in ("o_x", "o_a", "o_c"))
+    neg = tuple(g(k)[:, L:].contiguous() for k in ("o_x", "o_a", "o_c"))
+    profile = (g("p_x"), g("p_a"), g("p_c"))
+    opt = Adam(model.parameters(), lr=5e-2, betas=(0.9, 0.98))  # big steps: stale weights would be obvious
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        y = model(profile=profile, targets=[pos, neg])
+        (y * y).sum().backward()
+        opt.step()
+    with torch.no_grad():
+        model.eval()
+        y_now = model(profile=profile, targets=[pos, neg])
+        fresh = model_from_fixture(fx).cuda().eval()
+        fresh.load_state_dict(copy.deepcopy(model.state_dict()))
+        y_fresh = fresh(profile=profile, targets=[pos, neg])
+    assert torch.equal(y_now, y_fresh)
+    # and in train mode (the autograd path packs separately)
+    model.train()
+    fresh.train()
+    y_t = model(profile=profile, targets=[pos, neg])
+    y_ft = fresh(profile=profile, targets=[pos, neg])
+    assert torch.equal(y_t, y_ft)
+
+
+def test_fused_torch_adam_does_not_leave_stale_packed_weights():
+    """torch.optim.Adam(fused=True) does not bump parameter versions; the packed-weight caches must not rely on them."""
+    import copy
+
+    from tests.golden_util import load
+    from tests.model_util import model_from_fixture
+
+    fx = load("g2_d90h3")
+    model = model_from_fixture(fx).cuda().train()
+    g = lambda k: fx.ins[k].cuda()  # noqa: E731
+    L = fx.ins["p_x"].shape[1]
+    pos = tuple(g(k)[:, :L].contiguous() for k in ("o_x", "o_a", "o_c"))
+    neg = tuple(g(k)[:, L:].contiguous() for k in ("o_x", "o_a", "o_c"))
+    profile = (g("p_x"), g("p_a"), g("p_c"))
+    opt = torch.optim.Adam(model.parameters(), lr=5e-2, betas=(0.9, 0.98), fused=True)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        y = model(profile=profile, targets=[pos, neg])
+        (y * y).sum().backward()
+        opt.step()
+    fresh = model_from_fixture(fx).cuda()
+    fresh.load_state_dict(copy.deepcopy(model.state_dict()))
+    for mode in (True, False):  # the training path packs per step; the inference path repacks once after training
+        model.train(mode)
+        fresh.train(mode)
+        with torch.set_grad_enabled(mode):
+            assert torch.equal(model(profile=profile, targets=[pos, neg]), fresh(profile=profile, targets=[pos, neg]))
+    model.fold_embedding(True)
+    fresh.fold_embedding(True)
+    with torch.no_grad():
+        assert torch.equal(model(profile=profile, targets=[pos, neg]), fresh(profile=profile, targets=[pos, neg]))
