@@ -195,26 +195,32 @@ class PackedWeights:
         return self.buf[self.offsets[i]: self.offsets[i] + it.dst_rows * it.dst_cols].view(it.dst_rows, it.dst_cols)
 
     def _fill(self, tensors) -> list:
+        """Point the descriptors at `tensors` (the items' sources, or gradient tensors of the same shapes).  Everything
+        that does not depend on the tensors is written once (this runs for ~70 descriptors per train step)."""
         keep = []
+        base = self.buf.data_ptr()
+        first = not self.__dict__.get("_static_done")
         for i, (it, src) in enumerate(zip(self.items, tensors)):
-            src = src.detach()
-            src2 = src.reshape(1, -1) if src.dim() == 1 else src.reshape(src.shape[0], -1)
-            if src2.dtype != torch.float32 or src2.stride(1) != 1:
-                raise CarcaHipError("pack: parameters must be fp32 with unit inner stride")
-            _need_cuda(src2)
-            keep.append(src2)
+            if src.requires_grad:
+                src = src.detach()
+            if src.dim() != 2:
+                src = src.reshape(1, -1) if src.dim() == 1 else src.reshape(src.shape[0], -1)
+            if src.dtype != torch.float32 or src.stride(1) != 1 or not src.is_cuda:
+                raise CarcaHipError("pack: parameters must be fp32 CUDA tensors with unit inner stride")
+            keep.append(src)
             d = self._descs[i]
-            d.src, d.dst = src2.data_ptr(), self.ptr(i)
-            if it.transposed:
-                d.rows, d.cols = src2.shape[1], src2.shape[0]
-            else:
-                d.rows, d.cols = src2.shape[0], src2.shape[1]
-            d.src_ld = src2.stride(0)
-            d.dst_rows, d.dst_cols = it.dst_rows, it.dst_cols
-            d.row_dh, d.row_dhp = it.row_heads
-            d.col_dh, d.col_dhp = it.col_heads
-            d.transposed = int(it.transposed)
-            d.frag16 = int(it.frag16)
+            d.src, d.dst, d.src_ld = src.data_ptr(), base + 4 * self.offsets[i], src.stride(0)
+            r, c = (src.shape[1], src.shape[0]) if it.transposed else (src.shape[0], src.shape[1])
+            if first:
+                d.rows, d.cols = r, c
+                d.dst_rows, d.dst_cols = it.dst_rows, it.dst_cols
+                d.row_dh, d.row_dhp = it.row_heads
+                d.col_dh, d.col_dhp = it.col_heads
+                d.transposed = int(it.transposed)
+                d.frag16 = int(it.frag16)
+            elif d.rows != r or d.cols != c:
+                raise CarcaHipError("pack: tensor shape differs from the item this descriptor was built for")
+        self._static_done = True
         return keep
 
     def pack(self) -> None:
