@@ -22,6 +22,15 @@ extern "C" int carca_set_debug_buffer(void* p) {
   return CARCA_OK;
 }
 int carca_tuning(int key) { return (key >= 0 && key < CARCA_TUNE_COUNT) ? g_tuning[key] : 0; }
+int carca_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
 extern "C" int carca_set_tuning(int key, int value) {
   CARCA_CHECK_ARG(key >= 0 && key < CARCA_TUNE_COUNT, "set_tuning: unknown key %d", key);
   g_tuning[key] = value;

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
                                                           int ld_da, const int32_t* __restrict__ ids,
                                                           float* __restrict__ dqh, float* __restrict__ dkh,
                                                           float* __restrict__ dvh, int L, int dh,
-                                                          const uint8_t* __restrict__ m_attn, float dscale) {
+                                                          const uint8_t* __restrict__ m_attn, float dscale, int nparts) {
   using G = AttGeom<DPI, DHP, NH>;
   constexpr int SO = G::SO, DPO = G::DPO, NW = 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -314,7 +314,10 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
   float* PT = Os + ATT_LMAX * SO;   // [64][ATT_SP]
   float* DST = PT + ATT_LMAX * ATT_SP;
 
-  const int u = blockIdx.x;
+  // With fewer users than CUs the HEADS of a user are shared by two workgroups (their outputs are disjoint column
+  // ranges of dQ / dK / dV: nothing passes between them, no atomics).
+  const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
+  const int h_per = (NH + nparts - 1) / nparts, h_lo = part * h_per, h_hi = min(NH, h_lo + h_per);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int LT = (L + 15) >> 4;
   const int32_t* uid = ids + (size_t)u * L;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
   const int ln = lane & 15, mq = lane >> 4;
   const float* vh_user = vh + ubase * DPO;
 #pragma unroll 1
-  for (int h = 0; h < NH; ++h) {
+  for (int h = h_lo; h < h_hi; ++h) {
     for (int qt = wave; qt < LT; qt += NW) {
       const int q = 16 * qt + ln;
       const bool q_ok = (pmask >> q) & 1ull;
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
                                                              const float* __restrict__ ffn_w_pad,
                                                              float* __restrict__ dkh, float* __restrict__ dvh,
                                                              float* __restrict__ d_ffn_w_pad, int L, int dh,
-                                                             int training, float dscale) {
+                                                             int training, float dscale, int nparts) {
   using G = AttGeom<DPI, DHP, NH>;
   constexpr int SO = G::SO, DPO = G::DPO, NW = 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -413,7 +416,9 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
   float* wps = dls + 64;                 // [DPO] ffn weight, head-padded
   float* dwp = wps + DPO;                // [DPO] its gradient, accumulated over the user's targets
 
-  const int u = blockIdx.x;
+  // heads shared by two workgroups when users <= CUs / 2 (see sa_attn_bwd_kernel); dlogit is written by the first
+  const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
+  const int h_per = (NH + nparts - 1) / nparts, h_lo = part * h_per, h_hi = min(NH, h_lo + h_per);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int LT = (L + 15) >> 4;
   const int32_t* uid = p_ids + (size_t)u * L;
@@ -453,13 +458,13 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
         if (tid < nq) {
           const float yv = grp.y[gbase + tid];
           dl = grp.dy[gbase + tid] * yv * (1.0f - yv);  // d sigmoid
-          if (grp.dlogit) grp.dlogit[gbase + tid] = dl;
+          if (grp.dlogit && part == 0) grp.dlogit[gbase + tid] = dl;
         }
         dls[tid] = dl;
       }
       __syncthreads();
 #pragma unroll 1
-      for (int h = 0; h < NH; ++h) {
+      for (int h = h_lo; h < h_hi; ++h) {
         for (int qt = wave; qt < QT; qt += NW) {
           const int qloc = 16 * qt + ln;      // row in the chunk
           const int nslot = n0 + qloc;        // target slot in the group
@@ -553,8 +558,9 @@ int launch_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const 
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds_bytes, stream, qh, kh, vh, d_attn, ld_da, ids, dqh, dkh, dvh, L, d / NH,
-                     m_attn, dscale);
+  const int nparts = (NH >= 2 && carca_tuning(CARCA_TUNE_ATTN_VARIANT) != 1 && 2 * B <= carca_num_cus()) ? 2 : 1;
+  hipLaunchKernelGGL(kern, dim3(B * nparts), dim3(512), lds_bytes, stream, qh, kh, vh, d_attn, ld_da, ids, dqh, dkh, dvh, L,
+                     d / NH, m_attn, dscale, nparts);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -575,8 +581,9 @@ int launch_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds_bytes, stream, kh, vh, p_ids, groups, ffn_w_pad, dkh, dvh,
-                     d_ffn_w_pad, L, d / NH, training, dscale);
+  const int nparts = (NH >= 2 && carca_tuning(CARCA_TUNE_ATTN_VARIANT) != 1 && 2 * B <= carca_num_cus()) ? 2 : 1;
+  hipLaunchKernelGGL(kern, dim3(B * nparts), dim3(512), lds_bytes, stream, kh, vh, p_ids, groups, ffn_w_pad, dkh, dvh,
+                     d_ffn_w_pad, L, d / NH, training, dscale, nparts);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

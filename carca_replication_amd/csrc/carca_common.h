@@ -105,6 +105,7 @@ void carca_set_error(const char* fmt, ...);
 // Keys 3..5 are used by number (see include/carca_hip.h).
 enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_COUNT = 8 };
 int carca_tuning(int key);
+int carca_num_cus();  // compute units of the current device (cached)
 unsigned long long* carca_debug_buffer();  // device buffer for in-kernel phase stamps (diagnostic runs), or null
 #define CARCA_CHECK_ARG(cond, ...)            \
   do {                                        \
