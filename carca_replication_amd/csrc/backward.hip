@@ -194,8 +194,8 @@ __device__ __forceinline__ void masked_softmax(f32x4 (&p)[ATT_LT], unsigned okbi
 //   dofrag(ft) must return the lane's Bt fragment of dO: dO[q][hDHP + 16ft + 4mq + 0..3]
 //   returns p (probabilities) so that the cross kernel can also form O.
 template <int DHP, int SO, typename DoFrag>
-__device__ __forceinline__ void attn_bwd_phase1(const float* Qs, const float* Ks, const float* __restrict__ vh_user,
-                                                int L, int dpo, int h, int qrow, int qcol, int nkt, unsigned okbits,
+__device__ __forceinline__ void attn_bwd_phase1(const float* Qs, const float* Ks, const float* V, int vstride,
+                                                int L, int h, int qrow, int qcol, int nkt, unsigned okbits,
                                                 float sqrt_dh, DoFrag dofrag, float* PT, float* DST,
                                                 float* __restrict__ dq_row, f32x4 (&p)[ATT_LT], int lane,
                                                 const uint8_t* __restrict__ mrow = nullptr, float dscale = 1.f) {
@@ -214,13 +214,13 @@ __device__ __forceinline__ void attn_bwd_phase1(const float* Qs, const float* Ks
     dp[kt] = zero4();
     if (kt < nkt) {
       const float* krow = Ks + (16 * kt + ln) * SO + h * DHP + 4 * mq;
-      const int vr = min(16 * kt + ln, L - 1);
-      const float* vrow = vh_user + (size_t)vr * dpo + h * DHP + 4 * mq;
+      // V: the user's rows staged in LDS like K (stride SO), or straight from HBM where LDS has no room (stride DPO)
+      const float* vrow = V + (size_t)min(16 * kt + ln, L - 1) * vstride + h * DHP + 4 * mq;
       f32x4 s = zero4(), t = zero4();
 #pragma unroll
       for (int ft = 0; ft < NFH; ++ft) {
         s = mfma16_group(lds4(krow + 16 * ft), qf[ft], s);    // S^T[key][q]
-        t = mfma16_group(glb4(vrow + 16 * ft), dof[ft], t);   // dP^T[key][q] = V[key] . dO[q]
+        t = mfma16_group(*reinterpret_cast<const f32x4*>(vrow + 16 * ft), dof[ft], t);   // dP^T[key][q] = V[key] . dO[q]
       }
       p[kt] = s;
       dp[kt] = t;
@@ -298,6 +298,11 @@ __device__ __forceinline__ f32x4 attn_bwd_phase2_tile(const float* M, int kt, in
 
 // ---- SelfAttentionBlock's attention core --------------------------------------------------------------
 template <int DPI, int DHP, int NH>
+constexpr bool sa_bwd_v_in_lds() {
+  return sizeof(float) * (4 * ATT_LMAX * AttGeom<DPI, DHP, NH>::SO + 2 * ATT_LMAX * ATT_SP) <= 160 * 1024;
+}
+
+template <int DPI, int DHP, int NH>
 __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restrict__ qh, const float* __restrict__ kh,
                                                           const float* __restrict__ vh,
                                                           const float* __restrict__ d_attn /*[B*L, ld] plain*/,
@@ -311,7 +316,9 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
   float* Qs = lds;                  // [64][SO]
   float* Ks = Qs + ATT_LMAX * SO;   // [64][SO]
   float* Os = Ks + ATT_LMAX * SO;   // [64][SO]  dO
-  float* PT = Os + ATT_LMAX * SO;   // [64][ATT_SP]
+  constexpr bool V_LDS = sa_bwd_v_in_lds<DPI, DHP, NH>();  // (d = 128: four [64][136] images + P / dS exceed 160 KB)
+  float* Vs = Os + ATT_LMAX * SO;   // [64][SO] when V_LDS
+  float* PT = Vs + (V_LDS ? ATT_LMAX * SO : 0);  // [64][ATT_SP]
   float* DST = PT + ATT_LMAX * ATT_SP;
 
   // With fewer users than CUs the HEADS of a user are shared by two workgroups (their outputs are disjoint column
@@ -328,11 +335,12 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
   constexpr int V4 = DPO / 4;
   for (int i = tid; i < 16 * LT * V4; i += 512) {
     const int r = i / V4, c4 = i - r * V4;
-    f32x4 q = zero4(), k = zero4(), o = zero4();
+    f32x4 q = zero4(), k = zero4(), o = zero4(), v = zero4();
     if (r < L) {
       const size_t off = (ubase + r) * DPO + 4 * c4;
       q = glb4(qh + off);
       k = glb4(kh + off);
+      if (V_LDS) v = glb4(vh + off);
       const float* dar = d_attn + (ubase + r) * ld_da;  // plain feature order -> head-padded order
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -343,12 +351,14 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
     *reinterpret_cast<f32x4*>(Qs + r * SO + 4 * c4) = q;
     *reinterpret_cast<f32x4*>(Ks + r * SO + 4 * c4) = k;
     *reinterpret_cast<f32x4*>(Os + r * SO + 4 * c4) = o;
+    if (V_LDS) *reinterpret_cast<f32x4*>(Vs + r * SO + 4 * c4) = v;
   }
   __syncthreads();
 
   const float sqrt_dh = sqrtf((float)dh);
   const int ln = lane & 15, mq = lane >> 4;
-  const float* vh_user = vh + ubase * DPO;
+  const float* vsrc = V_LDS ? Vs : vh + ubase * DPO;
+  const int vstride = V_LDS ? SO : DPO;
 #pragma unroll 1
   for (int h = h_lo; h < h_hi; ++h) {
     for (int qt = wave; qt < LT; qt += NW) {
@@ -366,8 +376,8 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
       auto dofrag = [&](int ft) { return lds4(Os + q * SO + h * DHP + 16 * ft + 4 * mq); };
       float* dq_row = q < L ? dqh + (ubase + q) * DPO : nullptr;
       const uint8_t* mrow = m_attn ? m_attn + (((size_t)u * NH + h) * L + (q < L ? q : 0)) * L : nullptr;
-      attn_bwd_phase1<DHP, SO>(Qs, Ks, vh_user, L, DPO, h, q, q, qt + 1, okbits, sqrt_dh, dofrag, PT, DST, dq_row, p,
-                               lane, mrow, dscale);
+      attn_bwd_phase1<DHP, SO>(Qs, Ks, vsrc, vstride, L, h, q, q, qt + 1, okbits, sqrt_dh, dofrag, PT, DST, dq_row, p, lane,
+                               mrow, dscale);
     }
     __syncthreads();
     // dK / dV tiles: job = (which, kt, ft); queries that can see key tile kt are tiles qt >= kt
@@ -410,7 +420,8 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Qs = lds;                       // [64][SO] one chunk of <= 64 targets
   float* Ks = Qs + ATT_LMAX * SO;        // [64][SO]
-  float* PT = Ks + ATT_LMAX * SO;        // [64][ATT_SP]
+  float* Vs = Ks + ATT_LMAX * SO;        // [64][SO]
+  float* PT = Vs + ATT_LMAX * SO;        // [64][ATT_SP]
   float* DST = PT + ATT_LMAX * ATT_SP;   // [64][ATT_SP]
   float* dls = DST + ATT_LMAX * ATT_SP;  // [64] dlogit of the chunk
   float* wps = dls + 64;                 // [DPO] ffn weight, head-padded
@@ -428,9 +439,13 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
 
   for (int i = tid; i < 16 * LT * V4; i += 512) {
     const int r = i / V4, c4 = i - r * V4;
-    f32x4 k = zero4();
-    if (r < L) k = glb4(kh + (ubase + r) * DPO + 4 * c4);
+    f32x4 k = zero4(), v = zero4();
+    if (r < L) {
+      k = glb4(kh + (ubase + r) * DPO + 4 * c4);
+      v = glb4(vh + (ubase + r) * DPO + 4 * c4);
+    }
     *reinterpret_cast<f32x4*>(Ks + r * SO + 4 * c4) = k;
+    *reinterpret_cast<f32x4*>(Vs + r * SO + 4 * c4) = v;
   }
   for (int i = tid; i < DPO; i += 512) {
     wps[i] = ffn_w_pad[i];
@@ -439,7 +454,6 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
 
   const float sqrt_dh = sqrtf((float)dh);
   const int ln = lane & 15, mq = lane >> 4;
-  const float* vh_user = vh + ubase * DPO;
   bool first_pass = true;
   for (int gi = 0; gi < groups.n; ++gi) {
     const CarcaCrossBwdGroup grp = groups.g[gi];
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
           float* dq_row = in_range ? grp.dqh + (gbase + qloc) * DPO : nullptr;
           const uint8_t* mrow =
               grp.m_attn ? grp.m_attn + (((size_t)u * NH + h) * grp.N + (in_range ? nslot : 0)) * L : nullptr;
-          attn_bwd_phase1<DHP, SO>(Qs, Ks, vh_user, L, DPO, h, qloc, qloc, nkt, okbits, sqrt_dh, dofrag, PT, DST,
+          attn_bwd_phase1<DHP, SO>(Qs, Ks, Vs, SO, L, h, qloc, qloc, nkt, okbits, sqrt_dh, dofrag, PT, DST,
                                    dq_row, p, lane, mrow, dscale);
           // d w_pad[f] += sum_q dl[q] * O[q][f],  O^T[f][q] = sum_key V[key][f] P^T[key][q]
 #pragma unroll
@@ -496,10 +510,8 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
             for (int kt = 0; kt < ATT_LT; ++kt)
               if (kt < nkt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const int vr = min(16 * kt + 4 * mq + r, L - 1);
-                  acc = mfma16(vh_user[(size_t)vr * DPO + h * DHP + 16 * ft + ln], p[kt][r], acc);
-                }
+                for (int r = 0; r < 4; ++r)
+                  acc = mfma16(Vs[(16 * kt + 4 * mq + r) * SO + h * DHP + 16 * ft + ln], p[kt][r], acc);
               }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -547,7 +559,7 @@ int launch_sa_attn_bwd(const float* qh, const float* kh, const float* vh, const 
                        const int32_t* ids, float* dqh, float* dkh, float* dvh, int B, int L, int d,
                        const uint8_t* m_attn, float dscale, hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
-  const size_t lds_bytes = sizeof(float) * (3 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP);
+  const size_t lds_bytes = sizeof(float) * ((sa_bwd_v_in_lds<DPI, DHP, NH>() ? 4 : 3) * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP);
   auto kern = sa_attn_bwd_kernel<DPI, DHP, NH>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -570,7 +582,7 @@ int launch_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids
                           const float* ffn_w_pad, float* dkh, float* dvh, float* d_ffn_w_pad, int B, int L, int d,
                           int training, float dscale, hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
-  const size_t lds_bytes = sizeof(float) * (2 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP + 64 + 2 * G::DPO);
+  const size_t lds_bytes = sizeof(float) * (3 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP + 64 + 2 * G::DPO);
   auto kern = cross_attn_bwd_kernel<DPI, DHP, NH>;
   static bool attr_set = false;
   if (!attr_set) {
