@@ -274,14 +274,19 @@ __global__ __launch_bounds__((BM / 32) * 64) void gemm_rows_group_kernel(const G
 // MFMAs, fragments are double-buffered in registers one 8-k group ahead, LDS is double-buffered so
 // that there is ONE barrier per K step, global loads run two tiles ahead on a scalar base + constant
 // per-lane offsets (no address arithmetic in the loop), and all LDS addresses are immediates.
-template <int DBG>
+// TN = 3: tile 384 x 96 (the C2 feature GEMM: 5 column blocks of N = 450).  TN = 4: tile 384 x 128 for N that 128-wide
+// blocks cover in one round where 96-wide ones need two (g = 640: 5 x 51 = 255 blocks instead of 7 x 51 = 357); its B
+// tile is 1024 staging slots for 768 threads: every thread carries two, the second one live for threads 0..255 and a
+// clamped load + a store into a dummy LDS strip for the others (the pipelined body stays branch-free).
+template <int DBG, int TN = 3>
 __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
-  constexpr int BM = 384, BN = 96, BK = 32, NW = 12, NT = 768, LS = BK + 4, TN = 3, C4 = BK / 4;
-  constexpr int A_PER = BM * C4 / NT, B_PER = 1;  // 4 + 1 staged float4 per thread and tile
-  static_assert(BN * C4 == NT, "one B slot per thread");
+  constexpr int BM = 384, BN = 32 * TN, BK = 32, NW = 12, NT = 768, LS = BK + 4, C4 = BK / 4;
+  constexpr int A_PER = BM * C4 / NT, B_PER = (BN * C4 + NT - 1) / NT;  // 4 + 1 (or 2) staged float4 per thread and tile
+  static_assert(TN == 3 || TN == 4, "column tiles per block");
   constexpr int A_BUF = BM * LS, B_BUF = BN * LS;  // floats per LDS buffer
+  constexpr int DUMMY = (B_PER * NT > BN * C4) ? (B_PER * NT - BN * C4) * 4 : 0;  // floats: dead B slots land here
   __shared__ __attribute__((aligned(16))) float As[2 * A_BUF];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * B_BUF];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * B_BUF + DUMMY];
 
   const CarcaGemmDesc& D = args.d;
   const int id = blockIdx.x, total = args.nrb * args.ncb;
@@ -316,34 +321,47 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
     a_byte[i] = (unsigned)((aoff0[i] + c4 * 4) * sizeof(float));
     a_lds[i] = r * LS + c4 * 4;
   }
-  const int b_r = tid / C4, b_c4 = tid - b_r * C4;
-  const int b_gn = min(n0 + b_r, D.N - 1);
-  const unsigned b_byte = (unsigned)(((size_t)b_gn * D.ldb0 + b_c4 * 4) * sizeof(float));
-  const int b_lds = b_r * LS + b_c4 * 4;
+  int b_gn[B_PER], b_c4[B_PER];
+  int b_at[2][B_PER];  // float index inside Bs of the slot's 16 bytes, per LDS buffer (dead slots: the dummy strip)
+  unsigned b_byte[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int slot = tid + i * NT;
+    const bool live = DUMMY == 0 || slot < BN * C4;
+    const int r = live ? slot / C4 : 0;
+    b_c4[i] = slot % C4;
+    b_gn[i] = min(n0 + r, D.N - 1);
+    b_byte[i] = (unsigned)(((size_t)b_gn[i] * D.ldb0 + b_c4[i] * 4) * sizeof(float));
+    b_at[0][i] = live ? r * LS + b_c4[i] * 4 : 2 * B_BUF + (slot - BN * C4) * 4;
+    b_at[1][i] = live ? B_BUF + r * LS + b_c4[i] * 4 : 2 * B_BUF + (slot - BN * C4) * 4;
+  }
 
-  f32x4 ra[A_PER], rbv;
+  f32x4 ra[A_PER], rbv[B_PER];
   // Buffer loads: scalar resource + 32-bit per-lane offset + scalar tile offset -- no address arithmetic in the
   // loop and half the address data of a 64-bit global_load per instruction.
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sg.a0, 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)D.bt0, 0, -1, 0x00020000);
   int k_byte = 0;  // scalar: byte offset of the NEXT tile to load inside a row
-  auto load_fast = [&](int i) {  // slot i of that tile (i == A_PER: the B slot)
-    const u32x4 v = i < A_PER ? __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_byte[i < A_PER ? i : 0], k_byte, 0)
-                              : __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_byte, k_byte, 0);
+  auto load_fast = [&](int i) {  // slot i of that tile (i >= A_PER: B slot i - A_PER)
+    const int ia = i < A_PER ? i : 0, ib = i < A_PER ? 0 : i - A_PER;
+    const u32x4 v = i < A_PER ? __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_byte[ia], k_byte, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_byte[ib], k_byte, 0);
     f32x4 f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(v[e]);
     if (i < A_PER)
-      ra[i < A_PER ? i : 0] = f;
+      ra[ia] = f;
     else
-      rbv = f;
+      rbv[ib] = f;
   };
   auto store_slot = [&](int i, int buf) {
-    if (i < A_PER)
+    if (i < A_PER) {
       *reinterpret_cast<f32x4*>(&As[buf * A_BUF + a_lds[i]]) = ra[i];
-    else
-      *reinterpret_cast<f32x4*>(&Bs[buf * B_BUF + b_lds]) = rbv;
+    } else {
+      // (dead slots -- the second B slot of threads >= 256 at TN = 4 -- write their own 16 bytes of the dummy strip)
+      *reinterpret_cast<f32x4*>(&Bs[b_at[buf][i - A_PER]]) = rbv[i - A_PER];
+    }
   };
   auto load4 = [](const float* p, bool full, int kk, int klen) -> f32x4 {
     if (full) return *reinterpret_cast<const f32x4_u*>(p);
@@ -367,7 +385,9 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
       const int c4 = (tid + i * NT) % C4;
       ra[i] = load4(abase + (src1 ? aoff1[i] : aoff0[i]) + k0 + c4 * 4, full, k0 + c4 * 4, klen);
     }
-    rbv = load4(bbase + (size_t)b_gn * ldb + k0 + b_c4 * 4, full, k0 + b_c4 * 4, klen);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      rbv[i] = load4(bbase + (size_t)b_gn[i] * ldb + k0 + b_c4[i] * 4, full, k0 + b_c4[i] * 4, klen);
   };
 
   f32x16 acc[TN];
@@ -389,11 +409,12 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
     else
       fb[j - 1] = *reinterpret_cast<const f32x4*>(b_frag + buf * B_BUF + (j - 1) * 32 * LS + kg * 8);
   };
-  // 12 MFMAs of one 8-k group; aux(i) is issued behind MFMA i (i = 0..11) and must be independent of it
+  // 4 TN MFMAs of one 8-k group; aux(i) is issued behind MFMA i and must be independent of it
+  constexpr int NR = TN + 1;  // fragment reads per group: A, then the TN B tiles
   auto mfma_group = [&](const f32x4& fa, const f32x4(&fb)[TN], auto&& aux) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      acc[i % 3] = mfma32(fa[i / 3], fb[i % 3][i / 3], acc[i % 3]);
+    for (int i = 0; i < 4 * TN; ++i) {
+      acc[i % TN] = mfma32(fa[i / TN], fb[i % TN][i / TN], acc[i % TN]);
       CARCA_PIN();
       aux(i);
       CARCA_PIN();
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
     constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
     const bool has1 = t + 1 < nfast, has2 = t + 2 < nfast;
     mfma_group(fa0, fb0, [&](int i) {
-      if (i < 4) read_frag(i, CUR, 1, fa1, fb1);
+      if (i < NR) read_frag(i, CUR, 1, fa1, fb1);
     });
     if constexpr (DBG) {
       const unsigned long long ta = __builtin_amdgcn_s_memtime();
@@ -417,17 +438,18 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
       w_vm += __builtin_amdgcn_s_memtime() - ta;
       CARCA_PIN();
     }
+    static_assert(NR + A_PER + B_PER <= 4 * TN, "a group's gaps hold its reads and the tile's staging slots");
     mfma_group(fa1, fb1, [&](int i) {
-      if (i < 4)
+      if (i < NR)
         read_frag(i, CUR, 2, fa0, fb0);
-      else if (i < 4 + A_PER + B_PER && has1)
-        store_slot(i - 4, NXT);
+      else if (i < NR + A_PER + B_PER && has1)
+        store_slot(i - NR, NXT);
     });
     mfma_group(fa0, fb0, [&](int i) {
-      if (i < 4)
+      if (i < NR)
         read_frag(i, CUR, 3, fa1, fb1);
-      else if (i < 4 + A_PER + B_PER && has2)
-        load_fast(i - 4);
+      else if (i < NR + A_PER + B_PER && has2)
+        load_fast(i - NR);
     });
     if (has2) k_byte += BK * sizeof(float);
     CARCA_PIN();
@@ -441,7 +463,7 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
     }
     CARCA_PIN();
     mfma_group(fa1, fb1, [&](int i) {
-      if (i < 4 && has1) read_frag(i, NXT, 0, fa0, fb0);
+      if (i < NR && has1) read_frag(i, NXT, 0, fa0, fb0);
     });
   };
 
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) read_frag(j, 0, 0, fa0, fb0);
+    for (int j = 0; j < NR; ++j) read_frag(j, 0, 0, fa0, fb0);
     if constexpr (DBG) t_begin = __builtin_amdgcn_s_memtime();
     int t = 0;
     for (; t + 1 < nfast; t += 2) {
@@ -733,7 +755,7 @@ static int launch_gemm_rows(const CarcaGemmDesc* desc, hipStream_t stream) {
   return CARCA_OK;
 }
 
-template <int DBG>
+template <int DBG, int TN = 3>
 static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream) {
   GemmDev g{};
   g.d = *desc;
@@ -745,14 +767,14 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream) {
   }
   g.rb_start[desc->nseg] = rb;
   g.nrb = rb;
-  g.ncb = (desc->ncols_out + 95) / 96;
+  g.ncb = (desc->ncols_out + 32 * TN - 1) / (32 * TN);
   g.dbg = carca_debug_buffer();
-  hipLaunchKernelGGL((gemm_rows_cu_kernel<DBG>), dim3(rb * g.ncb), dim3(768), 0, stream, g);
+  hipLaunchKernelGGL((gemm_rows_cu_kernel<DBG, TN>), dim3(rb * g.ncb), dim3(768), 0, stream, g);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
 
-enum GemmChoice { GEMM_NARROW_BUF, GEMM_NARROW, GEMM_CU, GEMM_CU_STAMPS, GEMM_TILED_BUF, GEMM_TILED };
+enum GemmChoice { GEMM_NARROW_BUF, GEMM_NARROW, GEMM_CU, GEMM_CU_STAMPS, GEMM_CU128, GEMM_TILED_BUF, GEMM_TILED };
 
 // argument checks + kernel selection of one product
 static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice) {
@@ -805,10 +827,15 @@ static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice) {
   // One 384 x 96 block per CU when the grid fills the chip's 256 CUs about as well as the 128 x 96 blocks (3 per CU)
   // would: compare rounds x tiles per block.
   if (fits && desc->K0 >= 64 && variant != 1) {
-    const int ncb = (desc->ncols_out + 95) / 96;
+    const int ncb = (desc->ncols_out + 95) / 96, ncb128 = (desc->ncols_out + 127) / 128;
     const long units_cu = (long)((rb384 * ncb + 255) / 256) * 36, units_3 = (long)((rb128 * ncb + 255) / 256) * 12;
-    if (variant == 3 || variant == 2 || units_cu <= units_3) {
+    const long units_cu128 = (long)((rb384 * ncb128 + 255) / 256) * 48;  // 384 x 128 tiles: 48 32x32 tiles per block
+    if (variant == 3 || variant == 2 || (units_cu <= units_3 && units_cu <= units_cu128)) {
       *choice = variant == 3 ? GEMM_CU_STAMPS : GEMM_CU;
+      return CARCA_OK;
+    }
+    if (variant == 7 || (variant == 0 && units_cu128 < units_cu && units_cu128 <= units_3)) {  // (7: force 384 x 128)
+      *choice = GEMM_CU128;
       return CARCA_OK;
     }
   }
@@ -825,6 +852,7 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
     case GEMM_NARROW: return launch_gemm_rows<128, 32, 32, 4>(desc, stream);
     case GEMM_CU: return launch_gemm_rows_cu<0>(desc, stream);
     case GEMM_CU_STAMPS: return launch_gemm_rows_cu<1>(desc, stream);
+    case GEMM_CU128: return launch_gemm_rows_cu<0, 4>(desc, stream);
     case GEMM_TILED_BUF: return launch_gemm_rows<128, 96, 32, 1, true>(desc, stream);
     default: return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
   }

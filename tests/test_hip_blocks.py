@@ -39,7 +39,7 @@ def test_gemm_rows_plain(rows, N, K0, K1):
     assert float(got[:, N:].abs().max()) == 0.0  # pad columns are written as zeros
 
 
-@pytest.fixture(params=[0, 1, 2, 4], ids=["auto", "tile128x96", "one-block-per-cu", "no-buffer-loads"])
+@pytest.fixture(params=[0, 1, 2, 4, 7], ids=["auto", "tile128x96", "one-block-per-cu", "no-buffer-loads", "cu-384x128"])
 def gemm_variant(request):
     """Every carca_gemm_rows test runs under each kernel choice (tuning key 0); the forced ones take effect where the
     launcher's preconditions hold and otherwise fall through to the default, so all shapes stay valid."""
