@@ -174,11 +174,11 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     if (rc != CARCA_OK) return rc; \
   } while (0)
   if (!D->fold_wc) {
-    CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
-                              D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_GATHER, stream_));
+    // gather + feature GEMM in one call: the gather rides in the GEMM's launch when that leaves a CU idle (C2: 255 blocks)
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], stream);
     CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
-                              D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_FEAT, stream_));
+                              D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_GATHER | CARCA_EMBED_FEAT,
+                              stream_));
     if (ev) (void)hipEventRecord((hipEvent_t)ev[1], stream);
     CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
                               D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_JOINT, stream_));

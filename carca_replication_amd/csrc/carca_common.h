@@ -101,11 +101,54 @@ __device__ __forceinline__ int unpad_feature(int fp, int dh, int dhp) {
 #define CARCA_ERR_BADARG (-2)
 
 void carca_set_error(const char* fmt, ...);
+// zq[r, 0:d] = items_w[ids[r]] * sqrt(d) for the rows of all segments (carca.py:87-88).  Runs either as its own launch
+// (embed.hip) or as a PASSENGER block of the feature-GEMM launch (gemm.hip): that launch has 255 blocks for 256 CUs at
+// C2, and one extra workgroup on the idle CU copies the 7 MB while the others multiply.
+struct CarcaGatherArgs {
+  const int32_t* ids[4 /*CARCA_MAX_SEGS*/];
+  int row_start[5];
+  int nseg;
+  const float* items_w;
+  float* zq;
+  int d, ldz, total_rows;
+  float scale;
+};
+// RIF rows in flight per wave: a lone workgroup (the passenger) needs them -- one row at a time is a ~1.3 us dependent
+// chain per row (id, row, store), 2.1 ms for the 19 k rows of C2 on 12 waves; with 16 in flight ~0.2 ms.
+template <int RIF = 1>
+__device__ __forceinline__ void carca_gather_rows(const CarcaGatherArgs& ga, int wave, int nwaves, int lane) {
+  for (int row0 = wave * RIF; row0 < ga.total_rows; row0 += nwaves * RIF) {
+    const float* src[RIF];
+#pragma unroll
+    for (int i = 0; i < RIF; ++i) {
+      const int row = min(row0 + i, ga.total_rows - 1);
+      int s = 0;
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
+        if (j < ga.nseg && row >= ga.row_start[j]) s = j;
+      src[i] = ga.items_w + (size_t)ga.ids[s][row - ga.row_start[s]] * ga.d;
+    }
+    for (int c0 = 0; c0 < ga.d; c0 += 64) {
+      const int c = c0 + lane;
+      float v[RIF];
+#pragma unroll
+      for (int i = 0; i < RIF; ++i) v[i] = c < ga.d ? src[i][c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < RIF; ++i)
+        if (c < ga.d && row0 + i < ga.total_rows) ga.zq[(size_t)(row0 + i) * ga.ldz + c] = v[i] * ga.scale;
+    }
+  }
+}
+
 // tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice.
 // Keys 3..5 are used by number (see include/carca_hip.h).
 enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_COUNT = 8 };
 int carca_tuning(int key);
 int carca_num_cus();  // compute units of the current device (cached)
+struct CarcaGemmDesc;
+// carca_gemm_rows with the item-row gather riding along where the kernel choice leaves a CU idle; *rode tells whether
+// it did (otherwise the caller launches the gather itself)
+int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* ga, int* rode, void* stream);
 unsigned long long* carca_debug_buffer();  // device buffer for in-kernel phase stamps (diagnostic runs), or null
 #define CARCA_CHECK_ARG(cond, ...)            \
   do {                                        \

@@ -14,28 +14,12 @@
 
 namespace {
 
-struct GatherArgs {
-  const int32_t* ids[CARCA_MAX_SEGS];
-  int row_start[CARCA_MAX_SEGS + 1];
-  int nseg;
-};
-
-// zq[r, 0:d] = items_w[ids[r]] * sqrt(d)   (carca.py:87-88); one wave per row, lanes over columns
-__global__ void gather_items_kernel(const GatherArgs ga, const float* __restrict__ items_w, int d, float sqrt_d,
-                                    float* __restrict__ zq, int ldz, int total_rows) {
+// (one wave per row, lanes over columns)
+__global__ void gather_items_kernel(const CarcaGatherArgs ga) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (int row = wave; row < total_rows; row += nwaves) {
-    int s = 0;
-#pragma unroll
-    for (int i = 1; i < CARCA_MAX_SEGS; ++i)
-      if (i < ga.nseg && row >= ga.row_start[i]) s = i;
-    const int id = ga.ids[s][row - ga.row_start[s]];
-    const float* src = items_w + (size_t)id * d;
-    float* dst = zq + (size_t)row * ldz;
-    for (int c = lane; c < d; c += 64) dst[c] = src[c] * sqrt_d;
-  }
+  carca_gather_rows<1>(ga, wave, nwaves, lane);
 }
 
 }  // namespace
@@ -51,7 +35,7 @@ extern "C" int carca_embed_fwd(const CarcaRowSeg* segs, int nseg, int n_attrs, i
   CARCA_CHECK_ARG(ld_e >= d, "embed_fwd: ld_e=%d < d=%d", ld_e, d);
   const int ldz = d + g;
 
-  GatherArgs ga{};
+  CarcaGatherArgs ga{};
   CarcaGemmDesc fa{}, ja{};
   int row_start = 0;
   for (int s = 0; s < nseg; ++s) {
@@ -76,18 +60,28 @@ extern "C" int carca_embed_fwd(const CarcaRowSeg* segs, int nseg, int n_attrs, i
   ga.nseg = nseg;
   const int total_rows = row_start;
 
-  if (stages & CARCA_EMBED_GATHER) {
+  ga.items_w = items_w; ga.zq = zq; ga.d = d; ga.ldz = ldz; ga.total_rows = total_rows; ga.scale = (float)sqrt((double)d);
+  auto launch_gather = [&]() -> int {
     const int blocks = min((total_rows + 3) / 4, 2048);
-    hipLaunchKernelGGL(gather_items_kernel, dim3(blocks), dim3(256), 0, stream, ga, items_w, d,
-                       (float)sqrt((double)d), zq, ldz, total_rows);
+    hipLaunchKernelGGL(gather_items_kernel, dim3(blocks), dim3(256), 0, stream, ga);
     CARCA_LAUNCH_CHECK();
-  }
-  if (stages & CARCA_EMBED_FEAT) {  // q = [attrs ; ctx] W_f^T + b_f  (carca.py:86)
-    fa.nseg = nseg;
-    fa.lda0 = n_attrs; fa.lda1 = n_ctx; fa.K0 = n_attrs; fa.K1 = n_ctx;
-    fa.bt0 = feats_w; fa.ldb0 = n_attrs + n_ctx;
-    fa.bt1 = feats_w + n_attrs; fa.ldb1 = n_attrs + n_ctx;
-    fa.N = g; fa.ldc = ldz; fa.ncols_out = g; fa.bias = feats_b;
+    return CARCA_OK;
+  };
+  fa.nseg = nseg;
+  fa.lda0 = n_attrs; fa.lda1 = n_ctx; fa.K0 = n_attrs; fa.K1 = n_ctx;
+  fa.bt0 = feats_w; fa.ldb0 = n_attrs + n_ctx;
+  fa.bt1 = feats_w + n_attrs; fa.ldb1 = n_attrs + n_ctx;
+  fa.N = g; fa.ldc = ldz; fa.ncols_out = g; fa.bias = feats_b;
+  if ((stages & CARCA_EMBED_GATHER) && (stages & CARCA_EMBED_FEAT)) {
+    // both asked for in one call: the gather rides in the feature GEMM's launch when that leaves a CU idle
+    int rode = 0;
+    const int rc = carca_gemm_rows_passenger(&fa, &ga, &rode, stream_);  // q = [attrs ; ctx] W_f^T + b_f  (carca.py:86)
+    if (rc != CARCA_OK) return rc;
+    if (!rode)
+      if (int rc2 = launch_gather()) return rc2;
+  } else if (stages & CARCA_EMBED_GATHER) {
+    if (int rc = launch_gather()) return rc;
+  } else if (stages & CARCA_EMBED_FEAT) {
     const int rc = carca_gemm_rows(&fa, stream_);
     if (rc != CARCA_OK) return rc;
   }

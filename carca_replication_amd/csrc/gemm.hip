@@ -32,6 +32,8 @@ struct GemmDev {
   int rb_start[CARCA_MAX_SEGS + 1];
   int nrb, ncb;
   unsigned long long* dbg;  // phase-stamp buffer of a diagnostic run (DBG instantiation only)
+  int has_pas;              // one-block-per-CU kernel: block nrb * ncb (one past the tiles) runs the item-row gather
+  CarcaGatherArgs pas;
 };
 
 template <int BM, int BN, int BK, int PF = 1, bool BUF = false>
@@ -290,6 +292,10 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
 
   const CarcaGemmDesc& D = args.d;
   const int id = blockIdx.x, total = args.nrb * args.ncb;
+  if (args.has_pas && id == total) {  // the passenger: this workgroup only copies item rows (an otherwise idle CU)
+    carca_gather_rows<16>(args.pas, (int)threadIdx.x >> 6, NW, (int)threadIdx.x & 63);
+    return;
+  }
   const int xcd = id & 7, q8 = total >> 3, r8 = total & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
   const int rb = wg / args.ncb, cb = wg - rb * args.ncb;
@@ -756,7 +762,8 @@ static int launch_gemm_rows(const CarcaGemmDesc* desc, hipStream_t stream) {
 }
 
 template <int DBG, int TN = 3>
-static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream) {
+static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream, const CarcaGatherArgs* pas = nullptr,
+                               int* rode = nullptr) {
   GemmDev g{};
   g.d = *desc;
   int rb = 0;
@@ -769,7 +776,14 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream) {
   g.nrb = rb;
   g.ncb = (desc->ncols_out + 32 * TN - 1) / (32 * TN);
   g.dbg = carca_debug_buffer();
-  hipLaunchKernelGGL((gemm_rows_cu_kernel<DBG, TN>), dim3(rb * g.ncb), dim3(768), 0, stream, g);
+  int grid = rb * g.ncb;
+  if (pas && grid < carca_num_cus()) {  // a CU is left over in the (single) round: it takes the gather
+    g.has_pas = 1;
+    g.pas = *pas;
+    ++grid;
+    if (rode) *rode = 1;
+  }
+  hipLaunchKernelGGL((gemm_rows_cu_kernel<DBG, TN>), dim3(grid), dim3(768), 0, stream, g);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -856,6 +870,17 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
     case GEMM_TILED_BUF: return launch_gemm_rows<128, 96, 32, 1, true>(desc, stream);
     default: return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
   }
+}
+
+int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* ga, int* rode, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  *rode = 0;
+  GemmChoice c;
+  if (int rc = gemm_rows_choose(desc, &c)) return rc;
+  if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 8) ga = nullptr;  // (8: never let the gather ride -- A/B switch)
+  if (c == GEMM_CU) return launch_gemm_rows_cu<0, 3>(desc, stream, ga, rode);
+  if (c == GEMM_CU128) return launch_gemm_rows_cu<0, 4>(desc, stream, ga, rode);
+  return carca_gemm_rows(desc, stream_);
 }
 
 // n independent products; those that select the narrow buffer-load kernel share launches (GEMM_GROUP_MAX per launch),

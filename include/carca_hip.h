@@ -43,7 +43,8 @@ int carca_abi_version(void);
 /* Kernel-variant knobs for tuning runs and A/B tests (tools/, tests/); 0 = the shipped choice everywhere.
  *   key 0  row / weight-gradient GEMM: 1 force 128x96 tiles, 2 force the one-block-per-CU kernels, 3 = 2 + in-kernel
  *          stamps, 4 no buffer loads, 5 tiled weight gradient only, 6 never group weight gradients / row GEMMs,
- *          7 force the one-block-per-CU row GEMM with 384 x 128 tiles
+ *          7 force the one-block-per-CU row GEMM with 384 x 128 tiles, 8 never let the item-row gather ride in the
+ *          feature GEMM's launch
  *   key 1  attention kernels: 1 one workgroup per user, 2 always two
  *   key 2  weight gradient: row-split slot target      key 4  minimum 32-row chunks per split
  *   key 3  weight gradient: plain stores instead of atomics (timing diagnostic, wrong results)

@@ -18,7 +18,10 @@ CONFIGS = {
     "CLI B=256 d=64 g=256 H=2 3 blocks n_attrs=512": dict(B=256, L=50, N=101, d=64, g=256, H=2, nb=3, n_attrs=512, n_ctx=6, n_items=12102),
     "small n_attrs=64                             ": dict(B=128, L=50, N=101, d=90, g=450, H=3, nb=2, n_attrs=64, n_ctx=6, n_items=12102),
 }
+only = os.environ.get("ONLY")  # e.g. ONLY=C5 (prefix of the configuration's name) for a rocprofv3 run of one of them
 for name, c in CONFIGS.items():
+    if only and not name.startswith(only):
+        continue
     torch.manual_seed(0)
     model = build_model(dict(d=c["d"], H=c["H"], n_blocks=c["nb"]), c["n_items"], c["g"], c["n_ctx"], c["n_attrs"], c["L"]).cuda().eval()
     profile, target, _ = synth_eval_batch(c["B"], c["L"], c["N"], c["n_items"], c["n_attrs"], c["n_ctx"], seed=1)
