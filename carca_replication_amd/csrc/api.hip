@@ -175,11 +175,11 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
   } while (0)
   if (!D->fold_wc) {
     // gather + feature GEMM in one call: the gather rides in the GEMM's launch when that leaves a CU idle (C2: 255 blocks)
-    if (ev) (void)hipEventRecord((hipEvent_t)ev[0], stream);
+    if (ev && ev[0]) (void)hipEventRecord((hipEvent_t)ev[0], stream);
     CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
                               D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_GATHER | CARCA_EMBED_FEAT,
                               stream_));
-    if (ev) (void)hipEventRecord((hipEvent_t)ev[1], stream);
+    if (ev && ev[1]) (void)hipEventRecord((hipEvent_t)ev[1], stream);
     CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
                               D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_JOINT, stream_));
   } else {
@@ -203,9 +203,9 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     f.lda0 = D->n_attrs; f.lda1 = D->n_ctx; f.K0 = D->n_attrs; f.K1 = D->n_ctx;
     f.bt0 = D->fold_wc; f.ldb0 = D->fold_ldwc; f.bt1 = D->fold_wc + D->n_attrs; f.ldb1 = D->fold_ldwc;
     f.N = D->d; f.ldc = D->ld_e; f.ncols_out = D->ld_e; f.ld_add = D->ld_e; f.pos = D->pos; f.mask_rows = 1;
-    if (ev) (void)hipEventRecord((hipEvent_t)ev[0], stream);
+    if (ev && ev[0]) (void)hipEventRecord((hipEvent_t)ev[0], stream);
     CARCA_TRY(carca_gemm_rows(&f, stream_));
-    if (ev) (void)hipEventRecord((hipEvent_t)ev[1], stream);
+    if (ev && ev[1]) (void)hipEventRecord((hipEvent_t)ev[1], stream);
   }
   const float* x = D->segs[0].e_out;
   for (int i = 0; i < D->n_blocks; ++i) {
@@ -221,10 +221,10 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     groups[gi].y = D->y[gi];
     groups[gi].N = D->N[gi];
   }
-  if (ev) (void)hipEventRecord((hipEvent_t)ev[2], stream);
+  if (ev && ev[2]) (void)hipEventRecord((hipEvent_t)ev[2], stream);
   CARCA_TRY(carca_cross_score_fwd(x, D->ld_e, D->segs[0].ids, D->p_normed, groups, D->ngroups, D->ld_e, D->B, D->L,
                                   D->d, D->H, &D->ca, D->ca_residual, D->training, nullptr, nullptr, stream_));
-  if (ev) (void)hipEventRecord((hipEvent_t)ev[3], stream);
+  if (ev && ev[3]) (void)hipEventRecord((hipEvent_t)ev[3], stream);
 #undef CARCA_TRY
   return CARCA_OK;
 }

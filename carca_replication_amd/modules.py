@@ -802,6 +802,8 @@ class CARCA(_PackedModule, Model):
         # the dot decoders return [B, T] unsqueezed (carca.py:361-367)
         if isinstance(self.decoder, CrossAttentionBlock):
             ys = [y.squeeze() for y in ys]
+        if len(ys) == 1 and not needs_grad:
+            return ys[0]  # (torch.cat of one tensor is a copy: the scores were allocated by this call, hand them out as is)
         return torch.cat(ys, dim=-1)
 
     def fold_embedding(self, on: bool = True) -> "CARCA":
