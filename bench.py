@@ -127,7 +127,7 @@ def measure_train(c, model, rank, world, device, steps):
     from carca_replication_amd.optim import Adam
 
     opt = Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))  # training.py:174's update, one launch for all tensors
-    for _ in range(2):
+    for _ in range(6):  # (allocator pools, lazily loaded code objects and the optimizer state settle in the first steps)
         engine.train_step(model, opt, batch, sharded=world > 1)
     torch.cuda.synchronize()
     if world > 1:
