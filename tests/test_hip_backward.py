@@ -50,8 +50,20 @@ def _step(model, fx, in_prefix=""):
     return y, loss
 
 
+@pytest.fixture(params=[0, 1], ids=["shared-users", "one-workgroup-per-user"])
+def attn_variant(request):
+    """The attention kernels (forward and backward) give a user to two workgroups while users <= CUs / 2 -- which every
+    fixture-sized batch satisfies -- and to one otherwise (tuning key 1 = 1 forces that path, what B > 128 takes)."""
+    from carca_replication_amd import _lib
+
+    lib = _lib.load()
+    lib.carca_set_tuning(1, request.param)
+    yield request.param
+    lib.carca_set_tuning(1, 0)
+
+
 @pytest.mark.parametrize("name", G1_NAMES)
-def test_g2_gradients_match_reference(name):
+def test_g2_gradients_match_reference(name, attn_variant):
     fx = load("g2_" + name)
     model = model_from_fixture(fx)
     y, loss = _step(model, fx)
