@@ -37,10 +37,18 @@ def train_step(model, optim, batch, sharded: bool = False) -> torch.Tensor:
     half = o_x.shape[1] // 2
     pos = tuple(t[:, :half] for t in (o_x, o_a, o_c))  # train.py:86-88
     neg = tuple(t[:, half:] for t in (o_x, o_a, o_c))
+    if o_x.shape[1] == 2 * half:  # the kernels want dense [B, L] ids per group: ONE copy for both halves instead of two
+        ids2 = o_x.view(o_x.shape[0], 2, half).transpose(0, 1).contiguous()
+        pos, neg = (ids2[0],) + pos[1:], (ids2[1],) + neg[1:]
     optim.zero_grad(set_to_none=True)
     y = model(profile=(p_x, p_a, p_c), targets=[pos, neg])
     denom = cdist.global_mask_count(o_x) if sharded else None
-    loss = _loss_fn(y, y_true, get_mask(o_x), denom=denom)
+    if o_x.dtype == torch.int32:  # BinaryCrossEntropy(y, y_true, get_mask(o_x)) without materialising the float mask
+        from .autograd import bce_with_grad
+
+        loss = bce_with_grad(y, y_true, None, 1e-8, denom, ids=o_x)
+    else:
+        loss = _loss_fn(y, y_true, get_mask(o_x), denom=denom)
     loss.backward()
     if sharded:
         cdist.allreduce_gradients(model.parameters(), sparse_rows=_sparse_tables(model, p_x, o_x))
