@@ -18,7 +18,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libcarca_hip.so")
 _STAMP = LIB_PATH + ".srchash"
-SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip", "optim.hip"]
+SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip", "block_bwd.hip", "optim.hip"]
 HEADERS = ["carca_common.h", "attn_common.h"]
 
 MAX_SEGS = 4
@@ -158,6 +158,14 @@ class AdamTensor(C.Structure):
     _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("n", C.c_int64)]
 
 
+class SaBwdDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("B", "L", "d", "H", "residual")] + [("drop_p", C.c_float), ("ids", _fp), ("dy", _fp)]
+                + [(n, _fp) for n in ("x_in", "qn", "qh", "kh", "vh", "r", "s2", "h1", "m_attn", "m_ffn2", "wq_t", "wk_t",
+                                      "wv_t", "w1_t", "w2_t", "ln1_w", "ln2_w", "g_w1", "g_b1", "g_w2", "g_b2", "g_wq",
+                                      "g_wk", "g_wv", "g_bq", "g_bk", "g_bv", "g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b",
+                                      "workspace", "dx")])
+
+
 class SaWeights(C.Structure):
     _fields_ = [(n, _fp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wk", "wv", "bq", "bk", "bv", "w1", "w2",
                                    "b1", "b2")]
@@ -225,6 +233,8 @@ SIGNATURES = {
     "carca_l2norm_fwd": (_i, [_fp, _i, _fp, _i, _i, _i, _fp]),
     "carca_l2norm_bwd": (_i, [_fp, _i, _fp, _i, _fp, _i, _i, _i, _fp]),
     "carca_knn_score": (_i, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _i, _fp, _i, _i, _i, _i, _fp]),
+    "carca_sa_block_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i]),
+    "carca_sa_block_bwd": (_i, [C.POINTER(SaBwdDesc), C.POINTER(WgradDesc), C.POINTER(_i), _fp]),
     "carca_adam_step": (_i, [C.POINTER(AdamTensor), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i,
                         _fp]),
     "carca_build_eval_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,

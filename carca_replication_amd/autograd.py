@@ -257,34 +257,17 @@ class _CarcaFn(torch.autograd.Function):
 
         # ---------------- encoder blocks, last to first (carca.py:297-318) --------------------------------
         for blk, sv, bp in zip(reversed(list(model.encoder)), reversed(st["blocks"]), reversed(bpks)):
-            dpo = bp.dpo
-            w1_t, w2_t = bp.wT(3), bp.wT(4)
+            # one host call per block (carca_sa_block_bwd): seven launches + five products appended to wg
             x_in = sv["x_in"].view(-1, dpi)
-            dy = dx
-            bp_ = sv["p"]
-            bscale = 1.0 / (1.0 - bp_) if bp_ > 0 else 1.0
-            # f = dropout2(ffn_2(dropout1(lrelu(ffn_1(s))))) (+ s): the f branch sees dy * mask2 / (1-p)
-            dyf = ops.mask_mul(dy, sv["m_ffn2"], bscale, d, dpi) if bp_ > 0 else dy
-            (dh1pre,) = ops.gemm_rows([dict(a0=dyf, gate=sv["h1"])], w2_t, d, d, dpi, gate_slope=0.01,
-                                      gate_scale=bscale, gate_zero_drops=bp_ > 0)
-            wg.add([dict(dy=dyf, x=sv["h1"])], d, d, gbp[id(blk.ffn_2.weight)].view(d, d), gbp[id(blk.ffn_2.bias)])
-            (ds,) = ops.gemm_rows([dict(a0=dh1pre, add=dy if blk.residual else None)], w1_t, d, d, dpi)
-            wg.add([dict(dy=dh1pre, x=sv["s2"])], d, d, gbp[id(blk.ffn_1.weight)].view(d, d), gbp[id(blk.ffn_1.bias)])
-            # s = LayerNorm2(r), r = attention (+ q)
-            dr = ops.layernorm_bwd(ds, sv["r"], blk.norm2.weight.detach(), d, dpi, dgamma=gbp[id(blk.norm2.weight)],
-                                   dbeta=gbp[id(blk.norm2.bias)])
-            dqh, dkh_b, dvh_b = ops.sa_attn_bwd(sv["qh"], sv["kh"], sv["vh"], dr, p_x, B, L, d, blk.attn.H,
-                                                m_attn=sv.get("m_attn") if bp_ > 0 else None, drop_scale=bscale)
-            bq_t, bk_t, bv_t = bp.wT(0), bp.wT(1), bp.wT(2)
-            (dqn,), (dx_kv,) = ops.gemm_rows_group([  # independent: one launch
-                dict(segs=[dict(a0=dqh, add=dr if blk.residual else None)], bt0=bq_t, N=d, K0=dpo, out_ld=dpi),
-                dict(segs=[dict(a0=dkh_b, a1=dvh_b)], bt0=bk_t, N=d, K0=dpo, out_ld=dpi, bt1=bv_t, K1=dpo)])
-            wg.add([dict(dy=dqh, x=sv["qn"])], dpo, d, bp.g(0), bp.g(3).view(-1))
-            wg.add([dict(dy=dkh_b, x=x_in)], dpo, d, bp.g(1), bp.g(4).view(-1))
-            wg.add([dict(dy=dvh_b, x=x_in)], dpo, d, bp.g(2), bp.g(5).view(-1))
-            # q = LayerNorm1(x); K, V from x itself
-            dx = ops.layernorm_bwd(dqn, x_in, blk.norm1.weight.detach(), d, dpi, addend=dx_kv,
-                                   dgamma=gbp[id(blk.norm1.weight)], dbeta=gbp[id(blk.norm1.bias)])
+            g = lambda p: gbp[id(p)]  # noqa: E731
+            dx = ops.sa_block_bwd(
+                dx, p_x, sv, x_in, (bp.wT(0), bp.wT(1), bp.wT(2), bp.wT(3), bp.wT(4)),
+                (blk.norm1.weight.detach(), blk.norm2.weight.detach()),
+                dict(g_w1=g(blk.ffn_1.weight), g_b1=g(blk.ffn_1.bias), g_w2=g(blk.ffn_2.weight), g_b2=g(blk.ffn_2.bias),
+                     g_wq=bp.g(0), g_wk=bp.g(1), g_wv=bp.g(2), g_bq=bp.g(3), g_bk=bp.g(4), g_bv=bp.g(5),
+                     g_ln1_w=g(blk.norm1.weight), g_ln1_b=g(blk.norm1.bias), g_ln2_w=g(blk.norm2.weight),
+                     g_ln2_b=g(blk.norm2.bias)),
+                B, L, d, blk.attn.H, blk.residual, sv["p"], wg)
 
         # ---------------- embedding (carca.py:85-95 and its ablations) -------------------------------------
         if st["p_emb"] > 0:  # CARCA.dropout on the profile embedding (carca.py:416)

@@ -1,0 +1,146 @@
+// Host-side orchestration of the backward pass, one C call per reference module (the kernels themselves live in
+// backward.hip / gemm.hip / wgrad_cu.hip).  The training step is host-bound in Python (~25 us of interpreter time per
+// launch against ~15 us kernels on the dependency chain), so the launch sequences of a module's backward are issued
+// from here, the way carca_forward issues the inference forward:
+//   carca_sa_block_bwd      autograd of SelfAttentionBlock.forward   carca.py:297-318 (+ 228-265)
+// Every entry launches its input-gradient chain on the caller's stream and APPENDS its weight-gradient products to a
+// caller-owned host array; the caller launches them together (carca_gemm_wgrad_group) once the pass is issued --
+// nothing downstream depends on them.
+#include <string.h>
+
+#include "carca_common.h"
+#include "../../include/carca_hip.h"
+
+namespace {
+
+CarcaWgradDesc wgrad_product(const float* dy, int ld_dy, const float* x, int ld_x, int rows, int N, int K, float* dw,
+                             int ldw, float* db) {
+  CarcaWgradDesc w;
+  memset(&w, 0, sizeof w);
+  w.nseg = 1;
+  w.seg[0].dy = dy;
+  w.seg[0].x = x;
+  w.seg[0].rows = rows;
+  w.seg[0].T = 1;
+  w.ld_dy = ld_dy;
+  w.ld_x = ld_x;
+  w.N = N;
+  w.K = K;
+  w.dw = dw;
+  w.ldw = ldw;
+  w.db = db;
+  return w;
+}
+
+CarcaGemmDesc gemm_product(const float* a0, int lda0, const float* bt0, int ldb0, int K0, int N, float* c, int ldc,
+                           int rows) {
+  CarcaGemmDesc g;
+  memset(&g, 0, sizeof g);
+  g.nseg = 1;
+  g.seg[0].a0 = a0;
+  g.seg[0].c = c;
+  g.seg[0].rows = rows;
+  g.seg[0].T = 1;
+  g.lda0 = lda0;
+  g.K0 = K0;
+  g.bt0 = bt0;
+  g.ldb0 = ldb0;
+  g.N = N;
+  g.ldc = ldc;
+  g.ncols_out = ldc;
+  g.gate_slope = 0.01f;
+  return g;
+}
+
+}  // namespace
+
+extern "C" size_t carca_sa_block_bwd_workspace(int B, int L, int d, int H) {
+  int dpi, dhp, dpo;
+  if (carca_padded_dims(d, H, &dpi, &dhp, &dpo) != CARCA_OK) return 0;
+  return (size_t)B * L * (6 * (size_t)dpi + 3 * (size_t)dpo);
+}
+
+extern "C" int carca_sa_block_bwd(const CarcaSaBwdDesc* D, CarcaWgradDesc* wgrads, int* n_wgrads, void* stream) {
+  CARCA_CHECK_ARG(D && wgrads && n_wgrads && *n_wgrads >= 0, "sa_block_bwd: null descriptor / product array");
+  CARCA_CHECK_ARG(D->B >= 1 && D->L >= 1 && D->d >= 1 && D->H >= 1 && D->d % D->H == 0 && D->drop_p >= 0.f &&
+                      D->drop_p < 1.f,
+                  "sa_block_bwd: bad dims");
+  CARCA_CHECK_ARG(D->ids && D->dy && D->x_in && D->qn && D->qh && D->kh && D->vh && D->r && D->s2 && D->h1 &&
+                      D->wq_t && D->wk_t && D->wv_t && D->w1_t && D->w2_t && D->ln1_w && D->ln2_w && D->g_w1 && D->g_b1 &&
+                      D->g_w2 && D->g_b2 && D->g_wq && D->g_wk && D->g_wv && D->g_bq && D->g_bk && D->g_bv &&
+                      D->g_ln1_w && D->g_ln1_b && D->g_ln2_w && D->g_ln2_b && D->workspace && D->dx,
+                  "sa_block_bwd: null pointer");
+  const bool drop = D->drop_p > 0.f;
+  CARCA_CHECK_ARG(!drop || (D->m_attn && D->m_ffn2), "sa_block_bwd: dropout was on but the keep-masks are missing");
+  int dpi, dhp, dpo;
+  if (int rc = carca_padded_dims(D->d, D->H, &dpi, &dhp, &dpo)) return rc;
+  const int rows = D->B * D->L, d = D->d;
+  const float bscale = drop ? 1.0f / (1.0f - D->drop_p) : 1.0f;
+  float* ws = D->workspace;
+  float* dyf = ws;                          ws += (size_t)rows * dpi;  // dy through dropout2 (only when dropout was on)
+  float* dh1pre = ws;                       ws += (size_t)rows * dpi;
+  float* ds = ws;                           ws += (size_t)rows * dpi;
+  float* dr = ws;                           ws += (size_t)rows * dpi;
+  float* dqn = ws;                          ws += (size_t)rows * dpi;
+  float* dx_kv = ws;                        ws += (size_t)rows * dpi;
+  float* dqh = ws;                          ws += (size_t)rows * dpo;
+  float* dkh = ws;                          ws += (size_t)rows * dpo;
+  float* dvh = ws;
+  int rc;
+  // f = dropout2(ffn_2(dropout1(lrelu(ffn_1(s))))) (+ s): the f branch sees dy * mask2 / (1 - p)   (carca.py:305-316)
+  const float* dyf_c = D->dy;
+  if (drop) {
+    if ((rc = carca_mask_mul(D->dy, dpi, D->m_ffn2, dpi, bscale, dyf, dpi, rows, d, dpi, stream))) return rc;
+    dyf_c = dyf;
+  }
+  {  // d h1pre = (dyf W_2) * LeakyReLU'(h1) (x dropout1')
+    CarcaGemmDesc g = gemm_product(dyf_c, dpi, D->w2_t, dpi, d, d, dh1pre, dpi, rows);
+    g.seg[0].gate = D->h1;
+    g.ld_gate = dpi;
+    g.gate_scale = bscale;
+    g.gate_zero_drops = drop ? 1 : 0;
+    if ((rc = carca_gemm_rows(&g, stream))) return rc;
+  }
+  {  // d s = d h1pre W_1 (+ dy: the post-LayerNorm2 residual)
+    CarcaGemmDesc g = gemm_product(dh1pre, dpi, D->w1_t, dpi, d, d, ds, dpi, rows);
+    if (D->residual) {
+      g.seg[0].add = D->dy;
+      g.ld_add = dpi;
+    }
+    if ((rc = carca_gemm_rows(&g, stream))) return rc;
+  }
+  // s = LayerNorm2(r), r = attention (+ q)
+  if ((rc = carca_layernorm_bwd(ds, dpi, D->r, dpi, D->ln2_w, rows, d, nullptr, 0, dr, dpi, dpi, D->g_ln2_w, D->g_ln2_b,
+                                stream)))
+    return rc;
+  if ((rc = carca_sa_attn_bwd(D->qh, D->kh, D->vh, dr, dpi, D->ids, dqh, dkh, dvh, D->B, D->L, d, D->H,
+                              drop ? D->m_attn : nullptr, bscale, stream)))
+    return rc;
+  {  // d qn = dQ W_Q (+ dr: the normed residual) beside d x|kv = dK W_K + dV W_V: independent, one launch
+    CarcaGemmDesc g[2];
+    g[0] = gemm_product(dqh, dpo, D->wq_t, dpo, dpo, d, dqn, dpi, rows);
+    if (D->residual) {
+      g[0].seg[0].add = dr;
+      g[0].ld_add = dpi;
+    }
+    g[1] = gemm_product(dkh, dpo, D->wk_t, dpo, dpo, d, dx_kv, dpi, rows);
+    g[1].seg[0].a1 = dvh;
+    g[1].lda1 = dpo;
+    g[1].K1 = dpo;
+    g[1].bt1 = D->wv_t;
+    g[1].ldb1 = dpo;
+    if ((rc = carca_gemm_rows_group(g, 2, stream))) return rc;
+  }
+  // q = LayerNorm1(x); K, V from x itself
+  if ((rc = carca_layernorm_bwd(dqn, dpi, D->x_in, dpi, D->ln1_w, rows, d, dx_kv, dpi, D->dx, dpi, dpi, D->g_ln1_w,
+                                D->g_ln1_b, stream)))
+    return rc;
+  CarcaWgradDesc* w = wgrads + *n_wgrads;
+  w[0] = wgrad_product(dyf_c, dpi, D->h1, dpi, rows, d, d, D->g_w2, d, D->g_b2);    // d ffn_2
+  w[1] = wgrad_product(dh1pre, dpi, D->s2, dpi, rows, d, d, D->g_w1, d, D->g_b1);   // d ffn_1
+  w[2] = wgrad_product(dqh, dpo, D->qn, dpi, rows, dpo, d, D->g_wq, d, D->g_bq);    // d W_Q (head-padded staging)
+  w[3] = wgrad_product(dkh, dpo, D->x_in, dpi, rows, dpo, d, D->g_wk, d, D->g_bk);  // d W_K
+  w[4] = wgrad_product(dvh, dpo, D->x_in, dpi, rows, dpo, d, D->g_wv, d, D->g_bv);  // d W_V
+  *n_wgrads += 5;
+  return CARCA_OK;
+}

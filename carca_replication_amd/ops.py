@@ -586,24 +586,63 @@ def gemm_wgrad(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, ma
 
 class WgradGroup:
     """Collects independent weight-gradient products (same arguments as gemm_wgrad) and issues them with ONE launch
-    (carca_gemm_wgrad_group): the d x d products of a backward pass are latency-bound launches of ~100 blocks each."""
+    (carca_gemm_wgrad_group): the d x d products of a backward pass are latency-bound launches of ~100 blocks each.
+    The C-side module backwards (sa_block_bwd) append their products to the same host array."""
+
+    CAPACITY = 64
 
     def __init__(self):
-        self.descs, self.keep = [], []
+        self.arr = (_lib.WgradDesc * self.CAPACITY)()
+        self.n = C.c_int(0)
+        self.keep = []  # every operand stays referenced until launch() has been issued
 
     def add(self, segs, N: int, K: int, dw: Tensor, db: Optional[Tensor] = None, mask_rows: bool = False,
             K1: int = 0) -> None:
+        if self.n.value >= self.CAPACITY:
+            raise CarcaHipError("WgradGroup: too many products")
         D, keep = _wgrad_desc(segs, N, K, dw, db, mask_rows, K1)
-        self.descs.append(D)
-        self.keep.append((keep, segs, dw, db))  # every operand stays referenced until launch() has been issued
+        self.arr[self.n.value] = D
+        self.n.value += 1
+        self.keep.append((keep, segs, dw, db))
 
     def launch(self) -> None:
-        if not self.descs:
-            return
-        lib = _lib.load()
-        arr = (_lib.WgradDesc * len(self.descs))(*self.descs)
-        _lib.check(lib.carca_gemm_wgrad_group(arr, len(self.descs), _stream()), "gemm_wgrad_group")
-        self.descs, self.keep = [], []
+        if self.n.value:
+            _lib.check(_lib.load().carca_gemm_wgrad_group(self.arr, self.n.value, _stream()), "gemm_wgrad_group")
+        self.n.value = 0
+        self.keep = []
+
+
+def sa_block_bwd(dy: Tensor, ids: Tensor, saved: dict, x_in: Tensor, wT, ln_w, grads: dict, B: int, L: int, d: int,
+                 H: int, residual: bool, drop_p: float, wg: WgradGroup) -> Tensor:
+    """Backward of one SelfAttentionBlock as ONE host call (carca_sa_block_bwd).  wT = (wq_t, wk_t, wv_t, w1_t, w2_t)
+    transposed packs, ln_w = (norm1.weight, norm2.weight), grads = the 14 gradient buffers by CarcaSaBwdDesc name.
+    Returns d(input) [B*L, DPI]; the block's five weight-gradient products are appended to `wg`."""
+    lib = _lib.load()
+    dpi, _, _ = padded_dims(d, H)
+    rows = B * L
+    ws = torch.empty(lib.carca_sa_block_bwd_workspace(B, L, d, H), dtype=torch.float32, device=dy.device)
+    dx = torch.empty(rows, dpi, dtype=torch.float32, device=dy.device)
+    ids32 = _ids32(ids.reshape(-1))
+    D = _lib.SaBwdDesc()
+    D.B, D.L, D.d, D.H, D.residual, D.drop_p = B, L, d, H, int(bool(residual)), float(drop_p)
+    D.ids, D.dy = ids32.data_ptr(), _row2d(dy, "dy").data_ptr()
+    if dy.stride(0) != dpi:
+        raise CarcaHipError("sa_block_bwd: dy must have row stride DPI")
+    D.x_in = x_in.data_ptr()
+    for k in ("qn", "qh", "kh", "vh", "r", "s2", "h1"):
+        setattr(D, k, saved[k].data_ptr())
+    if drop_p > 0:
+        D.m_attn, D.m_ffn2 = saved["m_attn"].data_ptr(), saved["m_ffn2"].data_ptr()
+    D.wq_t, D.wk_t, D.wv_t, D.w1_t, D.w2_t = (t.data_ptr() for t in wT)
+    D.ln1_w, D.ln2_w = ln_w[0].data_ptr(), ln_w[1].data_ptr()
+    for k, t in grads.items():
+        setattr(D, k, t.data_ptr())
+    D.workspace, D.dx = ws.data_ptr(), dx.data_ptr()
+    if wg.n.value + 5 > wg.CAPACITY:
+        raise CarcaHipError("WgradGroup: too many products")
+    _lib.check(lib.carca_sa_block_bwd(C.byref(D), wg.arr, C.byref(wg.n), _stream()), "sa_block_bwd")
+    wg.keep.append((ws, ids32, saved, x_in, wT, ln_w, grads, dy))
+    return dx
 
 
 def _wgrad_desc(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor], mask_rows: bool, K1: int):

@@ -343,6 +343,35 @@ int carca_knn_score(const float* p_a, int64_t p_bstride, const float* o_a, int64
  * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
 int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);
 
+/* ---- backward of whole modules as ONE host call each (csrc/block_bwd.hip) --------------------------------------
+ * The launch sequence of a module's backward is issued from C, like carca_forward issues the inference forward: the
+ * training step is otherwise bound by interpreter time per launch.  Each entry launches its input-gradient chain on
+ * `stream` and APPENDS its weight-gradient products to the caller's host array `wgrads` (*n_wgrads is advanced); the
+ * caller launches them together with carca_gemm_wgrad_group once the whole pass is issued -- until then the
+ * workspace and every saved tensor must stay alive.
+ * carca_sa_block_bwd: autograd of SelfAttentionBlock.forward (carca.py:297-318): given dL/d(output) it produces
+ * dL/d(input) and five products (ffn_2, ffn_1, W_Q, W_K, W_V with their biases); LayerNorm gammas / betas are
+ * accumulated directly.  All gradient buffers are ACCUMULATED into (caller zeroes). */
+typedef struct CarcaSaBwdDesc {
+  int32_t B, L, d, H, residual;
+  float drop_p;           /* the block's dropout probability in the forward (0 = none: masks unused) */
+  const int32_t* ids;     /* [B*L] */
+  const float* dy;        /* [B*L, DPI] gradient of the block's output */
+  const float *x_in, *qn, *qh, *kh, *vh, *r, *s2, *h1; /* the block's input + CarcaSaSave of the forward */
+  const uint8_t *m_attn, *m_ffn2;                      /* keep-masks of the forward (drop_p > 0) */
+  const float *wq_t, *wk_t, *wv_t; /* [DPI, DPO]: Bt[n = input feature][k = head-padded output feature] = W[k][n] */
+  const float *w1_t, *w2_t;        /* [DPI, DPI] transposed ffn weights */
+  const float *ln1_w, *ln2_w;      /* LayerNorm gammas [d] */
+  float *g_w1, *g_b1, *g_w2, *g_b2;             /* d ffn_1 / ffn_2: [d, d] (row stride d), [d] */
+  float *g_wq, *g_wk, *g_wv, *g_bq, *g_bk, *g_bv; /* head-padded staging: [DPO, d] (row stride d), [DPO] */
+  float *g_ln1_w, *g_ln1_b, *g_ln2_w, *g_ln2_b; /* [d] */
+  float* workspace;       /* carca_sa_block_bwd_workspace(B, L, d, H) floats, alive until the products have run */
+  float* dx;              /* out [B*L, DPI] gradient of the block's input */
+} CarcaSaBwdDesc;
+size_t carca_sa_block_bwd_workspace(int B, int L, int d, int H);
+int carca_sa_block_bwd(const CarcaSaBwdDesc* desc /*host*/, CarcaWgradDesc* wgrads /*host, room for 5 more*/,
+                       int* n_wgrads, void* stream);
+
 /* ---- f3: the optimizer step of the train driver (training.py:174, train.py:96) -------------------------------
  * torch.optim.Adam's update (no amsgrad; weight_decay added to the gradient) for every tensor of the table in one
  * launch: g += wd*p; m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
