@@ -166,6 +166,18 @@ class SaBwdDesc(C.Structure):
                                       "workspace", "dx")])
 
 
+class CrossBwdIn(C.Structure):
+    _fields_ = [(n, _fp) for n in ("qh", "y", "dy", "ids", "o", "m_attn", "de")] + [("N", C.c_int32)]
+
+
+class CrossBwdDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("B", "L", "d", "H", "ngroups", "residual", "training")] + [("drop_p", C.c_float),
+                ("group", CrossBwdIn * MAX_GROUPS)]
+                + [(n, _fp) for n in ("p_ids", "kh", "vh", "p_normed", "enc_out", "wq_t", "wk_t", "wv_t", "ffn_w_pad", "ffn_w",
+                                      "norm_w", "g_ffn_w", "g_ffn_b", "g_ffn_w_pad", "g_wq", "g_wk", "g_wv", "g_bq", "g_bk",
+                                      "g_bv", "g_norm_w", "g_norm_b", "workspace", "dx")])
+
+
 class SaWeights(C.Structure):
     _fields_ = [(n, _fp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wk", "wv", "bq", "bk", "bv", "w1", "w2",
                                    "b1", "b2")]
@@ -235,6 +247,8 @@ SIGNATURES = {
     "carca_knn_score": (_i, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _i, _fp, _i, _i, _i, _i, _fp]),
     "carca_sa_block_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i]),
     "carca_sa_block_bwd": (_i, [C.POINTER(SaBwdDesc), C.POINTER(WgradDesc), C.POINTER(_i), _fp]),
+    "carca_cross_score_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i, C.POINTER(C.c_int32), _i]),
+    "carca_cross_score_bwd": (_i, [C.POINTER(CrossBwdDesc), C.POINTER(WgradDesc), C.POINTER(_i), _fp]),
     "carca_adam_step": (_i, [C.POINTER(AdamTensor), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i,
                         _fp]),
     "carca_build_eval_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,

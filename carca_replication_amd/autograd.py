@@ -106,48 +106,26 @@ class _Packs:
         return self.plan.g.view(self.g_base + i)
 
 
-def _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, cp, d_wpad):
-    """Backward of the sigmoid/ffn head + cross-attention (carca.py:340-347): returns (d p_normed, [d o_g])."""
+def _cross_decoder_backward(model, st, ys, dys, gbp, wg, cp, d_wpad):
+    """Backward of the final LayerNorm + sigmoid/ffn head + cross-attention (carca.py:421, 340-347) as one host call:
+    returns (d encoder output, [d o_g])."""
     dec = model.decoder
     d, H = model.embeds.d, dec.attn.H
-    dpi, dhp, dpo = ops.padded_dims(d, H)
-    dh = d // H
-    B, L = st["B"], st["L"]
-    p_x = st["p_x"]
+    dpi = st["dpi"]
     ngroups = st["ngroups"]
-    bgroups = []
-    for gi in range(ngroups):
-        bgroups.append((st["csave"]["qh"][gi], ys[gi], dys[gi], st["segs"][gi + 1][0]))
-    ffn_w_pad_ptr = st["cw"].ffn_w_pad
-    cpd = st["csave"]["p"]
-    dqhs, dls, dkh, dvh = ops.cross_attn_bwd(st["csave"]["kh"], st["csave"]["vh"], p_x, bgroups, ffn_w_pad_ptr,
-                                             d_wpad, B, L, d, H, st["training"],
-                                             masks=st["csave"].get("m_attn") if cpd > 0 else None,
-                                             drop_scale=1.0 / (1.0 - cpd) if cpd > 0 else 1.0)
-    g_ffn_w, g_ffn_b = gbp[id(dec.ffn.weight)], gbp[id(dec.ffn.bias)]
-    o_rows = [st["es"][gi + 1].view(-1, dpi) for gi in range(ngroups)]
-    o_ids = [st["segs"][gi + 1][0] for gi in range(ngroups)]
-    if dec.residual:  # d ffn.bias = sum dlogit; residual part of d ffn.weight = dlogit^T . o: a 1 x d product of the group
-        wg.add([dict(dy=dls[gi].view(-1, 1), x=o_rows[gi]) for gi in range(ngroups)], 1, d, g_ffn_w.view(1, d), g_ffn_b)
-    else:
-        for gi in range(ngroups):
-            ops.colsum(dls[gi].view(-1, 1), 1, g_ffn_b)
-    # (the attention part of d ffn.weight, head-padded, lands in its staging slice d_wpad: unpacked with the rest)
-    # d o_g = dQ_g . W_Q (+ dlogit (x) w), masked like e * mask (carca.py:94)
-    wq_t, wk_t, wv_t = cp.wT(0), cp.wT(1), cp.wT(2)
-    ffn_w_plain = dec.ffn.weight.detach().reshape(-1)
-    # d o_g and d p_normed do not depend on each other: one launch (the two ~150-block products side by side)
-    des_t, (dp,) = ops.gemm_rows_group([
-        dict(segs=[dict(a0=dqhs[gi], rowscale=dls[gi] if dec.residual else None, ids=o_ids[gi])
-                   for gi in range(ngroups)], bt0=wq_t, N=d, K0=dpo, out_ld=dpi,
-             colvec=ffn_w_plain if dec.residual else None, mask_rows=True),
-        dict(segs=[dict(a0=dkh, a1=dvh)], bt0=wk_t, N=d, K0=dpo, out_ld=dpi, bt1=wv_t,
-             K1=dpo)])
-    wg.add([dict(dy=dqhs[gi], x=o_rows[gi]) for gi in range(ngroups)], dpo, d, cp.g(0), cp.g(3).view(-1))
-    pn = st["p_normed"].view(-1, st["p_normed"].shape[-1])
-    wg.add([dict(dy=dkh, x=pn)], dpo, d, cp.g(1), cp.g(4).view(-1))
-    wg.add([dict(dy=dvh, x=pn)], dpo, d, cp.g(2), cp.g(5).view(-1))
-    return dp, des_t
+    cs = st["csave"]
+    cpd = cs["p"]
+    masks = cs.get("m_attn") if cpd > 0 else None
+    groups = [(cs["qh"][gi], ys[gi], dys[gi], st["segs"][gi + 1][0], st["es"][gi + 1].view(-1, dpi),
+               masks[gi] if masks is not None else None) for gi in range(ngroups)]
+    g = lambda p: gbp[id(p)]  # noqa: E731
+    return ops.cross_score_bwd(
+        groups, st["p_x"], cs["kh"], cs["vh"], st["p_normed"], st["enc_out"], (cp.wT(0), cp.wT(1), cp.wT(2)),
+        st["cw"].ffn_w_pad, dec.ffn.weight.detach(), model.norm.weight.detach(),
+        dict(g_ffn_w=g(dec.ffn.weight), g_ffn_b=g(dec.ffn.bias), g_ffn_w_pad=d_wpad, g_wq=cp.g(0), g_wk=cp.g(1),
+             g_wv=cp.g(2), g_bq=cp.g(3), g_bk=cp.g(4), g_bv=cp.g(5), g_norm_w=g(model.norm.weight),
+             g_norm_b=g(model.norm.bias)),
+        st["B"], st["L"], d, H, dec.residual, st["training"], cpd, wg)
 
 
 class _CarcaFn(torch.autograd.Function):
@@ -247,13 +225,13 @@ class _CarcaFn(torch.autograd.Function):
         # the small weight-gradient products feed nothing downstream: collected, then issued as ONE grouped launch
         wg = ops.WgradGroup()
         if st["is_ca"]:
-            dp, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, dev, wg, cpk, plan.g.view(wpad_idx).view(-1))
+            dx, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, wg, cpk, plan.g.view(wpad_idx).view(-1))
         else:
             dp, des_t = dec.score_backward(dys, st["dsave"], B, L, d, dpi)
-        # final LayerNorm (carca.py:421)
-        enc_out = st["enc_out"].view(-1, dpi)
-        dx = ops.layernorm_bwd(dp, enc_out, model.norm.weight.detach(), d, dpi, dgamma=gbp[id(model.norm.weight)],
-                               dbeta=gbp[id(model.norm.bias)])
+            # final LayerNorm (carca.py:421)
+            enc_out = st["enc_out"].view(-1, dpi)
+            dx = ops.layernorm_bwd(dp, enc_out, model.norm.weight.detach(), d, dpi, dgamma=gbp[id(model.norm.weight)],
+                                   dbeta=gbp[id(model.norm.bias)])
 
         # ---------------- encoder blocks, last to first (carca.py:297-318) --------------------------------
         for blk, sv, bp in zip(reversed(list(model.encoder)), reversed(st["blocks"]), reversed(bpks)):

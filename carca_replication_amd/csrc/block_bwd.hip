@@ -3,6 +3,8 @@
 // launch against ~15 us kernels on the dependency chain), so the launch sequences of a module's backward are issued
 // from here, the way carca_forward issues the inference forward:
 //   carca_sa_block_bwd      autograd of SelfAttentionBlock.forward   carca.py:297-318 (+ 228-265)
+//   carca_cross_score_bwd   autograd of the final LayerNorm + CrossAttentionBlock.forward for every target group
+//                                                                     carca.py:421, 338-349
 // Every entry launches its input-gradient chain on the caller's stream and APPENDS its weight-gradient products to a
 // caller-owned host array; the caller launches them together (carca_gemm_wgrad_group) once the pass is issued --
 // nothing downstream depends on them.
@@ -142,5 +144,98 @@ extern "C" int carca_sa_block_bwd(const CarcaSaBwdDesc* D, CarcaWgradDesc* wgrad
   w[3] = wgrad_product(dkh, dpo, D->x_in, dpi, rows, dpo, d, D->g_wk, d, D->g_bk);  // d W_K
   w[4] = wgrad_product(dvh, dpo, D->x_in, dpi, rows, dpo, d, D->g_wv, d, D->g_bv);  // d W_V
   *n_wgrads += 5;
+  return CARCA_OK;
+}
+
+extern "C" size_t carca_cross_score_bwd_workspace(int B, int L, int d, int H, const int32_t* Ns, int ngroups) {
+  int dpi, dhp, dpo;
+  if (carca_padded_dims(d, H, &dpi, &dhp, &dpo) != CARCA_OK || !Ns) return 0;
+  size_t n = (size_t)B * L * (2 * (size_t)dpo + dpi);  // dK, dV, d p_normed
+  for (int g = 0; g < ngroups; ++g) n += (size_t)B * Ns[g] * (dpo + 1) + 3;  // dQ_g, dlogit_g (+ alignment slack)
+  return n;
+}
+
+extern "C" int carca_cross_score_bwd(const CarcaCrossBwdDesc* D, CarcaWgradDesc* wgrads, int* n_wgrads, void* stream) {
+  CARCA_CHECK_ARG(D && wgrads && n_wgrads && *n_wgrads >= 0, "cross_score_bwd: null descriptor / product array");
+  CARCA_CHECK_ARG(D->B >= 1 && D->L >= 1 && D->d >= 1 && D->H >= 1 && D->d % D->H == 0 && D->ngroups >= 1 &&
+                      D->ngroups <= CARCA_MAX_GROUPS && D->drop_p >= 0.f && D->drop_p < 1.f,
+                  "cross_score_bwd: bad dims");
+  CARCA_CHECK_ARG(D->p_ids && D->kh && D->vh && D->p_normed && D->enc_out && D->wq_t && D->wk_t && D->wv_t &&
+                      D->ffn_w_pad && D->ffn_w && D->norm_w && D->g_ffn_w && D->g_ffn_b && D->g_ffn_w_pad && D->g_wq &&
+                      D->g_wk && D->g_wv && D->g_bq && D->g_bk && D->g_bv && D->g_norm_w && D->g_norm_b &&
+                      D->workspace && D->dx,
+                  "cross_score_bwd: null pointer");
+  int dpi, dhp, dpo;
+  if (int rc = carca_padded_dims(D->d, D->H, &dpi, &dhp, &dpo)) return rc;
+  const int rows = D->B * D->L, d = D->d, ng = D->ngroups;
+  const bool drop = D->drop_p > 0.f;
+  float* ws = D->workspace;
+  float* dkh = ws;  ws += (size_t)rows * dpo;
+  float* dvh = ws;  ws += (size_t)rows * dpo;
+  float* dp = ws;   ws += (size_t)rows * dpi;
+  CarcaCrossBwdGroup grp[CARCA_MAX_GROUPS];
+  float* dls[CARCA_MAX_GROUPS];
+  for (int g = 0; g < ng; ++g) {
+    const CarcaCrossBwdIn& in = D->group[g];
+    CARCA_CHECK_ARG(in.qh && in.y && in.dy && in.ids && in.o && in.de && in.N >= 1 && (!drop || in.m_attn),
+                    "cross_score_bwd: group %d malformed", g);
+    const size_t gr = (size_t)D->B * in.N;
+    grp[g].qh = in.qh; grp[g].y = in.y; grp[g].dy = in.dy; grp[g].ids = in.ids;
+    grp[g].dqh = ws;                     ws += gr * dpo;
+    grp[g].dlogit = dls[g] = ws;         ws += (gr + 3) / 4 * 4;
+    grp[g].m_attn = drop ? in.m_attn : nullptr;
+    grp[g].N = in.N;
+  }
+  int rc;
+  // attention core + sigmoid(ffn(.)) head: dQ per group, dK, dV, dlogit, the attention part of d ffn.weight
+  if ((rc = carca_cross_attn_bwd(D->kh, D->vh, D->p_ids, grp, ng, D->ffn_w_pad, dkh, dvh, D->g_ffn_w_pad, D->B, D->L, d,
+                                 D->H, D->training, drop ? 1.0f / (1.0f - D->drop_p) : 1.0f, stream)))
+    return rc;
+  {  // d o_g = dQ_g W_Q (+ dlogit (x) w), masked like e * mask (carca.py:94), beside d p_normed = dK W_K + dV W_V
+    CarcaGemmDesc g[2];
+    memset(g, 0, sizeof g);
+    g[0].nseg = ng;
+    for (int i = 0; i < ng; ++i) {
+      CarcaGemmSeg& sg = g[0].seg[i];
+      sg.a0 = grp[i].dqh; sg.c = D->group[i].de; sg.ids = grp[i].ids; sg.rows = D->B * grp[i].N; sg.T = 1;
+      sg.rowscale = D->residual ? dls[i] : nullptr;
+    }
+    g[0].lda0 = dpo; g[0].K0 = dpo; g[0].bt0 = D->wq_t; g[0].ldb0 = dpo;
+    g[0].N = d; g[0].ldc = dpi; g[0].ncols_out = dpi; g[0].gate_slope = 0.01f; g[0].mask_rows = 1;
+    g[0].colvec = D->residual ? D->ffn_w : nullptr;
+    g[1] = gemm_product(dkh, dpo, D->wk_t, dpo, dpo, d, dp, dpi, rows);
+    g[1].seg[0].a1 = dvh; g[1].lda1 = dpo; g[1].K1 = dpo; g[1].bt1 = D->wv_t; g[1].ldb1 = dpo;
+    if ((rc = carca_gemm_rows_group(g, 2, stream))) return rc;
+  }
+  // final LayerNorm (carca.py:421)
+  if ((rc = carca_layernorm_bwd(dp, dpi, D->enc_out, dpi, D->norm_w, rows, d, nullptr, 0, D->dx, dpi, dpi, D->g_norm_w,
+                                D->g_norm_b, stream)))
+    return rc;
+  CarcaWgradDesc* w = wgrads + *n_wgrads;
+  int n = 0;
+  if (D->residual) {  // d ffn.bias = sum dlogit; residual part of d ffn.weight = dlogit^T o: a 1 x d product over the groups
+    CarcaWgradDesc& p = w[n++];
+    memset(&p, 0, sizeof p);
+    p.nseg = ng;
+    for (int i = 0; i < ng; ++i) {
+      p.seg[i].dy = dls[i]; p.seg[i].x = D->group[i].o; p.seg[i].rows = D->B * grp[i].N; p.seg[i].T = 1;
+    }
+    p.ld_dy = 1; p.ld_x = dpi; p.N = 1; p.K = d; p.dw = D->g_ffn_w; p.ldw = d; p.db = D->g_ffn_b;
+  } else {
+    for (int i = 0; i < ng; ++i)
+      if ((rc = carca_colsum(dls[i], 1, D->B * grp[i].N, 1, nullptr, nullptr, 1, D->g_ffn_b, stream))) return rc;
+  }
+  {  // d W_Q: one product over the groups' rows
+    CarcaWgradDesc& p = w[n++];
+    memset(&p, 0, sizeof p);
+    p.nseg = ng;
+    for (int i = 0; i < ng; ++i) {
+      p.seg[i].dy = grp[i].dqh; p.seg[i].x = D->group[i].o; p.seg[i].rows = D->B * grp[i].N; p.seg[i].T = 1;
+    }
+    p.ld_dy = dpo; p.ld_x = dpi; p.N = dpo; p.K = d; p.dw = D->g_wq; p.ldw = d; p.db = D->g_bq;
+  }
+  w[n++] = wgrad_product(dkh, dpo, D->p_normed, dpi, rows, dpo, d, D->g_wk, d, D->g_bk);
+  w[n++] = wgrad_product(dvh, dpo, D->p_normed, dpi, rows, dpo, d, D->g_wv, d, D->g_bv);
+  *n_wgrads += n;
   return CARCA_OK;
 }

@@ -645,6 +645,50 @@ def sa_block_bwd(dy: Tensor, ids: Tensor, saved: dict, x_in: Tensor, wT, ln_w, g
     return dx
 
 
+def cross_score_bwd(groups, p_ids: Tensor, kh: Tensor, vh: Tensor, p_normed: Tensor, enc_out: Tensor, wT, ffn_w_pad_ptr: int,
+                    ffn_w: Tensor, norm_w: Tensor, grads: dict, B: int, L: int, d: int, H: int, residual: bool,
+                    training: bool, drop_p: float, wg: WgradGroup):
+    """Backward of the final LayerNorm + CrossAttentionBlock over all target groups as ONE host call
+    (carca_cross_score_bwd).  groups: [(qh, y [B,N], dy [B,N], ids [B,N], o [B*N, DPI], m_attn or None)];
+    wT = (wq_t, wk_t, wv_t); grads by CarcaCrossBwdDesc name.  Returns (d encoder output [B*L, DPI], [d o_g])."""
+    lib = _lib.load()
+    dpi, _, _ = padded_dims(d, H)
+    ng = len(groups)
+    D = _lib.CrossBwdDesc()
+    D.B, D.L, D.d, D.H, D.ngroups = B, L, d, H, ng
+    D.residual, D.training, D.drop_p = int(bool(residual)), int(bool(training)), float(drop_p)
+    Ns = (C.c_int32 * ng)(*[int(g[1].shape[1]) for g in groups])
+    ws = torch.empty(lib.carca_cross_score_bwd_workspace(B, L, d, H, Ns, ng), dtype=torch.float32, device=kh.device)
+    keep, des = [ws], []
+    for i, (qh, y, dy, ids, o, m_attn) in enumerate(groups):
+        y, dy, ids32 = _f32(y), _f32(dy), _ids32(ids)
+        de = torch.empty(o.shape[0], dpi, dtype=torch.float32, device=o.device)
+        if o.stride(0) != dpi or o.stride(1) != 1:
+            raise CarcaHipError("cross_score_bwd: embedded targets must be [rows, DPI] dense")
+        G = D.group[i]
+        G.qh, G.y, G.dy, G.ids, G.o, G.de, G.N = (qh.data_ptr(), y.data_ptr(), dy.data_ptr(), ids32.data_ptr(), o.data_ptr(),
+                                                  de.data_ptr(), y.shape[1])
+        G.m_attn = m_attn.data_ptr() if (m_attn is not None and drop_p > 0) else None
+        keep += [qh, y, dy, ids32, o, m_attn]
+        des.append(de)
+    p_ids32 = _ids32(p_ids)
+    dx = torch.empty(B * L, dpi, dtype=torch.float32, device=kh.device)
+    D.p_ids, D.kh, D.vh, D.p_normed, D.enc_out = (p_ids32.data_ptr(), kh.data_ptr(), vh.data_ptr(), p_normed.data_ptr(),
+                                                   enc_out.data_ptr())
+    if p_normed.stride(-2) != dpi or enc_out.stride(-2) != dpi:
+        raise CarcaHipError("cross_score_bwd: p_normed / enc_out must have row stride DPI")
+    D.wq_t, D.wk_t, D.wv_t = (t.data_ptr() for t in wT)
+    D.ffn_w_pad, D.ffn_w, D.norm_w = ffn_w_pad_ptr, ffn_w.data_ptr(), norm_w.data_ptr()
+    for k, t in grads.items():
+        setattr(D, k, t.data_ptr())
+    D.workspace, D.dx = ws.data_ptr(), dx.data_ptr()
+    if wg.n.value + 4 > wg.CAPACITY:
+        raise CarcaHipError("WgradGroup: too many products")
+    _lib.check(lib.carca_cross_score_bwd(C.byref(D), wg.arr, C.byref(wg.n), _stream()), "cross_score_bwd")
+    wg.keep.append((keep, p_ids32, kh, vh, p_normed, enc_out, wT, ffn_w, norm_w, grads))
+    return dx, des
+
+
 def _wgrad_desc(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor], mask_rows: bool, K1: int):
     D = _lib.WgradDesc()
     D.nseg = len(segs)

@@ -372,6 +372,42 @@ size_t carca_sa_block_bwd_workspace(int B, int L, int d, int H);
 int carca_sa_block_bwd(const CarcaSaBwdDesc* desc /*host*/, CarcaWgradDesc* wgrads /*host, room for 5 more*/,
                        int* n_wgrads, void* stream);
 
+/* carca_cross_score_bwd: autograd of the final LayerNorm (carca.py:421) + CrossAttentionBlock.forward (carca.py:338-349)
+ * over every target group: given dL/dy per group it produces dL/d(embedded targets) per group (masked like e * mask),
+ * dL/d(encoder output) and up to four products (ffn head, W_Q over all groups, W_K, W_V). */
+typedef struct CarcaCrossBwdIn {
+  const float* qh;       /* [B*N, DPO] saved by carca_cross_score_fwd */
+  const float* y;        /* [B*N] forward scores */
+  const float* dy;       /* [B*N] incoming gradient */
+  const int32_t* ids;    /* [B*N] */
+  const float* o;        /* [B*N, DPI] embedded targets (the forward's input) */
+  const uint8_t* m_attn; /* keep-mask of the forward (drop_p > 0) or NULL */
+  float* de;             /* out [B*N, DPI]: gradient of the embedded targets */
+  int32_t N;
+} CarcaCrossBwdIn;
+typedef struct CarcaCrossBwdDesc {
+  int32_t B, L, d, H, ngroups, residual, training;
+  float drop_p;
+  CarcaCrossBwdIn group[CARCA_MAX_GROUPS];
+  const int32_t* p_ids;                /* [B*L] */
+  const float *kh, *vh;                /* [B*L, DPO] saved */
+  const float* p_normed;               /* [B*L, DPI] final-norm output saved by the forward */
+  const float* enc_out;                /* [B*L, DPI] encoder output (the final norm's input) */
+  const float *wq_t, *wk_t, *wv_t;     /* [DPI, DPO] transposed head-padded copies */
+  const float* ffn_w_pad;              /* [DPO] decoder.ffn.weight, head-padded (CarcaCaWeights.ffn_w_pad) */
+  const float* ffn_w;                  /* [d] decoder.ffn.weight as is */
+  const float* norm_w;                 /* [d] final LayerNorm gamma */
+  float *g_ffn_w, *g_ffn_b;            /* [d], [1] */
+  float* g_ffn_w_pad;                  /* [DPO] head-padded staging of the attention part of d ffn.weight */
+  float *g_wq, *g_wk, *g_wv, *g_bq, *g_bk, *g_bv; /* head-padded staging: [DPO, d], [DPO] */
+  float *g_norm_w, *g_norm_b;          /* [d] */
+  float* workspace;                    /* carca_cross_score_bwd_workspace(...) floats, alive until the products ran */
+  float* dx;                           /* out [B*L, DPI]: gradient of the encoder output */
+} CarcaCrossBwdDesc;
+size_t carca_cross_score_bwd_workspace(int B, int L, int d, int H, const int32_t* Ns /*host [ngroups]*/, int ngroups);
+int carca_cross_score_bwd(const CarcaCrossBwdDesc* desc /*host*/, CarcaWgradDesc* wgrads /*host, room for 4 more*/,
+                          int* n_wgrads, void* stream);
+
 /* ---- f3: the optimizer step of the train driver (training.py:174, train.py:96) -------------------------------
  * torch.optim.Adam's update (no amsgrad; weight_decay added to the gradient) for every tensor of the table in one
  * launch: g += wd*p; m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
