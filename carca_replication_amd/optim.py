@@ -37,6 +37,14 @@ class Adam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._steps = {}
+        self._fast = {}
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for st in sd["state"].values():  # (the group's entries share ONE step tensor here; torch's format has one each)
+            if "step" in st:
+                st["step"] = st["step"].clone()
+        return sd
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -45,13 +53,40 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        for group in self.param_groups:
-            live = [p for p in group["params"] if p.grad is not None]
+        fast = self.__dict__.setdefault("_fast", {})
+        for gi, group in enumerate(self.param_groups):
+            params = group["params"]
+            # steady state: every parameter has a gradient and state, all at the same step -> the cached table (p, m, v
+            # pointers and sizes are fixed) only needs this step's gradient pointers
+            c = fast.get(gi)
+            if c is not None and c["n"] == len(params) and all(p.grad is not None for p in params) and \
+                    all(pp == p.data_ptr() for pp, p in zip(c["pp"], params)):
+                arr = c["arr"]
+                keep = []
+                for i, p in enumerate(params):
+                    g = p.grad
+                    if not g.is_contiguous() or g.is_sparse:
+                        c = None
+                        break
+                    arr[i].g = g.data_ptr()
+                if c is not None:
+                    c["t"] += 1
+                    c["step"] += 1  # ONE CPU tensor shared by the group's state entries (37 separate ones cost 75 us)
+                    for p in params:
+                        self._steps[id(p)] = c["t"]
+                    torch.autograd.graph.increment_version(params)
+                    b1, b2 = group["betas"]
+                    _lib.check(lib.carca_adam_step(arr, len(params), float(group["lr"]), float(b1), float(b2),
+                                                   float(group["eps"]), float(group["weight_decay"]), c["t"], _stream()),
+                               "adam_step")
+                    continue
+            fast.pop(gi, None)
+            live = [p for p in params if p.grad is not None]
             if not live:
                 continue
             steps = set()
             arr = (_lib.AdamTensor * len(live))()
-            keep, counters = [], []
+            keep = []
             for i, p in enumerate(live):
                 g = p.grad
                 if g.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
@@ -69,19 +104,25 @@ class Adam(torch.optim.Optimizer):
                     t = int(st["step"])
                 self._steps[id(p)] = t + 1
                 steps.add(t + 1)
-                counters.append(st["step"])
                 a = arr[i]
                 a.p, a.g, a.m, a.v, a.n = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), \
                     p.numel()
-            torch._foreach_add_(counters, 1.0)
             # the kernel writes the parameters behind torch's back: bump their version counters, which is what the
             # modules' packed-weight caches (and autograd's saved-tensor checks) go by
             torch.autograd.graph.increment_version(live)
             b1, b2 = group["betas"]
             if len(steps) == 1:
+                t = steps.pop()
                 _lib.check(lib.carca_adam_step(arr, len(live), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                               float(group["weight_decay"]), steps.pop(), _stream()), "adam_step")
+                                               float(group["weight_decay"]), t, _stream()), "adam_step")
+                shared = torch.tensor(float(t), dtype=torch.float32)
+                for p in live:
+                    self.state[p]["step"] = shared
+                if len(live) == len(params) and not keep:
+                    fast[gi] = dict(arr=arr, n=len(params), t=t, pp=[p.data_ptr() for p in params], step=shared)
             else:  # parameters that joined later carry their own step count: one launch per count
+                for p in live:
+                    self.state[p]["step"] = torch.tensor(float(self._steps[id(p)]), dtype=torch.float32)
                 for t in sorted(steps):
                     idx = [i for i, p in enumerate(live) if self._steps[id(p)] == t]
                     sub = (_lib.AdamTensor * len(idx))(*[arr[i] for i in idx])
