@@ -178,6 +178,18 @@ class CrossBwdDesc(C.Structure):
                                       "g_bv", "g_norm_w", "g_norm_b", "workspace", "dx")])
 
 
+class EmbedBwdSeg(C.Structure):
+    _fields_ = [(n, _fp) for n in ("de", "ids", "attrs", "ctx", "attrs_table")] + [
+        ("attrs_bstride", C.c_int64), ("ctx_bstride", C.c_int64), ("rows", C.c_int32), ("T", C.c_int32),
+        ("attrs_table_rows", C.c_int32)]
+
+
+class EmbedBwdDesc(C.Structure):
+    _fields_ = ([("seg", EmbedBwdSeg * MAX_SEGS)] + [(n, C.c_int32) for n in ("nseg", "d", "g", "n_attrs", "n_ctx", "ld_de", "L")]
+                + [("zq", _fp), ("joint_wt", _fp), ("ld_joint_wt", C.c_int32)]
+                + [(n, _fp) for n in ("g_items", "g_feats_w", "g_feats_b", "g_joint_w", "g_joint_b", "g_pos", "workspace")])
+
+
 class SaWeights(C.Structure):
     _fields_ = [(n, _fp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wk", "wv", "bq", "bk", "bv", "w1", "w2",
                                    "b1", "b2")]
@@ -249,6 +261,8 @@ SIGNATURES = {
     "carca_sa_block_bwd": (_i, [C.POINTER(SaBwdDesc), C.POINTER(WgradDesc), C.POINTER(_i), _fp]),
     "carca_cross_score_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i, C.POINTER(C.c_int32), _i]),
     "carca_cross_score_bwd": (_i, [C.POINTER(CrossBwdDesc), C.POINTER(WgradDesc), C.POINTER(_i), _fp]),
+    "carca_embed_bwd_workspace": (C.c_size_t, [C.POINTER(C.c_int32), _i, _i, _i]),
+    "carca_embed_bwd": (_i, [C.POINTER(EmbedBwdDesc), _fp]),
     "carca_adam_step": (_i, [C.POINTER(AdamTensor), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i,
                         _fp]),
     "carca_build_eval_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,

@@ -5,6 +5,7 @@
 //   carca_sa_block_bwd      autograd of SelfAttentionBlock.forward   carca.py:297-318 (+ 228-265)
 //   carca_cross_score_bwd   autograd of the final LayerNorm + CrossAttentionBlock.forward for every target group
 //                                                                     carca.py:421, 338-349
+//   carca_embed_bwd         autograd of AllEmbedding.forward over all row segments           carca.py:85-95
 // Every entry launches its input-gradient chain on the caller's stream and APPENDS its weight-gradient products to a
 // caller-owned host array; the caller launches them together (carca_gemm_wgrad_group) once the pass is issued --
 // nothing downstream depends on them.
@@ -238,4 +239,70 @@ extern "C" int carca_cross_score_bwd(const CarcaCrossBwdDesc* D, CarcaWgradDesc*
   w[n++] = wgrad_product(dvh, dpo, D->p_normed, dpi, rows, dpo, d, D->g_wv, d, D->g_bv);
   *n_wgrads += n;
   return CARCA_OK;
+}
+
+extern "C" size_t carca_embed_bwd_workspace(const int32_t* rows, int nseg, int d, int g) {
+  size_t n = 0;
+  for (int s = 0; rows && s < nseg; ++s) n += (size_t)rows[s] * (d + g);  // d [z ; q] per segment
+  return n;
+}
+
+extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
+  CARCA_CHECK_ARG(D && D->nseg >= 1 && D->nseg <= CARCA_MAX_SEGS, "embed_bwd: bad segment count");
+  CARCA_CHECK_ARG(D->d >= 1 && D->g >= 1 && D->n_attrs >= 1 && D->n_ctx >= 0 && D->ld_de >= D->d && D->L >= 1,
+                  "embed_bwd: bad dims");
+  CARCA_CHECK_ARG(D->zq && D->joint_wt && D->g_items && D->g_feats_w && D->g_feats_b && D->g_joint_w && D->g_joint_b &&
+                      D->workspace,
+                  "embed_bwd: null pointer");
+  const int d = D->d, g = D->g, ldz = d + g;
+  int rc;
+  // d LearnableEncoding.encoding.weight[t] += sum over users of (d e * mask)[t]   (carca.py:25-31)
+  if (D->g_pos) {
+    const CarcaEmbedBwdSeg& p = D->seg[0];
+    if ((rc = carca_colsum(p.de, D->ld_de, p.rows, d, nullptr, p.ids, D->L, D->g_pos, stream))) return rc;
+  }
+  CarcaWgradDesc wj, wf;
+  CarcaGemmDesc gz;
+  memset(&wj, 0, sizeof wj);
+  memset(&wf, 0, sizeof wf);
+  memset(&gz, 0, sizeof gz);
+  size_t row0 = 0;
+  float* ws = D->workspace;
+  float* dzq[CARCA_MAX_SEGS];
+  for (int s = 0; s < D->nseg; ++s) {
+    const CarcaEmbedBwdSeg& sg = D->seg[s];
+    CARCA_CHECK_ARG(sg.rows >= 1 && sg.T >= 1 && sg.de && sg.ids && (sg.attrs || sg.attrs_table) &&
+                        (D->n_ctx == 0 || sg.ctx),
+                    "embed_bwd: segment %d malformed", s);
+    dzq[s] = ws;
+    ws += (size_t)sg.rows * ldz;
+    // d joint_embed = (d e * mask)^T [z ; q]
+    wj.seg[s].dy = sg.de; wj.seg[s].x = D->zq + row0 * ldz; wj.seg[s].ids = sg.ids; wj.seg[s].rows = sg.rows; wj.seg[s].T = 1;
+    // d [z ; q] = (d e * mask) W_j
+    gz.seg[s].a0 = sg.de; gz.seg[s].c = dzq[s]; gz.seg[s].ids = sg.ids; gz.seg[s].rows = sg.rows; gz.seg[s].T = 1;
+    // d feats_embed = dq^T [attrs | ctx]: the ctx columns ride along as a second X source
+    CarcaWgradSeg& f = wf.seg[s];
+    f.dy = dzq[s] + d; f.rows = sg.rows; f.T = sg.T; f.ids = sg.ids;
+    if (sg.attrs_table) {
+      f.x = sg.attrs_table; f.x_gather = sg.attrs_table_rows > 1 ? sg.attrs_table_rows : 1;
+    } else {
+      f.x = sg.attrs; f.x_bstride = sg.attrs_bstride;
+    }
+    f.x1 = D->n_ctx ? sg.ctx : nullptr; f.x1_bstride = sg.ctx_bstride;
+    row0 += sg.rows;
+  }
+  wj.nseg = gz.nseg = wf.nseg = D->nseg;
+  wj.ld_dy = D->ld_de; wj.ld_x = ldz; wj.N = d; wj.K = ldz; wj.dw = D->g_joint_w; wj.ldw = ldz; wj.db = D->g_joint_b;
+  wj.mask_rows = 1;
+  if ((rc = carca_gemm_wgrad(&wj, stream))) return rc;
+  gz.lda0 = D->ld_de; gz.K0 = d; gz.bt0 = D->joint_wt; gz.ldb0 = D->ld_joint_wt; gz.N = ldz; gz.ldc = ldz;
+  gz.ncols_out = ldz; gz.gate_slope = 0.01f; gz.mask_rows = 1;
+  if ((rc = carca_gemm_rows(&gz, stream))) return rc;
+  for (int s = 0; s < D->nseg; ++s)  // nn.Embedding(padding_idx = 0): z = E[ids] * sqrt(d)
+    if ((rc = carca_embed_scatter(dzq[s], ldz, D->seg[s].ids, D->seg[s].rows, d, (float)sqrt((double)d), D->g_items,
+                                  stream)))
+      return rc;
+  wf.ld_dy = ldz; wf.ld_x = D->n_attrs; wf.ld_x1 = D->n_ctx; wf.N = g; wf.K = D->n_attrs; wf.K1 = D->n_ctx;
+  wf.dw = D->g_feats_w; wf.ldw = D->n_attrs + D->n_ctx; wf.db = D->g_feats_b;
+  return carca_gemm_wgrad(&wf, stream);
 }

@@ -182,6 +182,7 @@ class AllEmbedding(Embedding):
         state = dict(super().__getstate__())
         state.pop("_attr_table", None)
         state.pop("_fold_cache", None)
+        state.pop("_wj_t", None)
         return state
 
     def register_attr_table(self, attrs: Optional[Tensor]) -> None:
@@ -232,39 +233,25 @@ class AllEmbedding(Embedding):
 
     def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int) -> None:
         """Backward of embed_segments (carca.py:85-95): des[i] = d e of segment i, [rows, dpi], NOT yet masked;
-        accumulates into the gradient buffers gbp[id(param)]."""
+        accumulates into the gradient buffers gbp[id(param)].  One host call (carca_embed_bwd): position-encoding
+        gradient, d joint_embed, d [z ; q], item-row scatter-add, d feats_embed."""
         d = self.d
-        dev = des[0].device
         g_feats = self.feats_embed.weight.shape[0]
         table = self.attr_table()
         n_attrs = table.shape[1] if table is not None else segs[0][1].shape[-1]
-        ids_seg = [s[0] for s in segs]
-        nseg = len(des)
-        row0 = [0]
-        for sg in segs:
-            row0.append(row0[-1] + sg[0].numel())
-        zq_seg = [zq[row0[i]: row0[i + 1]] for i in range(nseg)]
-        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
-        g_joint_w, g_joint_b = gbp[id(self.joint_embed.weight)], gbp[id(self.joint_embed.bias)]
-        ops.gemm_wgrad([dict(dy=des[i], x=zq_seg[i], ids=ids_seg[i]) for i in range(nseg)], d, d + g_feats, g_joint_w,
-                       g_joint_b, mask_rows=True)
-        wj_t = ops.PackedWeights([ops.PackItem(self.joint_embed.weight, d + g_feats, dpi, transposed=True)], dev)
-        wj_t.pack()
-        dzq = ops.gemm_rows([dict(a0=des[i], ids=ids_seg[i]) for i in range(nseg)], wj_t.view(0), d + g_feats, d,
-                            d + g_feats, mask_rows=True)
-        g_items = gbp[id(self.items_embed.weight)]
-        for i in range(nseg):
-            ops.embed_scatter(dzq[i], ids_seg[i], d, float(d) ** 0.5, g_items)
-        g_feats_w, g_feats_b = gbp[id(self.feats_embed.weight)], gbp[id(self.feats_embed.bias)]
         n_ctx = segs[0][2].shape[-1]
-
-        # d feats_embed.weight = dq^T [attrs | ctx]: one launch, the ctx columns ride along as a second X source
-        def xsrc(i):  # dense attrs batch tensor, or the registered table gathered by id
-            a = segs[i][1]
-            return dict(x=a) if a is not None else dict(x=table, x_gather=True, ids=ids_seg[i])
-
-        ops.gemm_wgrad([dict(dy=dzq[i][:, d:], x1=segs[i][2] if n_ctx else None, **xsrc(i)) for i in range(nseg)],
-                       g_feats, n_attrs, g_feats_w, g_feats_b, K1=n_ctx)
+        wj_t = self.__dict__.get("_wj_t")  # Bt[n = input feature of joint_embed][k = output feature]: repacked every step
+        if wj_t is None or wj_t.buf.device != des[0].device or wj_t.items[0].dst_cols != dpi:
+            wj_t = ops.PackedWeights([ops.PackItem(self.joint_embed.weight, d + g_feats, dpi, transposed=True)], des[0].device)
+            self.__dict__["_wj_t"] = wj_t
+        wj_t.items[0].src = self.joint_embed.weight
+        wj_t.pack()
+        enc_w = self.enc.encoding.weight if hasattr(self.enc, "encoding") else None
+        ops.embed_bwd(des, segs, zq, wj_t.view(0),
+                      dict(g_items=gbp[id(self.items_embed.weight)], g_feats_w=gbp[id(self.feats_embed.weight)],
+                           g_feats_b=gbp[id(self.feats_embed.bias)], g_joint_w=gbp[id(self.joint_embed.weight)],
+                           g_joint_b=gbp[id(self.joint_embed.bias)]),
+                      table, d, g_feats, n_attrs, n_ctx, L, gbp[id(enc_w)] if enc_w is not None else None)
 
     def forward(self, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
         """`mask` must be get_mask(x) (it always is in the reference, carca.py:413-426); the kernel uses x != 0."""

@@ -696,6 +696,47 @@ def cross_score_bwd(groups, p_ids: Tensor, kh: Tensor, vh: Tensor, p_normed: Ten
     return dx, des
 
 
+def embed_bwd(des, segs, zq: Tensor, joint_wt: Tensor, grads: dict, table: Optional[Tensor], d: int, g: int, n_attrs: int,
+              n_ctx: int, L: int, g_pos: Optional[Tensor]) -> None:
+    """Backward of AllEmbedding.forward over all segments as ONE host call (carca_embed_bwd).  des[i]: d e [rows, ld]
+    (unmasked); segs[i] = (ids, attrs or None, ctx, is_target); joint_wt: [d + g, ld] transposed joint weight."""
+    lib = _lib.load()
+    nseg = len(des)
+    D = _lib.EmbedBwdDesc()
+    D.nseg, D.d, D.g, D.n_attrs, D.n_ctx, D.L = nseg, d, g, n_attrs, n_ctx, L
+    keep = []
+    rows = (C.c_int32 * nseg)()
+    for i, (de, (x, a, c, _tgt)) in enumerate(zip(des, segs)):
+        de = _row2d(de, "de")
+        if i == 0:
+            D.ld_de = de.stride(0)
+        elif de.stride(0) != D.ld_de:
+            raise CarcaHipError("embed_bwd: all segments must share the row stride of d e")
+        ids32 = _ids32(x.reshape(-1))
+        S = D.seg[i]
+        S.de, S.ids, S.rows, S.T = de.data_ptr(), ids32.data_ptr(), de.shape[0], x.shape[1]
+        rows[i] = de.shape[0]
+        if a is not None:
+            a, a_bs = _btk_view(a)
+            S.attrs, S.attrs_bstride = a.data_ptr(), a_bs
+        elif table is not None:
+            S.attrs_table, S.attrs_table_rows = table.data_ptr(), table.shape[0]
+        else:
+            raise CarcaHipError("embed_bwd: attrs is None and no attribute table is registered")
+        if n_ctx > 0:
+            c, c_bs = _btk_view(c)
+            S.ctx, S.ctx_bstride = c.data_ptr(), c_bs
+        keep += [de, ids32, a, c]
+    ws = torch.empty(lib.carca_embed_bwd_workspace(rows, nseg, d, g), dtype=torch.float32, device=zq.device)
+    D.zq, D.joint_wt, D.ld_joint_wt = zq.data_ptr(), joint_wt.data_ptr(), joint_wt.stride(0)
+    for k, t in grads.items():
+        setattr(D, k, t.data_ptr())
+    D.g_pos = _ptr(g_pos)
+    D.workspace = ws.data_ptr()
+    _lib.check(lib.carca_embed_bwd(C.byref(D), _stream()), "embed_bwd")
+    del keep
+
+
 def _wgrad_desc(segs, N: int, K: int, dw: Tensor, db: Optional[Tensor], mask_rows: bool, K1: int):
     D = _lib.WgradDesc()
     D.nseg = len(segs)

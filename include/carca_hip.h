@@ -408,6 +408,31 @@ size_t carca_cross_score_bwd_workspace(int B, int L, int d, int H, const int32_t
 int carca_cross_score_bwd(const CarcaCrossBwdDesc* desc /*host*/, CarcaWgradDesc* wgrads /*host, room for 4 more*/,
                           int* n_wgrads, void* stream);
 
+/* carca_embed_bwd: autograd of AllEmbedding.forward (carca.py:85-95) over all row segments, given dL/de per segment
+ * (NOT yet masked: the e * mask of carca.py:94 is applied here): position-encoding gradient, d joint_embed, d [z ; q],
+ * item-row scatter-add, d feats_embed.  Everything is launched here (these products feed each other). */
+typedef struct CarcaEmbedBwdSeg {
+  const float* de;           /* [rows, ld_de] */
+  const int32_t* ids;        /* [rows] */
+  const float* attrs;        /* [rows, n_attrs] (or a [B, T, n_attrs] view, see attrs_bstride) */
+  const float* ctx;          /* [rows, n_ctx] */
+  const float* attrs_table;  /* optional [n_items, n_attrs]: rows gathered by id instead of `attrs` */
+  int64_t attrs_bstride, ctx_bstride;
+  int32_t rows, T, attrs_table_rows;
+} CarcaEmbedBwdSeg;
+typedef struct CarcaEmbedBwdDesc {
+  CarcaEmbedBwdSeg seg[CARCA_MAX_SEGS]; /* seg[0] = the profile (the only one with a position encoding) */
+  int32_t nseg, d, g, n_attrs, n_ctx, ld_de, L;
+  const float* zq;        /* [sum rows, d + g] saved by carca_embed_fwd */
+  const float* joint_wt;  /* [d + g, ld_joint_wt]: joint_embed.weight transposed (Bt of the input-gradient product) */
+  int32_t ld_joint_wt;
+  float *g_items, *g_feats_w, *g_feats_b, *g_joint_w, *g_joint_b; /* accumulated into (caller zeroes) */
+  float* g_pos;           /* [L, d] gradient of LearnableEncoding.encoding.weight, or NULL */
+  float* workspace;       /* carca_embed_bwd_workspace(...) floats */
+} CarcaEmbedBwdDesc;
+size_t carca_embed_bwd_workspace(const int32_t* rows /*host [nseg]*/, int nseg, int d, int g);
+int carca_embed_bwd(const CarcaEmbedBwdDesc* desc /*host*/, void* stream);
+
 /* ---- f3: the optimizer step of the train driver (training.py:174, train.py:96) -------------------------------
  * torch.optim.Adam's update (no amsgrad; weight_decay added to the gradient) for every tensor of the table in one
  * launch: g += wd*p; m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
