@@ -17,6 +17,7 @@ with events on the launch stream inside the timed region.  `cpu_baseline` is the
 (oracle/carca_oracle.py, a port of the reference's PyTorch-CPU path) on all host cores.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -106,9 +107,10 @@ def cpu_baseline(c, model, profile, target, budget_s=15.0):
                       f"oracle/carca_oracle.py on torch-CPU, {cores} threads"}
 
 
-def measure_train(c, model, rank, world, device, steps):
+def measure_train(c, model, rank, world, device, steps, fold=False):
     """Secondary metric: train users/sec = fwd + bwd + gradient all-reduce + Adam, L pos + L neg
-    targets per user (train.py:84-96 call shape), dropout p = 0, same C2 model and batch size per GPU."""
+    targets per user (train.py:84-96 call shape), dropout p = 0, same C2 model and batch size per GPU.
+    fold: the opt-in re-associated embedding in both directions (CARCA.fold_embedding(True, training=True))."""
     import torch
     import torch.distributed as dist
 
@@ -124,6 +126,7 @@ def measure_train(c, model, rank, world, device, steps):
     y_true = torch.cat([(px != 0).int(), torch.zeros_like(px)], dim=1)
     batch = tuple(t.to(device) for t in (profile[0], profile[1], profile[2], o_x, o_a, o_c, y_true))
     model.train()
+    model.fold_embedding(fold, training=fold)
     from carca_replication_amd.optim import Adam
 
     opt = Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))  # training.py:174's update, one launch for all tensors
@@ -140,8 +143,12 @@ def measure_train(c, model, rank, world, device, steps):
         dist.barrier()
     dt = time.perf_counter() - t0
     model.eval()
-    return {"users_per_s": world * c["B"] * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "what": "fwd+bwd+Adam (+RCCL grad all-reduce when n_gpus>1), p=0, L pos + L neg targets, B=%d per GPU" % c["B"],
+    model.fold_embedding(False)
+    what = "fwd+bwd+Adam (+RCCL grad all-reduce when n_gpus>1), p=0, L pos + L neg targets, B=%d per GPU" % c["B"]
+    if fold:
+        what += ("; opt-in re-association of the linear embedding (one F->d GEMM forward, one F->d weight-gradient "
+                 "product backward: ~5x fewer executed flops there, same gradients to ~1e-6)")
+    return {"users_per_s": world * c["B"] * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "what": what,
             "last_loss": float(loss)}
 
 
@@ -229,6 +236,11 @@ def main():
         for _ in range(args.warmup):
             step(False)
         fence()
+        # The interpreter's cyclic collector scans every container object of the process when its oldest generation
+        # fills up: 80-120 ms here (torch + the synthetic inputs), i.e. one such pause inside a 24-step train measurement
+        # reads as +4 ms per step.  Everything built so far is long-lived: park it in the permanent generation.
+        gc.collect()
+        gc.freeze()
         time.sleep(0.3)  # let the CPU pools used while building the inputs go idle (cgroup CPU quota, see above)
         for _ in range(3):
             step(False)
@@ -298,9 +310,11 @@ def main():
                      "what": "CARCA.fold_embedding(True): e = z W_jz^T + [a;c] (W_jq W_f)^T + const, one F->d GEMM instead of "
                              "F->g->d; executed flops per user 5x lower in the embedding, algorithmic flops unchanged"}
 
-    train_info = None
+    train_info = train_fold_info = None
     if args.train_steps > 0:
         train_info = measure_train(c, model, rank, world, device, args.train_steps)
+        if not args.no_fold:
+            train_fold_info = measure_train(c, model, rank, world, device, args.train_steps, fold=True)
 
     feat_ms = sorted(e[0].elapsed_ms(e[1]) for e in used)
     ca_ms = sorted(e[2].elapsed_ms(e[3]) for e in ca_used)
@@ -345,6 +359,8 @@ def main():
         }
         if train_info is not None:
             out["train"] = train_info
+        if train_fold_info is not None:
+            out["train_folded_embedding"] = train_fold_info
         if table_info is not None:
             out["attr_table_path"] = table_info
         if fold_info is not None:

@@ -144,7 +144,10 @@ class _CarcaFn(torch.autograd.Function):
         c_ = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
         segs = [(c_(p_x), p_a, p_c, False)] + [(c_(o_x), o_a, o_c, True) for (o_x, o_a, o_c) in targets]
         p_x = segs[0][0]
-        es, emb_saved = emb.embed_segments(segs, ld_e=dpi)
+        if emb.__dict__.get("_fold_train"):  # CARCA.fold_embedding(True, training=True): the re-associated embedding
+            es, emb_saved = emb._embed_segments_folded(segs, ld_e=dpi), "folded"
+        else:
+            es, emb_saved = emb.embed_segments(segs, ld_e=dpi)
         x = es[0]
         # one seed per forward; every dropout site hashes (seed, site id, element index)  (include/carca_hip.h)
         seed = ops.new_dropout_seed() if model.training else 0

@@ -128,7 +128,9 @@ extern "C" int carca_pack_weights(const CarcaPackDesc* descs, int n, void* strea
     PackArgs pa{};
     const int m = min(PACK_CHUNK, n - base);
     for (int i = 0; i < m; ++i) pa.d[i] = descs[base + i];
-    hipLaunchKernelGGL(pack_kernel, dim3(8, m), dim3(256), 0, stream, pa);
+    int big = 0;  // (an F x g transpose is 7.4 MB: 8 blocks took 450 us; the grid follows the largest descriptor)
+    for (int i = 0; i < m; ++i) big = max(big, pa.d[i].dst_rows * pa.d[i].dst_cols);
+    hipLaunchKernelGGL(pack_kernel, dim3(min(max(big / 2048, 8), 1024), m), dim3(256), 0, stream, pa);
     CARCA_LAUNCH_CHECK();
   }
   return CARCA_OK;

@@ -375,7 +375,9 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   }
   // worth it only when every CU gets a long run of chunks (pipeline fill + two flushes per block are overhead)
   const bool forced = carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 2 || carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 3;
-  if (!forced && (total < (long)g_num_cus * 48 || chunks < 8)) return 1;
+  // (24 chunk-tiles per CU: the d x F product of the re-associated embedding backward, 26 per CU at C2, runs 2x faster
+  // here than on the tile kernel; the joint-embedding dW, 5 per CU, does not)
+  if (!forced && (total < (long)g_num_cus * 24 || chunks < 8)) return 1;
   g.per = (int)((total + g_num_cus - 1) / g_num_cus);
   const int grid = (int)((total + g.per - 1) / g.per);
   g.V = chunks * WG_BR;

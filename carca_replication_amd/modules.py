@@ -183,6 +183,8 @@ class AllEmbedding(Embedding):
         state.pop("_attr_table", None)
         state.pop("_fold_cache", None)
         state.pop("_wj_t", None)
+        state.pop("_fold_train", None)
+        state.pop("_wf_t", None)
         return state
 
     def register_attr_table(self, attrs: Optional[Tensor]) -> None:
@@ -219,6 +221,7 @@ class AllEmbedding(Embedding):
         (bc,) = ops.gemm_rows([dict(a0=wjq, add=bj.view(d, 1))], bf.view(1, g), 1, g, 4)
         bias_c = bc[:, 0].contiguous()
         self.__dict__["_fold_cache"] = (key, wc, bias_c)
+        self.__dict__["_wf_t"] = wf_t  # [F, g] transposed copy, reused by the re-associated backward of the same step
         return wc, bias_c
 
     def _pos(self, T: int) -> Optional[Tensor]:
@@ -231,10 +234,84 @@ class AllEmbedding(Embedding):
         return ops.embed_fwd(call, self.items_embed.weight, self.feats_embed.weight, self.feats_embed.bias,
                              self.joint_embed.weight, self.joint_embed.bias, pos, ld_e, attrs_table=self.attr_table())
 
+    # ---- opt-in re-association for TRAINING (CARCA.fold_embedding(True, training=True)) -------------------------
+    # AllEmbedding is linear (carca.py:86-89): e = sqrt(d) E[x] W_jz^T + [a;c] (W_jq W_f)^T + (W_jq b_f + b_j).  Evaluated in
+    # that order the F -> g product never happens: the forward needs one F -> d GEMM (14 instead of 71 GFLOP at C2) and
+    # the backward one F -> d weight-gradient product G = (de*mask)^T [a;c], from which
+    #   d W_f = W_jq^T G,  d b_f = W_jq^T cs,  d W_jq = G W_f^T + cs (x) b_f,  cs = colsum(de*mask) = d b_j
+    # are small products.  Same algebra, different fp32 summation order (~1e-6 relative).
+    def _embed_segments_folded(self, segs, ld_e: int):
+        d = self.d
+        wc, bias_c = self.folded_weights()  # recomposed at every training step (the cache key carries the epoch)
+        E, Wj = self.items_embed.weight.detach(), self.joint_embed.weight.detach()
+        table = self.attr_table()
+        pos = _segs_pos(self.enc, segs)
+        n_ctx = segs[0][2].shape[-1]
+        n_attrs = table.shape[1] if table is not None else segs[0][1].shape[-1]
+        es = [torch.empty(x.shape[0], x.shape[1], ld_e, dtype=torch.float32, device=E.device) for (x, _, _, _) in segs]
+        outs = [e.view(-1, ld_e) for e in es]
+        ops.gemm_rows([dict(a0=E, a0_gather=True, ids=x, out=o) for (x, _, _, _), o in zip(segs, outs)], Wj[:, :d], d, d,
+                      ld_e, bias=bias_c, alpha=float(d) ** 0.5)
+
+        def src(a, x):
+            return dict(a0=a) if a is not None else dict(a0=table, a0_gather=True)
+
+        ops.gemm_rows([dict(a1=c if n_ctx else None, ids=x, add=o, out=o, add_pos=(not tgt) and pos is not None,
+                            T=x.shape[1], **src(a, x)) for (x, a, c, tgt), o in zip(segs, outs)],
+                      wc[:, :n_attrs], d, n_attrs, ld_e, bt1=wc[:, n_attrs:] if n_ctx else None, K1=n_ctx, pos=pos,
+                      mask_rows=True)
+        return es
+
+    def _embed_backward_folded(self, des, segs, gbp, L: int, dpi: int) -> None:
+        d = self.d
+        E, Wj, Wf, bf = (p.detach() for p in (self.items_embed.weight, self.joint_embed.weight, self.feats_embed.weight,
+                                               self.feats_embed.bias))
+        g_feats, F = Wf.shape
+        table = self.attr_table()
+        n_ctx = segs[0][2].shape[-1]
+        n_attrs = F - n_ctx
+        ids_seg = [sg[0] for sg in segs]
+        nseg = len(des)
+        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
+        g_joint_w, g_joint_b = gbp[id(self.joint_embed.weight)], gbp[id(self.joint_embed.bias)]
+        # d W_jz = sqrt(d) (de*mask)^T E[x];  d b_j = cs
+        ops.gemm_wgrad([dict(dy=des[i], x=E, x_gather=True, ids=ids_seg[i]) for i in range(nseg)], d, d, g_joint_w[:, :d],
+                       g_joint_b, mask_rows=True)
+        g_joint_w[:, :d].mul_(float(d) ** 0.5)
+        # d E[x] += sqrt(d) (de*mask) W_jz
+        wjz_t = ops.PackedWeights([ops.PackItem(Wj[:, :d], d, dpi, transposed=True)], des[0].device)
+        wjz_t.pack()
+        dz = ops.gemm_rows([dict(a0=des[i], ids=ids_seg[i]) for i in range(nseg)], wjz_t.view(0), d, d, d, mask_rows=True)
+        g_items = gbp[id(self.items_embed.weight)]
+        for i in range(nseg):
+            ops.embed_scatter(dz[i], ids_seg[i], d, float(d) ** 0.5, g_items)
+        # G = (de*mask)^T [a ; c]   [d, F]
+        G = torch.zeros(d, F, dtype=torch.float32, device=des[0].device)
+
+        def xsrc(i):
+            a = segs[i][1]
+            return dict(x=a) if a is not None else dict(x=table, x_gather=True)
+
+        ops.gemm_wgrad([dict(dy=des[i], ids=ids_seg[i], x1=segs[i][2] if n_ctx else None, **xsrc(i)) for i in range(nseg)],
+                       d, n_attrs, G, None, mask_rows=True, K1=n_ctx)
+        wjq = Wj[:, d:]  # [d, g] view
+        cs = g_joint_b    # colsum(de*mask), complete in stream order
+        ops.gemm_wgrad([dict(dy=wjq, x=G)], g_feats, F, gbp[id(self.feats_embed.weight)], None)
+        ops.gemm_wgrad([dict(dy=wjq, x=cs.view(d, 1))], g_feats, 1, gbp[id(self.feats_embed.bias)].view(g_feats, 1), None)
+        # d W_jq = G W_f^T + cs (x) b_f: 90 rows against K = 4102 is one long dependent chain per block as a row GEMM (150 us),
+        # so it runs as a weight-gradient product over the F "rows" of the two transposed operands instead
+        g_t = ops.PackedWeights([ops.PackItem(G, F, dpi, transposed=True)], G.device)  # G^T [F, dpi]
+        g_t.pack()
+        wf_t = self.__dict__["_wf_t"].view(0)                                          # W_f^T [F, g] of this step's forward
+        ops.gemm_wgrad([dict(dy=g_t.view(0), x=wf_t)], d, g_feats, g_joint_w[:, d:], None)
+        g_joint_w[:, d:].addmm_(cs.view(d, 1), bf.view(1, g_feats))
+
     def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int) -> None:
         """Backward of embed_segments (carca.py:85-95): des[i] = d e of segment i, [rows, dpi], NOT yet masked;
         accumulates into the gradient buffers gbp[id(param)].  One host call (carca_embed_bwd): position-encoding
         gradient, d joint_embed, d [z ; q], item-row scatter-add, d feats_embed."""
+        if isinstance(zq, str):  # the forward took the re-associated path
+            return self._embed_backward_folded(des, segs, gbp, L, dpi)
         d = self.d
         g_feats = self.feats_embed.weight.shape[0]
         table = self.attr_table()
@@ -793,10 +870,14 @@ class CARCA(_PackedModule, Model):
             return ys[0]  # (torch.cat of one tensor is a copy: the scores were allocated by this call, hand them out as is)
         return torch.cat(ys, dim=-1)
 
-    def fold_embedding(self, on: bool = True) -> "CARCA":
-        """Opt-in inference shortcut: compose AllEmbedding's two Linear layers into one (include/carca_hip.h,
-        CarcaForwardDesc.fold_wc).  Same algebra, ~1e-6 relative fp32 re-association; ignored while training."""
+    def fold_embedding(self, on: bool = True, training: bool = False) -> "CARCA":
+        """Opt-in shortcut: compose AllEmbedding's two Linear layers into one (include/carca_hip.h,
+        CarcaForwardDesc.fold_wc).  Same algebra, ~1e-6 relative fp32 re-association.  Inference only unless
+        training=True, which also re-associates the training step (AllEmbedding._embed_segments_folded: no F -> g
+        product in the forward or in the backward)."""
         self.__dict__["_fold"] = bool(on)
+        if isinstance(self.embeds, AllEmbedding):
+            self.embeds.__dict__["_fold_train"] = bool(on) and bool(training)
         return self
 
     # ---- inference: one host call per forward (include/carca_hip.h: carca_forward) -----------------------------

@@ -169,3 +169,24 @@ def test_engine_train_step_and_eval_batch():
     sums = sums.cpu()
     assert float(sums[0]) == float(fx8.outs["hr10"]) and abs(float(sums[1]) - float(fx8.outs["ndcg10"])) < 1e-4
     assert float(sums[2]) == 0.0 and float(sums[4]) == 64.0
+
+
+@pytest.mark.parametrize("name", ["d90h3", "d128h4"])
+def test_folded_training_path_matches_reference_gradients(name):
+    """CARCA.fold_embedding(True, training=True): the re-associated embedding (no F -> g product in either direction)
+    gives the reference's outputs and gradients -- same tolerances as the plain path -- and stays close to it."""
+    fx = load("g2_" + name)
+    model = model_from_fixture(fx)
+    y0, loss0 = _step(model, fx)
+    plain = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    model.fold_embedding(True, training=True)
+    y, loss = _step(model, fx)
+    assert float((y.detach().cpu() - fx.outs["y"]).abs().max()) < 2e-5
+    assert abs(float(loss) - float(fx.outs["loss"])) < 2e-6
+    _check_grads(model, {k[len("grad/"):]: v for k, v in fx.outs.items() if k.startswith("grad/")})
+    for n, p in model.named_parameters():
+        scale = float(plain[n].abs().max()) + 1e-12
+        assert float((p.grad - plain[n]).abs().max()) <= 2e-5 * scale + 1e-7, n
+    model.fold_embedding(False)
+    y1, _ = _step(model, fx)
+    assert torch.equal(y1, y0)  # and switching it off restores the plain path exactly

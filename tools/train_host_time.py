@@ -15,6 +15,8 @@ from carca_replication_amd import _lib  # noqa: E402
 for kv in filter(None, os.environ.get("TUNE", "").split(",")):  # e.g. TUNE="2=256,5=16" (carca_set_tuning keys)
     _lib.load().carca_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 model = bench.build_model(c, "cuda").train()
+if os.environ.get("FOLD"):  # the re-associated embedding in both directions (opt-in)
+    model.fold_embedding(True, training=True)
 L = c["L"]
 profile, pos, _ = eval_batch(c["B"], L, L, c["n_items"], c["n_attrs"], c["n_ctx"], seed=4321)
 px = profile[0]
