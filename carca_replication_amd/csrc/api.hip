@@ -51,7 +51,7 @@ extern "C" int carca_padded_dims(int d, int H, int* dpi, int* dhp, int* dpo) {
 }
 
 namespace {
-constexpr int PACK_CHUNK = 32;
+constexpr int PACK_CHUNK = 64;  // descriptors per launch (3.6 KB of kernel arguments): a model's forward packs fit one
 struct PackArgs {
   CarcaPackDesc d[PACK_CHUNK];
 };
