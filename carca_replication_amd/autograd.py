@@ -15,7 +15,7 @@ import torch
 from torch import Tensor
 
 from . import ops
-from ._lib import CarcaHipError
+from ._lib import MAX_BLOCKS, MAX_GROUPS, CarcaHipError
 
 
 def _zeros_like_params(params, extra: int = 0):
@@ -144,6 +144,27 @@ class _CarcaFn(torch.autograd.Function):
         c_ = lambda t: t if t.is_contiguous() else t.contiguous()  # noqa: E731
         segs = [(c_(p_x), p_a, p_c, False)] + [(c_(o_x), o_a, o_c, True) for (o_x, o_a, o_c) in targets]
         p_x = segs[0][0]
+        if (is_ca and not emb.__dict__.get("_fold_train") and model._fusable() and len(model.encoder) <= MAX_BLOCKS
+                and len(targets) <= MAX_GROUPS):
+            # the reference architecture: the whole training forward is ONE host call (carca_forward with its training
+            # extras: saved tensors, per-block outputs, dropout sites)
+            for blk in model.encoder:
+                blk._check_mode()
+            dec._check_mode()
+            tr: dict = {}
+            ys = model._forward_fused((p_x, p_a, p_c), [sg[:3] for sg in segs[1:]], train=tr)
+            st = dict(p_x=p_x, segs=segs, es=tr["es"], emb_saved=tr["zq"], blocks=tr["blocks"], enc_out=tr["enc_out"],
+                      training=model.training, B=B, L=L, m_embed=tr["m_embed"], p_emb=tr["p_emb"], dpi=dpi, is_ca=True,
+                      p_normed=tr["p_normed"], csave=tr["csave"], cw=tr["cw"], keep=tr["keep"], ngroups=len(ys))
+            if getattr(model, "_keep_dropout_masks", False):  # test hook (see below)
+                model._last_dropout_masks = dict(
+                    embed=tr["m_embed"], blocks=[{k: v for k, v in b.items() if k.startswith("m_")} for b in tr["blocks"]],
+                    cross=tr["csave"].get("m_attn"))
+            ctx.model = model
+            ctx.params = params
+            ctx.st = st
+            ctx.save_for_backward(*ys)
+            return tuple(ys)
         if emb.__dict__.get("_fold_train"):  # CARCA.fold_embedding(True, training=True): the re-associated embedding
             es, emb_saved = emb._embed_segments_folded(segs, ld_e=dpi), "folded"
         else:

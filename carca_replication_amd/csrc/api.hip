@@ -167,7 +167,9 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
   CARCA_CHECK_ARG(D && D->ngroups >= 1 && D->ngroups <= CARCA_MAX_GROUPS && D->n_blocks >= 0 &&
                       D->n_blocks <= CARCA_MAX_BLOCKS,
                   "forward: bad group / block count");
-  CARCA_CHECK_ARG(D->x_work[0] && D->x_work[1] && (D->zq || D->fold_wc), "forward: null workspace");
+  bool need_xw = false;  // the ping-pong buffers are only needed by blocks without an output of their own
+  for (int i = 0; i < D->n_blocks; ++i) need_xw = need_xw || !D->x_out[i];
+  CARCA_CHECK_ARG((!need_xw || (D->x_work[0] && D->x_work[1])) && (D->zq || D->fold_wc), "forward: null workspace");
   const int nseg = D->ngroups + 1;
   int rc;
 #define CARCA_TRY(call) \
@@ -209,11 +211,18 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     CARCA_TRY(carca_gemm_rows(&f, stream_));
     if (ev && ev[1]) (void)hipEventRecord((hipEvent_t)ev[1], stream);
   }
+  if (D->p_embed > 0.f) {  // CARCA.dropout on the profile embedding (carca.py:416), in place
+    CARCA_CHECK_ARG(D->m_embed && D->p_embed < 1.f, "forward: embedding dropout needs its mask buffer and p < 1");
+    CarcaDropout dr{D->p_embed, D->seed, 1000u};
+    CARCA_TRY(carca_dropout_fwd(D->segs[0].e_out, D->B * D->L, D->d, D->ld_e, &dr, D->m_embed, stream_));
+  }
   const float* x = D->segs[0].e_out;
   for (int i = 0; i < D->n_blocks; ++i) {
-    float* y = D->x_work[i & 1];
+    float* y = D->x_out[i] ? D->x_out[i] : D->x_work[i & 1];
+    CarcaDropout dr{D->p_block, D->seed, (uint32_t)(4 * i)};
     CARCA_TRY(carca_sa_block_fwd(x, D->ld_e, D->segs[0].ids, y, D->ld_e, D->B, D->L, D->d, D->H, &D->sa[i],
-                                 D->sa_residual[i], nullptr, nullptr, stream_));
+                                 D->sa_residual[i], D->save_blocks ? &D->sa_save[i] : nullptr,
+                                 D->p_block > 0.f ? &dr : nullptr, stream_));
     x = y;
   }
   CarcaTargetGroup groups[CARCA_MAX_GROUPS];
@@ -224,8 +233,10 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     groups[gi].N = D->N[gi];
   }
   if (ev && ev[2]) (void)hipEventRecord((hipEvent_t)ev[2], stream);
+  CarcaDropout drc{D->p_cross, D->seed, 2000u};
   CARCA_TRY(carca_cross_score_fwd(x, D->ld_e, D->segs[0].ids, D->p_normed, groups, D->ngroups, D->ld_e, D->B, D->L,
-                                  D->d, D->H, &D->ca, D->ca_residual, D->training, nullptr, nullptr, stream_));
+                                  D->d, D->H, &D->ca, D->ca_residual, D->training, D->save_cross ? &D->ca_save : nullptr,
+                                  (D->save_cross && D->p_cross > 0.f) ? &drc : nullptr, stream_));
   if (ev && ev[3]) (void)hipEventRecord((hipEvent_t)ev[3], stream);
 #undef CARCA_TRY
   return CARCA_OK;

@@ -889,7 +889,10 @@ class CARCA(_PackedModule, Model):
             return False
         return True
 
-    def _forward_fused(self, profile, targets, events=None) -> List[Tensor]:
+    def _forward_fused(self, profile, targets, events=None, train: Optional[dict] = None) -> List[Tensor]:
+        """One host call for the whole forward (carca_forward).  train: None = inference (workspaces cached per shape);
+        a dict = the TRAINING forward: fresh buffers, the backward's saved tensors and the dropout sites, all handed back
+        through that dict (the keys autograd._CarcaFn keeps in its state)."""
         import ctypes as C
 
         p_x, p_a, p_c = profile
@@ -905,14 +908,18 @@ class CARCA(_PackedModule, Model):
         n_attrs = table.shape[1] if table is not None else p_a.shape[-1]
         Ns = tuple(int(t[0].shape[1]) for t in targets)
         key = (str(dev), B, L, Ns, n_attrs, n_ctx, table is not None)
-        plan = self.__dict__.get("_plan")
-        if plan is None or plan["key"] != key:
-            rows = B * (L + sum(Ns))
-            f32 = dict(dtype=torch.float32, device=dev)
-            plan = dict(key=key, D=_lib.ForwardDesc(), zq=torch.empty(rows, d + g, **f32),
-                        es=[torch.empty(B, T, dpi, **f32) for T in (L,) + Ns],
-                        xw=[torch.empty(B, L, dpi, **f32) for _ in range(2)])
-            self.__dict__["_plan"] = plan
+        rows = B * (L + sum(Ns))
+        f32 = dict(dtype=torch.float32, device=dev)
+        if train is None:
+            plan = self.__dict__.get("_plan")
+            if plan is None or plan["key"] != key:
+                plan = dict(key=key, D=_lib.ForwardDesc(), zq=torch.empty(rows, d + g, **f32),
+                            es=[torch.empty(B, T, dpi, **f32) for T in (L,) + Ns],
+                            xw=[torch.empty(B, L, dpi, **f32) for _ in range(2)])
+                self.__dict__["_plan"] = plan
+        else:  # everything the backward reads must outlive this call: fresh buffers
+            plan = dict(D=_lib.ForwardDesc(), zq=torch.empty(rows, d + g, **f32),
+                        es=[torch.empty(B, T, dpi, **f32) for T in (L,) + Ns], xw=[None, None])
         D = plan["D"]
         segs = [(p_x, p_a, p_c)] + [tuple(t) for t in targets]
         keep = []
@@ -956,7 +963,8 @@ class CARCA(_PackedModule, Model):
             D.fold_wc, D.fold_bias, D.fold_ldwc = wc.data_ptr(), bias_c.data_ptr(), wc.stride(0)
         else:
             D.fold_wc, D.fold_bias, D.fold_ldwc = None, None, 0
-        D.x_work[0], D.x_work[1] = plan["xw"][0].data_ptr(), plan["xw"][1].data_ptr()
+        if train is None:
+            D.x_work[0], D.x_work[1] = plan["xw"][0].data_ptr(), plan["xw"][1].data_ptr()
         repack: list = []  # (after a training step every module repacks: one launch for all of them)
         for i, blk in enumerate(self.encoder):
             blk._check_mode()
@@ -972,6 +980,45 @@ class CARCA(_PackedModule, Model):
             ys.append(y)
             D.y[gi], D.N[gi] = y.data_ptr(), N
         D.p_normed = None
+        if train is not None:
+            _, _, dpo = ops.padded_dims(d, H)
+            u8 = lambda *sh: torch.empty(*sh, dtype=torch.uint8, device=dev)  # noqa: E731
+            mk = lambda n, w_: torch.empty(n, w_, **f32)  # noqa: E731
+            seed = ops.new_dropout_seed() if self.training else 0
+            p_emb = float(self.dropout.p) if self.training else 0.0
+            p_blk = max([b.drop_p() for b in self.encoder], default=0.0)
+            if any(b.drop_p() != p_blk for b in self.encoder):
+                raise CarcaHipError("forward: the blocks' dropout probabilities differ (one value per call)")
+            p_ca = dec.drop_p()
+            blocks, x_prev = [], plan["es"][0]
+            for i, blk in enumerate(self.encoder):
+                y_i = torch.empty(B, L, dpi, **f32)
+                D.x_out[i] = y_i.data_ptr()
+                sv = dict(qn=mk(B * L, dpi), qh=mk(B * L, dpo), kh=mk(B * L, dpo), vh=mk(B * L, dpo), r=mk(B * L, dpi),
+                          s2=mk(B * L, dpi), h1=mk(B * L, dpi))
+                if p_blk > 0:
+                    sv.update(m_attn=u8(B, blk.attn.H, L, L), m_ffn1=u8(B * L, dpi), m_ffn2=u8(B * L, dpi))
+                S = D.sa_save[i]
+                for k in ("qn", "qh", "kh", "vh", "r", "s2", "h1", "m_attn", "m_ffn1", "m_ffn2"):
+                    setattr(S, k, sv[k].data_ptr() if k in sv else None)
+                sv["x_in"], sv["p"] = x_prev, p_blk
+                blocks.append(sv)
+                x_prev = y_i
+            p_normed = torch.empty(B, L, dpi, **f32)
+            D.p_normed = p_normed.data_ptr()
+            csave = dict(kh=mk(B * L, dpo), vh=mk(B * L, dpo), qh=[mk(B * N, dpo) for N in Ns], p=p_ca)
+            D.ca_save.kh, D.ca_save.vh = csave["kh"].data_ptr(), csave["vh"].data_ptr()
+            if p_ca > 0:
+                csave["m_attn"] = [u8(B, H, N, L) for N in Ns]
+            for gi in range(_lib.MAX_GROUPS):
+                D.ca_save.qh[gi] = csave["qh"][gi].data_ptr() if gi < len(Ns) else None
+                D.ca_save.m_attn[gi] = csave["m_attn"][gi].data_ptr() if (p_ca > 0 and gi < len(Ns)) else None
+            m_embed = u8(B * L, d) if p_emb > 0 else None
+            D.save_blocks = D.save_cross = 1
+            D.p_embed, D.p_block, D.p_cross, D.seed = p_emb, p_blk, p_ca, seed
+            D.m_embed = m_embed.data_ptr() if m_embed is not None else None
+            train.update(es=plan["es"], zq=plan["zq"], blocks=blocks, enc_out=x_prev, p_normed=p_normed, csave=csave,
+                         cw=D.ca, m_embed=m_embed, p_emb=p_emb, keep=(keep, D))
         ev = (C.c_void_p * 4)(*events) if events is not None else None
         _lib.check(_lib.load().carca_forward(C.byref(D), ev, ops._stream()), "forward")
         return ys

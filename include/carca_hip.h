@@ -502,6 +502,21 @@ typedef struct CarcaForwardDesc {
   const float* fold_wc;
   const float* fold_bias;
   int32_t fold_ldwc;
+  /* TRAINING extras (all zero / NULL = the inference forward): the same launch sequence with the tensors the backward
+   * entries (carca_sa_block_bwd, carca_cross_score_bwd, carca_embed_bwd) need, and the reference's dropout sites.
+   *   x_out[i]     block i writes its output here instead of the ping-pong buffers (block i+1's input is saved)
+   *   sa_save[i]   CarcaSaSave of block i (save_blocks = 1);  ca_save: CarcaCaSave of the scoring kernel (save_cross = 1);
+   *                p_normed (above) receives the final norm's output
+   *   p_embed / p_block / p_cross  dropout probabilities of CARCA.dropout (carca.py:416), of every block's three sites
+   *                and of the decoder's attention weights; one `seed` per forward; sites 1000, 4 i .. 4 i + 2, 2000 + g;
+   *                m_embed [B*L, d] receives the embedding dropout's keep-mask */
+  float* x_out[CARCA_MAX_BLOCKS];
+  CarcaSaSave sa_save[CARCA_MAX_BLOCKS];
+  CarcaCaSave ca_save;
+  int32_t save_blocks, save_cross;
+  float p_embed, p_block, p_cross;
+  uint64_t seed;
+  uint8_t* m_embed;
 } CarcaForwardDesc;
 int carca_forward(const CarcaForwardDesc* desc /*host*/, void* const* ev /*4 hipEvent_t or NULL*/, void* stream);
 /* Event helpers so that a host language without a HIP binding can time kernels on the launch stream. */
