@@ -355,7 +355,12 @@ def main():
             "roofline_cross_score": {"kernel": "cross_score_kernel_w16<96,32,3> (final norm + CrossAttentionBlock)",
                                      "bound": "mfma", "achieved": ca_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                                      "unit": "TFLOP/s", "frac": ca_tflops / PEAK_F32_MFMA_TFLOPS, "avg_ms": ca_avg,
-                                     "min_ms": ca_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["ca"] / 1e9},
+                                     "min_ms": ca_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["ca"] / 1e9,
+                                     "note": "timed with its own events in an untimed pass after the timed region; at "
+                                             "B=128 the launch is one latency chain per workgroup (two workgroups per user); "
+                                             "29 % at B >= 1024 (tools/scale_attn.py); the 16-wide MFMA tiles execute 1.4x "
+                                             "the algorithmic flops (slots 50->64, targets 101->112, d 90->96, d/H 30->32), "
+                                             "so 71 % is this tiling's ceiling"},
         }
         if train_info is not None:
             out["train"] = train_info
