@@ -21,11 +21,14 @@ struct GroupsDev {
   int n;
 };
 
-// 16 waves per user; phase C is split into (16-target tile, head) wave jobs so that four waves per SIMD
+// NW = 16 waves per user; phase C is split into (16-target tile, head) wave jobs so that four waves per SIMD
 // overlap each other's weight-fragment latency; per-head partial logits meet in LDS.
+// NW = 8 is the same kernel for batches of many users per CU: two 8-wave workgroups share a CU (LDS permitting), so
+// that one user's prologue / K,V phase / barriers run under the other's target jobs, and a user's N = 101 targets
+// (21 jobs) fill 21 of 24 wave slots instead of 21 of 32.
 #define CROSS_TPR 16  // target tiles per round (jobs per round = 16 * H >= 16 waves)
-template <int DPI, int DHP, int NH>
-__global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __restrict__ p_raw, int ldp,
+template <int DPI, int DHP, int NH, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void cross_score_kernel_w16(const float* __restrict__ p_raw, int ldp,
                                                                const int32_t* __restrict__ p_ids,
                                                                float* __restrict__ p_normed,
                                                                const GroupsDev groups, int ldo, int L, int d, int dh,
@@ -38,12 +41,11 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
   } while (0)
   CA_STAMP(0);
   using G = AttGeom<DPI, DHP, NH>;
-  constexpr int NW = 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ps = lds;                     // [64][SI]
   float* Ks = Ps + ATT_LMAX * G::SI;   // [64][SO]
   float* Vt = Ks + ATT_LMAX * G::SO;   // [DPO][ATT_SK]
-  float* Yp = Vt + G::DPO * ATT_SK;    // [CROSS_TPR][NH][16] partial logits
+  float* Yp = Ps;                      // [CROSS_TPR][NH][16] partial logits (the final-norm image is dead after phase B)
 
   // With fewer users than CUs a user's target tiles are shared by TWO workgroups; both build the same final-norm /
   // K / V^T images (nothing passes between them), the first one writes the copies kept for the backward pass.
@@ -143,15 +145,13 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
 #pragma unroll
       for (int kg = 0; kg < G::NKG; ++kg) qfrag[kg] = gload4(grp.o, (int)(row * ldo) + 4 * mq + 16 * kg);
       const bool q_ok = in_range && grp.ids[row] != 0;
+      // bit (4 kt + r) = this lane's target may attend key 16 kt + 4 mq + r: real keys (pmask), when training only those
+      // before its own slot
+      unsigned long long allowed = q_ok ? pmask : 0ull;
+      if (training) allowed &= n >= 64 ? ~0ull : (1ull << n) - 1ull;
       unsigned okbits = 0;
 #pragma unroll
-      for (int kt = 0; kt < ATT_LT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * kt + 4 * mq + r;
-          const bool ok = q_ok && ((pmask >> key) & 1ull) && (!training || key < n);
-          okbits |= (ok ? 1u : 0u) << (4 * kt + r);
-        }
+      for (int kt = 0; kt < ATT_LT; ++kt) okbits |= ((unsigned)(allowed >> (16 * kt + 4 * mq)) & 15u) << (4 * kt);
       const int nkt = training ? min(LT, qt + 1) : LT;
       // the residual part of the logit (w . o, once per target) first: it is the last use of the target row's
       // fragments outside the Q projection, so they die early instead of living through the whole head
@@ -202,12 +202,19 @@ __global__ __launch_bounds__(1024) void cross_score_kernel_w16(const float* __re
 }
 
 template <int DPI, int DHP, int NH>
-int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_normed, const GroupsDev& groups, int ldo,
-                 int B, int L, int d, const CarcaCaWeights& w, int residual, int training, const CarcaCaSave& sv,
-                 const DropCfg& dc, unsigned site, hipStream_t stream) {
+constexpr size_t cross_lds_bytes() {
   using G = AttGeom<DPI, DHP, NH>;
-  const size_t lds_bytes = sizeof(float) * (ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK + CROSS_TPR * NH * 16);
-  auto kern = cross_score_kernel_w16<DPI, DHP, NH>;
+  return sizeof(float) * (ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK);
+}
+
+template <int DPI, int DHP, int NH, int NW>
+int launch_cross_nw(const float* p_raw, int ldp, const int32_t* p_ids, float* p_normed, const GroupsDev& groups, int ldo,
+                 int B, int L, int d, const CarcaCaWeights& w, int residual, int training, const CarcaCaSave& sv,
+                 const DropCfg& dc, unsigned site, int nparts, hipStream_t stream) {
+  using G = AttGeom<DPI, DHP, NH>;
+  static_assert(CROSS_TPR * NH * 16 <= ATT_LMAX * G::SI, "partial logits must fit the final-norm image they alias");
+  const size_t lds_bytes = cross_lds_bytes<DPI, DHP, NH>();
+  auto kern = cross_score_kernel_w16<DPI, DHP, NH, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -217,19 +224,29 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
     }
     attr_set = true;
   }
-  static int num_cus = 0;
-  if (num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    num_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                  ? prop.multiProcessorCount : 256;
-  }
-  const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);  // 1 = one workgroup per user, 2 = always two
-  const int nparts = (groups.tile_start[groups.n] > 1 && tune != 1 && (tune == 2 || 2 * B <= num_cus)) ? 2 : 1;
-  hipLaunchKernelGGL(kern, dim3(B * nparts), dim3(1024), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L,
+  hipLaunchKernelGGL(kern, dim3(B * nparts), dim3(NW * 64), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L,
                      d, d / NH, w, residual, training, sv, dc, site, nparts, carca_debug_buffer());
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
+}
+
+// Variant choice (tuning key 1: 1 = one 16-wave workgroup per user, 2 = always two, 3 = one 8-wave workgroup):
+//   2 B <= #CUs          two 16-wave workgroups per user, the target tiles halved between them (latency regime)
+//   B >= 2 #CUs and two workgroups' LDS fit a CU   one 8-wave workgroup per user, two resident per CU (throughput regime)
+//   otherwise            one 16-wave workgroup per user
+template <int DPI, int DHP, int NH>
+int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_normed, const GroupsDev& groups, int ldo,
+                 int B, int L, int d, const CarcaCaWeights& w, int residual, int training, const CarcaCaSave& sv,
+                 const DropCfg& dc, unsigned site, hipStream_t stream) {
+  const int num_cus = carca_num_cus();
+  const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);
+  const int nparts = (groups.tile_start[groups.n] > 1 && tune != 1 && tune != 3 && (tune == 2 || 2 * B <= num_cus)) ? 2 : 1;
+  constexpr bool pair_fits = 2 * cross_lds_bytes<DPI, DHP, NH>() <= 160 * 1024;
+  if (pair_fits && nparts == 1 && (tune == 3 || (tune == 0 && B >= 2 * num_cus)))
+    return launch_cross_nw<DPI, DHP, NH, 8>(p_raw, ldp, p_ids, p_normed, groups, ldo, B, L, d, w, residual, training, sv,
+                                            dc, site, nparts, stream);
+  return launch_cross_nw<DPI, DHP, NH, 16>(p_raw, ldp, p_ids, p_normed, groups, ldo, B, L, d, w, residual, training, sv,
+                                           dc, site, nparts, stream);
 }
 
 }  // namespace

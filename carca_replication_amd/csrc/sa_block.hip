@@ -131,14 +131,11 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
     f32x4 qfrag[G::NKG];
 #pragma unroll
     for (int kg = 0; kg < G::NKG; ++kg) qfrag[kg] = lds4(Qn + q * G::SI + 16 * kg + 4 * mq);
+    // bit (4 kt + r) = this lane's query may attend key 16 kt + 4 mq + r: real keys (pmask) at or before it (q < 64)
+    const unsigned long long allowed = q_ok ? pmask & (~0ull >> (63 - q)) : 0ull;
     unsigned okbits = 0;
 #pragma unroll
-    for (int kt = 0; kt < ATT_LT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = 16 * kt + 4 * mq + r;
-        okbits |= ((q_ok && key <= q && ((pmask >> key) & 1ull)) ? 1u : 0u) << (4 * kt + r);
-      }
+    for (int kt = 0; kt < ATT_LT; ++kt) okbits |= ((unsigned)(allowed >> (16 * kt + 4 * mq)) & 15u) << (4 * kt);
     f32x4 oh[G::NFH], p[ATT_LT];
     const unsigned midx = (unsigned)((((size_t)u * NH + h) * L + (q < L ? q : 0)) * L);
     attend_head<DPI, DHP, NH, true>(qfrag, w.wq, w.bq, Ks, Vt, h, qt + 1, okbits, sqrt_dh, oh, p, lane,

@@ -50,10 +50,11 @@ def _step(model, fx, in_prefix=""):
     return y, loss
 
 
-@pytest.fixture(params=[0, 1], ids=["shared-users", "one-workgroup-per-user"])
+@pytest.fixture(params=[0, 1, 3], ids=["shared-users", "one-workgroup-per-user", "eight-wave-scoring-workgroups"])
 def attn_variant(request):
     """The attention kernels (forward and backward) give a user to two workgroups while users <= CUs / 2 -- which every
-    fixture-sized batch satisfies -- and to one otherwise (tuning key 1 = 1 forces that path, what B > 128 takes)."""
+    fixture-sized batch satisfies -- and to one otherwise (tuning key 1 = 1 forces that path, what B > 128 takes; 3 forces
+    the scoring kernel's 8-wave workgroups, what B >= 512 takes)."""
     from carca_replication_amd import _lib
 
     lib = _lib.load()

@@ -301,7 +301,8 @@ def test_folded_embedding_matches_oracle():
 
 
 def test_two_workgroups_per_user_is_bitwise_the_same():
-    """Tuning key 1 (1 = one workgroup per user, 2 = two): the split only moves rows / target tiles between workgroups."""
+    """Tuning key 1 (1 = one workgroup per user, 2 = two, 3 = one 8-wave workgroup in the scoring kernel): the variants
+    only move rows / target tiles between workgroups and waves."""
     from carca_replication_amd import _lib
 
     cfg = O.CarcaConfig(d=90, H=3, n_blocks=2, encoding="learnable")
@@ -312,12 +313,12 @@ def test_two_workgroups_per_user_is_bitwise_the_same():
     lib = _lib.load()
     outs = {}
     try:
-        for tune in (1, 2):
+        for tune in (1, 2, 3):
             lib.carca_set_tuning(1, tune)
             with torch.no_grad():
                 outs[tune] = model(profile=dev(profile), targets=[dev(target)]).cpu()
     finally:
         lib.carca_set_tuning(1, 0)
-    assert torch.equal(outs[1], outs[2])
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
     want = O.carca_forward(P, cfg, profile, [target], training=False)
     assert float((outs[2] - want).abs().max()) < Y_ATOL

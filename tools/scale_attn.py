@@ -34,6 +34,9 @@ def timed(fn, reps=30):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+if os.environ.get("TUNE"):  # e.g. TUNE=1: the 16-wave scoring workgroups at every batch size (A/B against the 8-wave ones)
+    from carca_replication_amd import _lib
+    _lib.load().carca_set_tuning(1, int(os.environ["TUNE"]))
 for B in [int(b) for b in os.environ.get("BS", "128,256,512,1024,2048,4096,8192").split(",")]:
     x = torch.zeros(B, L, dpi, device="cuda")
     x[..., :d] = torch.randn(B, L, d, device="cuda")
