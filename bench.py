@@ -207,16 +207,17 @@ def main():
     fl = flops_per_user(c)
 
 
-    # hipEvent_t quadruples recorded INSIDE carca_forward, on the launch stream, around the feature GEMM and the
-    # scoring kernel of every timed step
+    # hipEvent_t quadruples handed to carca_forward: the first pair is bound to the feature GEMM's own dispatch on the
+    # launch stream in every timed step (hipExtLaunchKernel: the kernel's start / end, nothing extra queued), the second
+    # pair is recorded around the scoring kernel
     pool = [[ops.HipEvent() for _ in range(4)] for _ in range(args.steps)]
     used = []
     ca_pool = [[ops.HipEvent() for _ in range(4)] for _ in range(10)]
     ca_used = []
 
-    # An event record is a barrier packet of its own: ~6 us of GPU time between two kernels (kernel trace).  The timed
-    # steps therefore carry only the two records the roofline contract asks for (around the feature GEMM, every step);
-    # the scoring kernel is timed the same way in a short untimed pass afterwards.
+    # An event RECORD is a barrier packet of its own: ~6 us of GPU time between two kernels (kernel trace).  The timed
+    # steps therefore carry only the kernel-bound pair of the roofline contract (the feature GEMM, every step); the
+    # scoring kernel is timed with records in a short untimed pass afterwards.
     def step(record, which="feat"):
         if record:
             evs = pool[len(used)] if which == "feat" else ca_pool[len(ca_used)]
@@ -332,7 +333,7 @@ def main():
     ca_avg = sum(ca_ms) / len(ca_ms)
 
     traffic = None  # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/README.md)
-    tpath = os.path.join(ROOT, "profiles", "r01_i_feat_gemm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_j_feat_gemm_traffic.json")
     if c["B"] == C2["B"] and os.path.exists(tpath):
         with open(tpath) as fh:
             traffic = json.load(fh)["hbm_bytes_per_launch"]
@@ -360,16 +361,16 @@ def main():
                          "bound": "mfma", "achieved": feat_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
-                                         "WRITE_SIZE, separate passes, profiles/r01_i_feat_gemm_traffic.json; algorithmic "
+                                         "WRITE_SIZE, separate passes, profiles/r01_j_feat_gemm_traffic.json; algorithmic "
                                          "bytes 359 MB",
                          "avg_ms": feat_avg, "min_ms": feat_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["feat"] / 1e9},
-            "roofline_cross_score": {"kernel": "cross_score_kernel_w16<96,32,3> (final norm + CrossAttentionBlock)",
+            "roofline_cross_score": {"kernel": "cross_score_kernel_w16<96,32,3,16> (final norm + CrossAttentionBlock)",
                                      "bound": "mfma", "achieved": ca_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                                      "unit": "TFLOP/s", "frac": ca_tflops / PEAK_F32_MFMA_TFLOPS, "avg_ms": ca_avg,
                                      "min_ms": ca_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["ca"] / 1e9,
                                      "note": "timed with its own events in an untimed pass after the timed region; at "
                                              "B=128 the launch is one latency chain per workgroup (two workgroups per user); "
-                                             "29 % at B >= 1024 (tools/scale_attn.py); the 16-wide MFMA tiles execute 1.4x "
+                                             "33-39 % at B = 512-4096 with two 8-wave workgroups per CU (tools/scale_attn.py); the 16-wide MFMA tiles execute 1.4x "
                                              "the algorithmic flops (slots 50->64, targets 101->112, d 90->96, d/H 30->32), "
                                              "so 71 % is this tiling's ceiling"},
         }

@@ -162,6 +162,21 @@ extern "C" int carca_event_elapsed_ms(void* start, void* stop, float* ms_out) {
   return CARCA_OK;
 }
 
+namespace {
+thread_local hipEvent_t g_armed_start = nullptr, g_armed_stop = nullptr;
+}
+void carca_arm_launch_events(void* start, void* stop) {
+  g_armed_start = (hipEvent_t)start;
+  g_armed_stop = (hipEvent_t)stop;
+}
+bool carca_take_launch_events(hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_armed_start && !g_armed_stop) return false;
+  *start = g_armed_start;
+  *stop = g_armed_stop;
+  g_armed_start = g_armed_stop = nullptr;
+  return true;
+}
+
 extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(D && D->ngroups >= 1 && D->ngroups <= CARCA_MAX_GROUPS && D->n_blocks >= 0 &&
@@ -179,11 +194,16 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
   } while (0)
   if (!D->fold_wc) {
     // gather + feature GEMM in one call: the gather rides in the GEMM's launch when that leaves a CU idle (C2: 255 blocks)
-    if (ev && ev[0]) (void)hipEventRecord((hipEvent_t)ev[0], stream);
-    CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
-                              D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_GATHER | CARCA_EMBED_FEAT,
-                              stream_));
-    if (ev && ev[1]) (void)hipEventRecord((hipEvent_t)ev[1], stream);
+    // ev[0], ev[1]: bound to the feature GEMM's own dispatch (start / end of that kernel, no packets of their own)
+    if (ev && ev[0] && ev[1]) carca_arm_launch_events(ev[0], ev[1]);
+    rc = carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
+                         D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_GATHER | CARCA_EMBED_FEAT, stream_);
+    hipEvent_t left0, left1;
+    if (carca_take_launch_events(&left0, &left1) && rc == CARCA_OK) {
+      carca_set_error("forward: the feature GEMM's launch did not take the timing events");
+      return CARCA_ERR_UNSUPPORTED;
+    }
+    if (rc != CARCA_OK) return rc;
     CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
                               D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_JOINT, stream_));
   } else {
@@ -207,9 +227,8 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     f.lda0 = D->n_attrs; f.lda1 = D->n_ctx; f.K0 = D->n_attrs; f.K1 = D->n_ctx;
     f.bt0 = D->fold_wc; f.ldb0 = D->fold_ldwc; f.bt1 = D->fold_wc + D->n_attrs; f.ldb1 = D->fold_ldwc;
     f.N = D->d; f.ldc = D->ld_e; f.ncols_out = D->ld_e; f.ld_add = D->ld_e; f.pos = D->pos; f.mask_rows = 1;
-    if (ev && ev[0]) (void)hipEventRecord((hipEvent_t)ev[0], stream);
+    if (ev && ev[0] && ev[1]) carca_arm_launch_events(ev[0], ev[1]);
     CARCA_TRY(carca_gemm_rows(&f, stream_));
-    if (ev && ev[1]) (void)hipEventRecord((hipEvent_t)ev[1], stream);
   }
   if (D->p_embed > 0.f) {  // CARCA.dropout on the profile embedding (carca.py:416), in place
     CARCA_CHECK_ARG(D->m_embed && D->p_embed < 1.f, "forward: embedding dropout needs its mask buffer and p < 1");

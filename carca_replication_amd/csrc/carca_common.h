@@ -145,6 +145,11 @@ __device__ __forceinline__ void carca_gather_rows(const CarcaGatherArgs& ga, int
 enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_COUNT = 8 };
 int carca_tuning(int key);
 int carca_num_cus();  // compute units of the current device (cached)
+// Timing events for this thread's NEXT row-GEMM launch (the roofline hooks of carca_forward): the launch binds them to
+// its own dispatch packet (hipExtLaunchKernel), so elapsed(start, stop) is the kernel's duration and no barrier packet
+// is queued around it (an hipEventRecord is one: ~6 us of GPU time between two kernels each).
+void carca_arm_launch_events(void* start, void* stop);
+bool carca_take_launch_events(hipEvent_t* start, hipEvent_t* stop);  // true (and disarms) when armed
 struct CarcaGemmDesc;
 // carca_gemm_rows with the item-row gather riding along where the kernel choice leaves a CU idle; *rode tells whether
 // it did (otherwise the caller launches the gather itself)

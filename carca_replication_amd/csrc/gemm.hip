@@ -21,6 +21,7 @@
 // Common: operands staged global -> registers -> LDS with rows padded to 36 floats (conflict-free 16-byte fragment
 // reads), buffer loads with 32-bit offsets wherever they provably fit, blocks that share an A row block numbered so
 // that they land on the same XCD (the A tile is fetched from HBM once and re-read from that XCD's L2).
+#include <hip/hip_ext.h>
 #include "carca_common.h"
 #include <type_traits>
 #include "../../include/carca_hip.h"
@@ -756,7 +757,11 @@ static int launch_gemm_rows(const CarcaGemmDesc* desc, hipStream_t stream) {
   g.nrb = rb;
   g.ncb = (desc->ncols_out + BN - 1) / BN;
   const int grid = rb * g.ncb;
-  hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, PF, BUF>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
+  hipEvent_t e0, e1;
+  if (carca_take_launch_events(&e0, &e1))
+    hipExtLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, PF, BUF>), dim3(grid), dim3((BM / 32) * 64), 0, stream, e0, e1, 0, g);
+  else
+    hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, PF, BUF>), dim3(grid), dim3((BM / 32) * 64), 0, stream, g);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -783,7 +788,11 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream, co
     ++grid;
     if (rode) *rode = 1;
   }
-  hipLaunchKernelGGL((gemm_rows_cu_kernel<DBG, TN>), dim3(grid), dim3(768), 0, stream, g);
+  hipEvent_t e0, e1;
+  if (carca_take_launch_events(&e0, &e1))
+    hipExtLaunchKernelGGL((gemm_rows_cu_kernel<DBG, TN>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
+  else
+    hipLaunchKernelGGL((gemm_rows_cu_kernel<DBG, TN>), dim3(grid), dim3(768), 0, stream, g);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

@@ -477,9 +477,11 @@ int carca_build_train_batch(const int32_t* hist, const int64_t* offs, const floa
  * at p = 0.  All buffers are caller-allocated:
  *   segs[0] = profile, segs[1..ngroups] = target groups (their e_out feed the scoring kernel),
  *   x_work[2] = two [B*L, ld_e] ping-pong buffers for the blocks' outputs.
- * ev (optional, host array of 4 hipEvent_t): recorded before/after the feature GEMM and before/after the
- * scoring kernel, on `stream`, so a benchmark can time exactly those kernels inside its timed region.  Entries may be
- * NULL (not recorded): a record is a barrier packet of its own and costs ~6 us of GPU time between two kernels. */
+ * ev (optional, host array of 4 hipEvent_t, entries may be NULL): so that a benchmark can time exactly these kernels
+ * inside its timed region.  ev[0], ev[1] (both or neither) are BOUND to the feature GEMM's dispatch on `stream`
+ * (hipExtLaunchKernel: start / end of that kernel, hipEventElapsedTime(ev[0], ev[1]) = its duration; nothing extra is
+ * queued).  ev[2], ev[3] are recorded (hipEventRecord) before / after the scoring kernel: a record is a barrier
+ * packet of its own and costs ~6 us of GPU time between two kernels. */
 #define CARCA_MAX_BLOCKS 8
 typedef struct CarcaForwardDesc {
   CarcaRowSeg segs[CARCA_MAX_SEGS];
