@@ -322,3 +322,27 @@ def test_two_workgroups_per_user_is_bitwise_the_same():
     assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
     want = O.carca_forward(P, cfg, profile, [target], training=False)
     assert float((outs[2] - want).abs().max()) < Y_ATOL
+
+
+def test_big_batch_scoring_variant_is_bitwise_the_same():
+    """B >= 2 x #CUs takes the scoring kernel's 8-wave workgroups (two resident per CU) by itself: same bits as the 16-wave
+    ones (tuning key 1 = 1), and the oracle's numbers."""
+    from carca_replication_amd import _lib
+
+    cfg = O.CarcaConfig(d=90, H=3, n_blocks=1, encoding="learnable")
+    n_items, n_attrs, n_ctx, g, L, N, B = 200, 24, 3, 64, 50, 37, 530
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    profile, target, _ = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=11)
+    model = model_from_params(P, cfg).eval()
+    lib = _lib.load()
+    outs = {}
+    try:
+        for tune in (0, 1):
+            lib.carca_set_tuning(1, tune)
+            with torch.no_grad():
+                outs[tune] = model(profile=dev(profile), targets=[dev(target)]).cpu()
+    finally:
+        lib.carca_set_tuning(1, 0)
+    assert torch.equal(outs[0], outs[1])
+    want = O.carca_forward(P, cfg, profile, [target], training=False)
+    assert float((outs[0] - want).abs().max()) < Y_ATOL

@@ -19,7 +19,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
                         decoder=["ca", "ca", "dot"][int(rng.integers(3))])
     L = int(rng.integers(1, 65))
     N = int(rng.integers(1, 230))
-    B = int([1, 2, 7, 64, 128, 129, 300][int(rng.integers(7))])
+    B = int([1, 2, 7, 64, 128, 129, 300, 520, 700][int(rng.integers(9))])  # (>= 512: the 8-wave scoring workgroups)
     n_attrs = int([7, 64, 513, 2048][int(rng.integers(4))])
     n_ctx, g, n_items = int(rng.integers(1, 9)), int([32, 250, 450][int(rng.integers(3))]), int(rng.integers(50, 400))
     n_items = max(n_items, L + N + 10)
