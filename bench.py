@@ -108,10 +108,11 @@ def cpu_baseline(c, model, profile, target, budget_s=15.0):
                       f"oracle/carca_oracle.py on torch-CPU, {cores} threads"}
 
 
-def measure_train(c, model, rank, world, device, steps, fold=False):
+def measure_train(c, model, rank, world, device, steps, fold=False, graphed=False):
     """Secondary metric: train users/sec = fwd + bwd + gradient all-reduce + Adam, L pos + L neg
     targets per user (train.py:84-96 call shape), dropout p = 0, same C2 model and batch size per GPU.
-    fold: the opt-in re-associated embedding in both directions (CARCA.fold_embedding(True, training=True))."""
+    fold: the opt-in re-associated embedding in both directions (CARCA.fold_embedding(True, training=True)).
+    graphed: forward + backward replayed from a hipGraph (engine.GraphedTrainStep, single process only)."""
     import torch
     import torch.distributed as dist
 
@@ -131,14 +132,19 @@ def measure_train(c, model, rank, world, device, steps, fold=False):
     from carca_replication_amd.optim import Adam
 
     opt = Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))  # training.py:174's update, one launch for all tensors
+    if graphed:
+        captured = engine.GraphedTrainStep(model, opt, batch)
+        run = lambda: captured(batch)  # noqa: E731
+    else:
+        run = lambda: engine.train_step(model, opt, batch, sharded=world > 1)  # noqa: E731
     for _ in range(6):  # (allocator pools, lazily loaded code objects and the optimizer state settle in the first steps)
-        engine.train_step(model, opt, batch, sharded=world > 1)
+        run()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = engine.train_step(model, opt, batch, sharded=world > 1)
+        loss = run()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -149,6 +155,9 @@ def measure_train(c, model, rank, world, device, steps, fold=False):
     if fold:
         what += ("; opt-in re-association of the linear embedding (one F->d GEMM forward, one F->d weight-gradient "
                  "product backward: ~5x fewer executed flops there, same gradients to ~1e-6)")
+    if graphed:
+        what += ("; forward + backward replayed from ONE hipGraph (engine.GraphedTrainStep), the optimizer's launch issued "
+                 "behind it: this path has 1.1 ms of kernels behind 1.5-2.3 ms of host-side launch work when issued eagerly")
     return {"users_per_s": world * c["B"] * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "what": what,
             "last_loss": float(loss)}
 
@@ -321,11 +330,14 @@ def main():
                      "what": "CARCA.fold_embedding(True): e = z W_jz^T + [a;c] (W_jq W_f)^T + const, one F->d GEMM instead of "
                              "F->g->d; executed flops per user 5x lower in the embedding, algorithmic flops unchanged"}
 
-    train_info = train_fold_info = None
+    train_info = train_fold_info = train_fold_graph_info = None
     if args.train_steps > 0:
         train_info = measure_train(c, model, rank, world, device, args.train_steps)
         if not args.no_fold:
             train_fold_info = measure_train(c, model, rank, world, device, args.train_steps, fold=True)
+            if world == 1:
+                train_fold_graph_info = measure_train(c, model, rank, world, device, args.train_steps, fold=True,
+                                                      graphed=True)
 
     feat_ms = sorted(e[0].elapsed_ms(e[1]) for e in used)
     ca_ms = sorted(e[2].elapsed_ms(e[3]) for e in ca_used)
@@ -378,6 +390,8 @@ def main():
             out["train"] = train_info
         if train_fold_info is not None:
             out["train_folded_embedding"] = train_fold_info
+        if train_fold_graph_info is not None:
+            out["train_folded_embedding_graphed"] = train_fold_graph_info
         if table_info is not None:
             out["attr_table_path"] = table_info
         if fold_info is not None:

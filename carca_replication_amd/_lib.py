@@ -138,7 +138,7 @@ class WgradDesc(C.Structure):
 
 
 class Dropout(C.Structure):
-    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("site", C.c_uint32)]
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("site", C.c_uint32), ("seed_offset", C.c_void_p)]
 
 
 class SaSave(C.Structure):
@@ -216,7 +216,7 @@ class ForwardDesc(C.Structure):
                 ("N", C.c_int32 * MAX_GROUPS), ("p_normed", _fp), ("fold_wc", _fp), ("fold_bias", _fp),
                 ("fold_ldwc", C.c_int32), ("x_out", _fp * MAX_BLOCKS), ("sa_save", SaSave * MAX_BLOCKS), ("ca_save", CaSave),
                 ("save_blocks", C.c_int32), ("save_cross", C.c_int32), ("p_embed", C.c_float), ("p_block", C.c_float),
-                ("p_cross", C.c_float), ("seed", C.c_uint64), ("m_embed", _fp)]
+                ("p_cross", C.c_float), ("seed", C.c_uint64), ("m_embed", _fp), ("seed_offset", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/carca_hip.h declares

@@ -165,6 +165,29 @@ extern "C" int carca_event_elapsed_ms(void* start, void* stop, float* ms_out) {
 namespace {
 thread_local hipEvent_t g_armed_start = nullptr, g_armed_stop = nullptr;
 }
+bool carca_stream_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
+void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view) {
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  void* p = nullptr;
+  hipError_t rc;
+  if (host_mapped) {
+    rc = hipHostMalloc(&p, bytes, hipHostMallocMapped);
+    if (rc == hipSuccess && device_view) rc = hipHostGetDevicePointer(device_view, p, 0);
+  } else {
+    rc = hipMalloc(&p, bytes);
+    if (device_view) *device_view = p;
+  }
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (rc != hipSuccess) {
+    carca_set_error("allocation of %zu B during stream capture failed: %s", bytes, hipGetErrorString(rc));
+    return nullptr;
+  }
+  return p;
+}
 void carca_arm_launch_events(void* start, void* stop) {
   g_armed_start = (hipEvent_t)start;
   g_armed_stop = (hipEvent_t)stop;
@@ -232,13 +255,13 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
   }
   if (D->p_embed > 0.f) {  // CARCA.dropout on the profile embedding (carca.py:416), in place
     CARCA_CHECK_ARG(D->m_embed && D->p_embed < 1.f, "forward: embedding dropout needs its mask buffer and p < 1");
-    CarcaDropout dr{D->p_embed, D->seed, 1000u};
+    CarcaDropout dr{D->p_embed, D->seed, 1000u, D->seed_offset};
     CARCA_TRY(carca_dropout_fwd(D->segs[0].e_out, D->B * D->L, D->d, D->ld_e, &dr, D->m_embed, stream_));
   }
   const float* x = D->segs[0].e_out;
   for (int i = 0; i < D->n_blocks; ++i) {
     float* y = D->x_out[i] ? D->x_out[i] : D->x_work[i & 1];
-    CarcaDropout dr{D->p_block, D->seed, (uint32_t)(4 * i)};
+    CarcaDropout dr{D->p_block, D->seed, (uint32_t)(4 * i), D->seed_offset};
     CARCA_TRY(carca_sa_block_fwd(x, D->ld_e, D->segs[0].ids, y, D->ld_e, D->B, D->L, D->d, D->H, &D->sa[i],
                                  D->sa_residual[i], D->save_blocks ? &D->sa_save[i] : nullptr,
                                  D->p_block > 0.f ? &dr : nullptr, stream_));
@@ -252,7 +275,7 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     groups[gi].N = D->N[gi];
   }
   if (ev && ev[2]) (void)hipEventRecord((hipEvent_t)ev[2], stream);
-  CarcaDropout drc{D->p_cross, D->seed, 2000u};
+  CarcaDropout drc{D->p_cross, D->seed, 2000u, D->seed_offset};
   CARCA_TRY(carca_cross_score_fwd(x, D->ld_e, D->segs[0].ids, D->p_normed, groups, D->ngroups, D->ld_e, D->B, D->L,
                                   D->d, D->H, &D->ca, D->ca_residual, D->training, D->save_cross ? &D->ca_save : nullptr,
                                   (D->save_cross && D->p_cross > 0.f) ? &drc : nullptr, stream_));

@@ -31,9 +31,10 @@ struct DropCfg {
   unsigned thresh;  // 0 = dropout off
   unsigned s0, s1;  // seed halves
   float scale;      // 1 / (1 - p)
+  const unsigned long long* offset;  // device, or null: added to the seed when the kernel starts (hipGraph replays)
 };
 __host__ inline DropCfg make_drop(const CarcaDropout* d) {
-  DropCfg c{0u, 0u, 0u, 1.0f};
+  DropCfg c{0u, 0u, 0u, 1.0f, nullptr};
   if (d && d->p > 0.f) {
     double t = (double)d->p * 16777216.0;
     c.thresh = t >= 16777215.0 ? 16777215u : (unsigned)t;
@@ -41,6 +42,16 @@ __host__ inline DropCfg make_drop(const CarcaDropout* d) {
     c.s0 = (unsigned)d->seed;
     c.s1 = (unsigned)(d->seed >> 32);
     c.scale = (float)(1.0 / (1.0 - (double)d->p));
+    c.offset = (const unsigned long long*)d->seed_offset;
+  }
+  return c;
+}
+// the launch's DropCfg with the device-side seed offset applied (a kernel's first statement about dropout)
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg c) {
+  if (c.thresh && c.offset) {
+    const unsigned long long sd = (((unsigned long long)c.s1 << 32) | c.s0) + *c.offset;
+    c.s0 = (unsigned)sd;
+    c.s1 = (unsigned)(sd >> 32);
   }
   return c;
 }

@@ -132,8 +132,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 // in-place dropout of a [rows, cols] matrix + its keep-mask (CARCA.dropout on the profile embedding)
-__global__ void dropout_fwd_kernel(float* __restrict__ x, int rows, int cols, int ld, const DropCfg dc, unsigned site,
+__global__ void dropout_fwd_kernel(float* __restrict__ x, int rows, int cols, int ld, const DropCfg dc_arg, unsigned site,
                                    uint8_t* __restrict__ mask) {
+  const DropCfg dc = drop_resolve(dc_arg);
   const int total = rows * cols;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int r = i / cols, c = i - r * cols;

@@ -148,6 +148,13 @@ int carca_num_cus();  // compute units of the current device (cached)
 // Timing events for this thread's NEXT row-GEMM launch (the roofline hooks of carca_forward): the launch binds them to
 // its own dispatch packet (hipExtLaunchKernel), so elapsed(start, stop) is the kernel's duration and no barrier packet
 // is queued around it (an hipEventRecord is one: ~6 us of GPU time between two kernels each).
+// True while `stream` is being captured into a hipGraph.  Launch helpers that hand a kernel memory of the library's own
+// (descriptor rings, row tables) then give it storage that is never recycled instead of an event-guarded ring slot: a
+// replay runs without the host code that would refill the slot, and an event recorded during capture cannot be waited on.
+bool carca_stream_capturing(hipStream_t stream);
+// hipMalloc / hipHostMalloc(mapped) that are legal inside a capture (thread capture mode relaxed around the call);
+// the memory lives as long as the process (a few hundred KB per captured step)
+void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view);
 void carca_arm_launch_events(void* start, void* stop);
 bool carca_take_launch_events(hipEvent_t* start, hipEvent_t* stop);  // true (and disarms) when armed
 struct CarcaGemmDesc;

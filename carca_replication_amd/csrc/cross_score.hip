@@ -33,8 +33,9 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_score_kernel_w16(const float
                                                                float* __restrict__ p_normed,
                                                                const GroupsDev groups, int ldo, int L, int d, int dh,
                                                                const CarcaCaWeights w, int residual, int training,
-                                                               const CarcaCaSave sv, const DropCfg dc,
+                                                               const CarcaCaSave sv, const DropCfg dc_arg,
                                                                unsigned site, int nparts, unsigned long long* stamps) {
+  const DropCfg dc = drop_resolve(dc_arg);
 #define CA_STAMP(i)                                                                                \
   do {                                                                                             \
     if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \

@@ -1057,11 +1057,20 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
   constexpr int BNO = 96, BKO = 128, BR = 32;
   const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
   int done = 0;
+  const bool capturing = carca_stream_capturing(stream);  // (hipGraph capture: storage of its own, see carca_common.h)
   while (done < n) {
-    const int slot = g_group_next;
-    g_group_next = (g_group_next + 1) % GROUP_RING;
-    if (g_group_used[slot]) (void)hipEventSynchronize(g_group_ev[slot]);  // normally long complete
-    WgradDev* host = g_group_host + (size_t)slot * WGRAD_GROUP_MAX;
+    int slot = -1;
+    WgradDev *host, *dev;
+    if (capturing) {
+      host = (WgradDev*)carca_capture_alloc(sizeof(WgradDev) * WGRAD_GROUP_MAX, true, (void**)&dev);
+      if (!host) return CARCA_ERR_BADARG;
+    } else {
+      slot = g_group_next;
+      g_group_next = (g_group_next + 1) % GROUP_RING;
+      if (g_group_used[slot]) (void)hipEventSynchronize(g_group_ev[slot]);  // normally long complete
+      host = g_group_host + (size_t)slot * WGRAD_GROUP_MAX;
+      dev = g_group_dev + (size_t)slot * WGRAD_GROUP_MAX;
+    }
     WgradGroupIndex idx{};
     int blocks = 0;
     while (done < n && idx.n < WGRAD_GROUP_MAX) {
@@ -1089,10 +1098,11 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
     }
     if (idx.n == 0) continue;
     idx.block_start[idx.n] = blocks;
-    WgradDev* dev = g_group_dev + (size_t)slot * WGRAD_GROUP_MAX;
     hipLaunchKernelGGL((gemm_wgrad_group_kernel<BNO, BKO, BR>), dim3(blocks), dim3(256), 0, stream, dev, idx);
-    (void)hipEventRecord(g_group_ev[slot], stream);
-    g_group_used[slot] = true;
+    if (slot >= 0) {
+      (void)hipEventRecord(g_group_ev[slot], stream);
+      g_group_used[slot] = true;
+    }
     CARCA_LAUNCH_CHECK();
   }
   return CARCA_OK;

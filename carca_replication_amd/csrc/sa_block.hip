@@ -23,9 +23,10 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
                                                             const int32_t* __restrict__ ids,
                                                             float* __restrict__ y, int ldy, int L, int d, int dh,
                                                             const CarcaSaWeights w, int residual,
-                                                            const CarcaSaSave sv, const DropCfg dc, unsigned site,
+                                                            const CarcaSaSave sv, const DropCfg dc_arg, unsigned site,
                                                             unsigned long long* stamps, int nparts) {
   using G = AttGeom<DPI, DHP, NH>;
+  const DropCfg dc = drop_resolve(dc_arg);
   static_assert(G::SO >= G::SI, "H1 reuses the K image");
 #define SA_STAMP(i)                                                                       \
   do {                                                                                    \

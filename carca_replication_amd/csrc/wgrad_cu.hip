@@ -385,27 +385,37 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
     for (int i = 0; i < TAB_RING; ++i) (void)hipEventCreateWithFlags(&g_tab_ev[i], hipEventDisableTiming);
     g_tab_init = true;
   }
-  const int slot = g_tab_next;
-  g_tab_next = (g_tab_next + 1) % TAB_RING;
-  if (g_tab_used[slot]) (void)hipEventSynchronize(g_tab_ev[slot]);  // its last consumer: normally long finished
-  if ((size_t)3 * g.V > g_tab_elems[slot]) {
-    if (g_tab[slot]) (void)hipFree(g_tab[slot]);
-    g_tab[slot] = nullptr;
-    g_tab_elems[slot] = (size_t)3 * g.V * 2;
-    if (hipMalloc(&g_tab[slot], g_tab_elems[slot] * sizeof(unsigned)) != hipSuccess) {
-      g_tab_elems[slot] = 0;
-      return 1;
+  int slot = -1;
+  unsigned* tab;
+  if (carca_stream_capturing(stream)) {  // hipGraph capture: a table of the graph's own, no ring slot, no guard event
+    tab = (unsigned*)carca_capture_alloc((size_t)3 * g.V * sizeof(unsigned), false, nullptr);
+    if (!tab) return 1;
+  } else {
+    slot = g_tab_next;
+    g_tab_next = (g_tab_next + 1) % TAB_RING;
+    if (g_tab_used[slot]) (void)hipEventSynchronize(g_tab_ev[slot]);  // its last consumer: normally long finished
+    if ((size_t)3 * g.V > g_tab_elems[slot]) {
+      if (g_tab[slot]) (void)hipFree(g_tab[slot]);
+      g_tab[slot] = nullptr;
+      g_tab_elems[slot] = (size_t)3 * g.V * 2;
+      if (hipMalloc(&g_tab[slot], g_tab_elems[slot] * sizeof(unsigned)) != hipSuccess) {
+        g_tab_elems[slot] = 0;
+        return 1;
+      }
     }
+    tab = g_tab[slot];
   }
-  g.tab = g_tab[slot];
-  hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((g.V + 255) / 256), dim3(256), 0, stream, g, g_tab[slot]);
+  g.tab = tab;
+  hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((g.V + 255) / 256), dim3(256), 0, stream, g, tab);
   g.dbg = carca_debug_buffer();
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 3 && g.dbg)
     hipLaunchKernelGGL(gemm_wgrad_cu_kernel<1>, dim3(grid), dim3(WG_NT), 0, stream, g);
   else
     hipLaunchKernelGGL(gemm_wgrad_cu_kernel<0>, dim3(grid), dim3(WG_NT), 0, stream, g);
-  (void)hipEventRecord(g_tab_ev[slot], stream);
-  g_tab_used[slot] = true;
+  if (slot >= 0) {
+    (void)hipEventRecord(g_tab_ev[slot], stream);
+    g_tab_used[slot] = true;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     carca_set_error("HIP launch failed: %s", hipGetErrorString(e));

@@ -1016,6 +1016,7 @@ class CARCA(_PackedModule, Model):
             m_embed = u8(B * L, d) if p_emb > 0 else None
             D.save_blocks = D.save_cross = 1
             D.p_embed, D.p_block, D.p_cross, D.seed = p_emb, p_blk, p_ca, seed
+            D.seed_offset = ops.dropout_seed_offset_ptr()
             D.m_embed = m_embed.data_ptr() if m_embed is not None else None
             train.update(es=plan["es"], zq=plan["zq"], blocks=blocks, enc_out=x_prev, p_normed=p_normed, csave=csave,
                          cw=D.ca, m_embed=m_embed, p_emb=p_emb, keep=(keep, D))

@@ -119,11 +119,29 @@ def new_dropout_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+_SEED_OFFSET: Optional[Tensor] = None  # device int64[1] added to every dropout seed inside the kernels, or None
+
+
+def set_dropout_seed_offset(counter: Optional[Tensor]) -> None:
+    """While set, every dropout site's kernel adds counter[0] (device, int64) to its seed when it starts.  A train step
+    captured into a hipGraph repeats its launch arguments -- the seeds among them -- so the graph increments this
+    counter per replay instead (engine.GraphedTrainStep); None (default) = seeds are used as passed."""
+    global _SEED_OFFSET
+    if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
+        raise CarcaHipError("set_dropout_seed_offset: need a CUDA int64 tensor of one element")
+    _SEED_OFFSET = counter
+
+
+def dropout_seed_offset_ptr() -> Optional[int]:
+    return _SEED_OFFSET.data_ptr() if _SEED_OFFSET is not None else None
+
+
 def _drop_struct(p: float, seed: int, site: int):
     if not p:
         return None
     d = _lib.Dropout()
     d.p, d.seed, d.site = float(p), int(seed), int(site)
+    d.seed_offset = dropout_seed_offset_ptr()
     return d
 
 

@@ -216,6 +216,8 @@ typedef struct CarcaDropout {
   float p;
   uint64_t seed;
   uint32_t site; /* first site id of this call; a kernel with several sites uses site, site+1, ... */
+  const uint64_t* seed_offset; /* device, or NULL: *seed_offset is added to `seed` when the kernel starts -- a step
+                                  captured into a hipGraph repeats its launch arguments, the graph bumps this counter */
 } CarcaDropout;
 
 /* Tensors the backward pass needs (all optional; pass save = NULL in eval): */
@@ -520,6 +522,7 @@ typedef struct CarcaForwardDesc {
   float p_embed, p_block, p_cross;
   uint64_t seed;
   uint8_t* m_embed;
+  const uint64_t* seed_offset; /* device or NULL, see CarcaDropout */
 } CarcaForwardDesc;
 int carca_forward(const CarcaForwardDesc* desc /*host*/, void* const* ev /*4 hipEvent_t or NULL*/, void* stream);
 /* Event helpers so that a host language without a HIP binding can time kernels on the launch stream. */

@@ -1,0 +1,77 @@
+"""engine.GraphedTrainStep: forward + backward replayed from a hipGraph, optimizer launched behind it."""
+import copy
+
+import pytest
+import torch
+
+from oracle import carca_oracle as O
+from tests.model_util import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(p_drop):
+    from carca_replication_amd.optim import Adam
+    from carca_replication_amd.synth import eval_batch
+
+    cfg = O.CarcaConfig(d=90, H=3, n_blocks=2, encoding="learnable")
+    n_items, n_attrs, n_ctx, g, L, B = 300, 40, 6, 64, 20, 9
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    profile, pos, _ = eval_batch(B, L, L, n_items, n_attrs, n_ctx, seed=5)
+    px = profile[0]
+    o_x = torch.cat([pos[0] * (px != 0), pos[0].flip(1) * (px != 0)], dim=1)
+    o_a = torch.cat([pos[1], pos[1].flip(1)], dim=1)
+    o_c = torch.cat([pos[2], pos[2]], dim=1)
+    y_true = torch.cat([(px != 0).int(), torch.zeros_like(px)], dim=1)
+    batch = tuple(t.cuda() for t in (profile[0], profile[1], profile[2], o_x, o_a, o_c, y_true))
+
+    def fresh():
+        m = build_model(dict(d=cfg.d, H=cfg.H, n_blocks=cfg.n_blocks, encoding=cfg.encoding), n_items, g, n_ctx, n_attrs, L,
+                        p=p_drop)
+        m.load_state_dict(copy.deepcopy(P), strict=True)
+        m = m.cuda().train()
+        return m, Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.98))
+
+    return fresh, batch
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_graphed_step_is_the_eager_step(p_drop, monkeypatch):
+    """Replay t of the captured step = eager train_step number t (with dropout: the eager step given seed + t): same
+    kernels on the same numbers, so losses and gradients agree to the run-to-run noise of the fp32 atomics that some
+    gradients are accumulated with (a wrong mask or a stale weight would show at 1e-2)."""
+    from carca_replication_amd import engine, ops
+
+    fresh, batch = _setup(p_drop)
+    base = 123456789
+    monkeypatch.setattr(ops, "new_dropout_seed", lambda: base)
+    model_g, opt_g = fresh()
+    step = engine.GraphedTrainStep(model_g, opt_g, batch)
+    model_e, opt_e = fresh()
+    graphed, eager = [], []
+    for t in range(1, 4):
+        graphed.append(float(step(batch)))
+        monkeypatch.setattr(ops, "new_dropout_seed", lambda t=t: base + t)
+        eager.append(float(engine.train_step(model_e, opt_e, batch)))
+        if t == 1:  # gradients of the first step (later ones see parameters whose gradient is pure round-off, the key
+            # biases, after Adam has turned that noise into +-lr steps)
+            for (n, a), (_, b) in zip(model_g.named_parameters(), model_e.named_parameters()):
+                assert torch.allclose(a.grad, b.grad, rtol=1e-3, atol=1e-6), n
+    assert int(step.replays.item()) == 3
+    assert graphed == pytest.approx(eager, rel=1e-4)
+    assert len(set(graphed)) == 3  # (the steps do move the loss: nothing is replaying a frozen state)
+
+
+def test_graphed_step_takes_new_batches():
+    """A different batch of the same shape goes through the graph's input tensors."""
+    from carca_replication_amd import engine
+
+    fresh, batch = _setup(0.0)
+    other = tuple(t.roll(1, 0) for t in batch)
+    model_g, opt_g = fresh()
+    step = engine.GraphedTrainStep(model_g, opt_g, batch)
+    got = [step(batch).clone(), step(other).clone()]
+    model_e, opt_e = fresh()
+    want = [engine.train_step(model_e, opt_e, batch).clone(), engine.train_step(model_e, opt_e, other).clone()]
+    assert [float(x) for x in got] == pytest.approx([float(x) for x in want], rel=1e-5)
+    assert abs(float(got[1]) - float(got[0])) > 1e-4
