@@ -782,7 +782,12 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream, co
   g.ncb = (desc->ncols_out + 32 * TN - 1) / (32 * TN);
   g.dbg = carca_debug_buffer();
   int grid = rb * g.ncb;
-  if (pas && grid < carca_num_cus()) {  // a CU is left over in the (single) round: it takes the gather
+  // A CU left over in the (single) round takes the gather -- if the tiles keep the others busy for longer than the lone
+  // workgroup needs: ~4.2 us per 32-k step here, ~12 ns per gathered row there (19 k rows: 0.2 ms against 0.54 ms at C2).
+  // With few attributes the launch would last as long as its passenger (n_attrs = 64: 0.55 ms per forward instead of
+  // 0.15), so the gather keeps its own 8 us launch then.
+  const double tiles_ns = 4200.0 * ((desc->K0 + 31) / 32 + (desc->K1 + 31) / 32);
+  if (pas && grid < carca_num_cus() && tiles_ns >= 2.0 * 12.0 * pas->total_rows) {
     g.has_pas = 1;
     g.pas = *pas;
     ++grid;

@@ -27,14 +27,17 @@ for name, c in CONFIGS.items():
     profile, target, _ = synth_eval_batch(c["B"], c["L"], c["N"], c["n_items"], c["n_attrs"], c["n_ctx"], seed=1)
     profile, target = tuple(t.cuda() for t in profile), tuple(t.cuda() for t in target)
     with torch.no_grad():
-        for _ in range(5):
-            model(profile=profile, targets=[target])
-        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(30):
+        while time.perf_counter() - t0 < 0.3:  # pre-heat as bench.py does: the clock needs tens of ms of load to settle
+            for _ in range(8):
+                model(profile=profile, targets=[target])
+            torch.cuda.synchronize()
+        steps = 100
+        t0 = time.perf_counter()
+        for _ in range(steps):
             model(profile=profile, targets=[target])
         torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 30
+    dt = (time.perf_counter() - t0) / steps
     F = c["n_attrs"] + c["n_ctx"]
     flop = c["B"] * ((c["L"] + c["N"]) * (2 * F * c["g"] + 2 * (c["d"] + c["g"]) * c["d"]) + c["nb"] * (10 * c["L"] * c["d"] ** 2 + 4 * c["L"] ** 2 * c["d"])
                      + 2 * c["N"] * c["d"] ** 2 + 4 * c["L"] * c["d"] ** 2 + 4 * c["N"] * c["L"] * c["d"] + 2 * c["N"] * c["d"])
