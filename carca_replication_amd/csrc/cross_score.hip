@@ -233,7 +233,8 @@ int launch_cross_nw(const float* p_raw, int ldp, const int32_t* p_ids, float* p_
 
 // Variant choice (tuning key 1: 1 = one 16-wave workgroup per user, 2 = always two, 3 = one 8-wave workgroup):
 //   2 B <= #CUs          two 16-wave workgroups per user, the target tiles halved between them (latency regime)
-//   B >= 2 #CUs and two workgroups' LDS fit a CU   one 8-wave workgroup per user, two resident per CU (throughput regime)
+//   B > #CUs and two workgroups' LDS fit a CU   one 8-wave workgroup per user, two resident per CU (more users than
+//                        CUs: 272..448 users take 47 us this way, 52-54 us as two rounds of 16-wave workgroups)
 //   otherwise            one 16-wave workgroup per user
 template <int DPI, int DHP, int NH>
 int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_normed, const GroupsDev& groups, int ldo,
@@ -243,7 +244,7 @@ int launch_cross(const float* p_raw, int ldp, const int32_t* p_ids, float* p_nor
   const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);
   const int nparts = (groups.tile_start[groups.n] > 1 && tune != 1 && tune != 3 && (tune == 2 || 2 * B <= num_cus)) ? 2 : 1;
   constexpr bool pair_fits = 2 * cross_lds_bytes<DPI, DHP, NH>() <= 160 * 1024;
-  if (pair_fits && nparts == 1 && (tune == 3 || (tune == 0 && B >= 2 * num_cus)))
+  if (pair_fits && nparts == 1 && (tune == 3 || (tune == 0 && B > num_cus)))
     return launch_cross_nw<DPI, DHP, NH, 8>(p_raw, ldp, p_ids, p_normed, groups, ldo, B, L, d, w, residual, training, sv,
                                             dc, site, nparts, stream);
   return launch_cross_nw<DPI, DHP, NH, 16>(p_raw, ldp, p_ids, p_normed, groups, ldo, B, L, d, w, residual, training, sv,

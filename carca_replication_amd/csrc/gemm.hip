@@ -858,11 +858,15 @@ static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice) {
     const int ncb = (desc->ncols_out + 95) / 96, ncb128 = (desc->ncols_out + 127) / 128;
     const long units_cu = (long)((rb384 * ncb + 255) / 256) * 36, units_3 = (long)((rb128 * ncb + 255) / 256) * 12;
     const long units_cu128 = (long)((rb384 * ncb128 + 255) / 256) * 48;  // 384 x 128 tiles: 48 32x32 tiles per block
-    if (variant == 3 || variant == 2 || (units_cu <= units_3 && units_cu <= units_cu128)) {
+    // (a unit of the one-block-per-CU kernel is ~1.2x cheaper than one of the 128 x 96 kernel -- 84 % against 68 % of the
+    // MFMA peak on the feature GEMM -- so a round-up that costs it a few per cent more units is still a win: n_attrs =
+    // 512, N = 1001, B = 512 gives 1008 against 996 units and ran 141.7 k users/s tiled between 148 k at B = 256 and
+    // 157 k at B = 1024, both one-block-per-CU)
+    if (variant == 3 || variant == 2 || (units_cu * 10 <= units_3 * 11 && units_cu <= units_cu128)) {
       *choice = variant == 3 ? GEMM_CU_STAMPS : GEMM_CU;
       return CARCA_OK;
     }
-    if (variant == 7 || (variant == 0 && units_cu128 < units_cu && units_cu128 <= units_3)) {  // (7: force 384 x 128)
+    if (variant == 7 || (variant == 0 && units_cu128 < units_cu && units_cu128 * 10 <= units_3 * 11)) {  // (7: force 384 x 128)
       *choice = GEMM_CU128;
       return CARCA_OK;
     }

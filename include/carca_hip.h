@@ -46,7 +46,7 @@ int carca_abi_version(void);
  *          7 force the one-block-per-CU row GEMM with 384 x 128 tiles, 8 never let the item-row gather ride in the
  *          feature GEMM's launch
  *   key 1  attention kernels: 1 one workgroup per user, 2 always two, 3 one 8-wave workgroup per user (the variant
- *          for batches of >= 2 users per CU, two workgroups resident per CU)
+ *          for batches of more users than CUs, two workgroups resident per CU)
  *   key 2  weight gradient: row-split slot target      key 4  minimum 32-row chunks per split
  *   key 3  weight gradient: plain stores instead of atomics (timing diagnostic, wrong results)
  *   key 5  grouped weight gradient: row-split slot target per product */

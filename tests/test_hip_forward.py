@@ -325,7 +325,7 @@ def test_two_workgroups_per_user_is_bitwise_the_same():
 
 
 def test_big_batch_scoring_variant_is_bitwise_the_same():
-    """B >= 2 x #CUs takes the scoring kernel's 8-wave workgroups (two resident per CU) by itself: same bits as the 16-wave
+    """B > #CUs takes the scoring kernel's 8-wave workgroups (two resident per CU) by itself: same bits as the 16-wave
     ones (tuning key 1 = 1), and the oracle's numbers."""
     from carca_replication_amd import _lib
 

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from carca_replication_amd import ops  # noqa: E402
 from tests.model_util import build_model  # noqa: E402
 
-L, N, d, g, H = 50, 101, 90, 450, 3
+L, N, d, g, H = 50, int(os.environ.get("N", "101")), 90, 450, 3
 PEAK = 157.3e12
 torch.manual_seed(0)
 model = build_model(dict(d=d, H=H, n_blocks=2), 500, g, 6, 64, L).eval().cuda()
