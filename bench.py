@@ -131,7 +131,9 @@ def measure_train(c, model, rank, world, device, steps, fold=False, graphed=Fals
     model.fold_embedding(fold, training=fold)
     from carca_replication_amd.optim import Adam
 
-    opt = Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))  # training.py:174's update, one launch for all tensors
+    # training.py:174's update, one launch for all tensors (lr 1e-5: with the synthetic U[0,1) attributes one 1e-3 step
+    # saturates the sigmoid and `last_loss` reads -log(1e-4) from then on; the step's cost does not depend on lr)
+    opt = Adam(model.parameters(), lr=1e-5, betas=(0.9, 0.98))
     if graphed:
         captured = engine.GraphedTrainStep(model, opt, batch)
         run = lambda: captured(batch)  # noqa: E731

@@ -15,6 +15,8 @@ from carca_replication_amd.optim import Adam  # noqa: E402
 from carca_replication_amd.synth import eval_batch  # noqa: E402
 
 c = dict(bench.C2)
+c["n_attrs"] = int(os.environ.get("ATTRS", c["n_attrs"]))  # (ATTRS=512: a step whose kernels take ~0.6 ms)
+c["B"] = int(os.environ.get("B", c["B"]))
 dev = torch.device("cuda")
 fold = bool(int(os.environ.get("FOLD", "0")))
 L = c["L"]
@@ -32,7 +34,7 @@ def fresh():
     m = bench.build_model(c, dev)
     m.train()
     m.fold_embedding(fold, training=fold)
-    return m, Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    return m, Adam(m.parameters(), lr=float(os.environ.get("LR", "1e-5")), betas=(0.9, 0.98))
 
 
 STEPS = 30
