@@ -159,7 +159,7 @@ def measure_train(c, model, rank, world, device, steps, fold=False, graphed=Fals
                  "product backward: ~5x fewer executed flops there, same gradients to ~1e-6)")
     if graphed:
         what += ("; forward + backward replayed from ONE hipGraph (engine.GraphedTrainStep), the optimizer's launch issued "
-                 "behind it: this path has 1.1 ms of kernels behind 1.5-2.3 ms of host-side launch work when issued eagerly")
+                 "behind it: ~40 launches cost 1.3-2.3 ms of host time per step when issued eagerly")
     return {"users_per_s": world * c["B"] * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "what": what,
             "last_loss": float(loss)}
 
@@ -332,9 +332,11 @@ def main():
                      "what": "CARCA.fold_embedding(True): e = z W_jz^T + [a;c] (W_jq W_f)^T + const, one F->d GEMM instead of "
                              "F->g->d; executed flops per user 5x lower in the embedding, algorithmic flops unchanged"}
 
-    train_info = train_fold_info = train_fold_graph_info = None
+    train_info = train_graph_info = train_fold_info = train_fold_graph_info = None
     if args.train_steps > 0:
         train_info = measure_train(c, model, rank, world, device, args.train_steps)
+        if world == 1:  # (the same step replayed from a hipGraph: wins where the host, not the GPU, paces the eager loop)
+            train_graph_info = measure_train(c, model, rank, world, device, args.train_steps, graphed=True)
         if not args.no_fold:
             train_fold_info = measure_train(c, model, rank, world, device, args.train_steps, fold=True)
             if world == 1:
@@ -390,6 +392,8 @@ def main():
         }
         if train_info is not None:
             out["train"] = train_info
+        if train_graph_info is not None:
+            out["train_graphed"] = train_graph_info
         if train_fold_info is not None:
             out["train_folded_embedding"] = train_fold_info
         if train_fold_graph_info is not None:
