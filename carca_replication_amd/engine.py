@@ -69,7 +69,9 @@ class GraphedTrainStep:
         step = GraphedTrainStep(model, optim, example_batch)   # shapes and dtypes are fixed from here on
         for batch in loader: loss = step(batch)                  # device loss, overwritten by the next call
 
-    The batch is copied into the graph's own input tensors (skipped for tensors that already are those, see `.inputs`).
+    The batch is copied into the graph's own input tensors `.inputs`; a loader that fills those tensors itself and passes
+    them back skips the copy (dense C2 batches are 315 MB: ~0.1 ms of HBM time per step; ids-only batches over a registered
+    attribute table are a few hundred KB).
     Single-process steps only (a sharded step has its gradient exchange between backward and optimizer: use train_step).
     Dropout: the seeds are launch arguments, which a replay repeats; the graph's first node increments a device counter
     that every dropout kernel adds to its seed (ops.set_dropout_seed_offset), so replay t draws the masks an eager step
