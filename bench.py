@@ -349,7 +349,7 @@ def main():
     ca_avg = sum(ca_ms) / len(ca_ms)
 
     traffic = None  # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/README.md)
-    tpath = os.path.join(ROOT, "profiles", "r01_k_feat_gemm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_l_feat_gemm_traffic.json")
     if c["B"] == C2["B"] and os.path.exists(tpath):
         with open(tpath) as fh:
             traffic = json.load(fh)["hbm_bytes_per_launch"]
@@ -377,7 +377,7 @@ def main():
                          "bound": "mfma", "achieved": feat_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
-                                         "WRITE_SIZE, separate passes, profiles/r01_k_feat_gemm_traffic.json; algorithmic "
+                                         "WRITE_SIZE, separate passes, profiles/r01_l_feat_gemm_traffic.json; algorithmic "
                                          "bytes 359 MB",
                          "avg_ms": feat_avg, "min_ms": feat_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["feat"] / 1e9},
             "roofline_cross_score": {"kernel": "cross_score_kernel_w16<96,32,3,16> (final norm + CrossAttentionBlock)",
