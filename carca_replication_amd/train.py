@@ -54,7 +54,9 @@ def evaluate(model: Model, loader: DataLoader, device: str, k: int) -> Tuple[flo
 
 def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_loader: DataLoader, device: str,
           optim: Optimizer, epochs: int, top_k: int = 10, verbose: int = 1, early_stop: int = 10,
-          datadir: str = "model", scheduler: Union[_LRScheduler, None] = None) -> Model:
+          datadir: str = "model", scheduler: Union[_LRScheduler, None] = None, graphed: bool = False) -> Model:
+    """src/train.py:56-152.  graphed (extension, off by default): batches of the first batch's shape replay their forward +
+    backward from one hipGraph (engine.GraphedTrainStep); any other shape (a short last batch) takes the eager step."""
     os.makedirs(datadir, exist_ok=True)
     model = model.train().to(device)
     best, stale = 0.0, 0
@@ -62,10 +64,19 @@ def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_l
     log = open(f"./{datadir}/{t0.year}-{t0.month}-{t0.day}T{t0.hour}-{t0.minute}-{t0.second}.csv", "a")
     now = lambda: datetime.now().strftime("%H:%M:%S")  # noqa: E731
     epoch = 0
+    captured = None
     for epoch in range(1, epochs + 1):
         loss_sum = torch.zeros((), dtype=torch.float32, device=device)
         for i, batch in enumerate(train_loader, start=1):
-            loss_sum += engine.train_step(model, optim, to(*batch, device=device))
+            dev_batch = to(*batch, device=device)
+            if graphed:
+                sig = tuple((tuple(t.shape), t.dtype) for t in dev_batch)
+                if captured is None:
+                    captured = (sig, engine.GraphedTrainStep(model, optim, dev_batch))
+            if graphed and captured[0] == sig:
+                loss_sum += captured[1](dev_batch)
+            else:
+                loss_sum += engine.train_step(model, optim, dev_batch)
             if verbose == 2:  # the reference prints a running mean per batch; that costs a sync per batch here too
                 print(f"{now()} - Batch {i:03d}: Loss = {(float(loss_sum) / i):.4f}")
         mean_loss = float(loss_sum) / len(train_loader)

@@ -29,8 +29,10 @@ def _write_dataset(tmp, n_users=40, n_items=60, n_attrs=12, n_ctx=3, seed=0):
         fh.write("\n".join(lines) + "\n")
 
 
-@pytest.mark.parametrize("decoder", ["ca", "dot"])  # --decoder ca, and the CLI default --decoder dot (training.py:60)
-def test_training_script_wiring_end_to_end(tmp_path, monkeypatch, decoder):
+# --decoder ca, and the CLI default --decoder dot (training.py:60); graphed: full batches replayed from a hipGraph, the
+# short last batch of every epoch on the eager step
+@pytest.mark.parametrize("decoder,graphed", [("ca", False), ("dot", False), ("ca", True), ("dot", True)])
+def test_training_script_wiring_end_to_end(tmp_path, monkeypatch, decoder, graphed):
     import torch.nn as nn
     from torch.optim import Adam
     from torch.utils.data import DataLoader
@@ -60,7 +62,7 @@ def test_training_script_wiring_end_to_end(tmp_path, monkeypatch, decoder):
     optim = Adam(model.parameters(), lr=1e-3, weight_decay=0.0, betas=(0.9, 0.98))
     hr0, ndcg0, loss0 = evaluate(model, val_loader, "cuda", 10)
     model = train(model=model, train_loader=train_loader, val_loader=val_loader, test_loader=test_loader, device="cuda",
-                  optim=optim, epochs=3, early_stop=20, datadir="results_run", verbose=1)
+                  optim=optim, epochs=3, early_stop=20, datadir="results_run", verbose=1, **({"graphed": True} if graphed else {}))
     hr1, ndcg1, loss1 = evaluate(model, val_loader, "cuda", 10)
     assert 0.0 <= hr1 <= 1.0 and 0.0 <= ndcg1 <= 1.0 and np.isfinite(loss1)
     logs = [f for f in os.listdir("results_run") if f.endswith(".csv")]
@@ -68,6 +70,8 @@ def test_training_script_wiring_end_to_end(tmp_path, monkeypatch, decoder):
     rows = [ln.strip().split(";") for ln in open(os.path.join("results_run", logs[0]))]
     assert [r[2] for r in rows].count("train") == 3 and [r[2] for r in rows].count("val") == 3 and rows[-1][2] == "test"
     assert any(f.endswith(".pth") for f in os.listdir("results_run"))
+    train_losses = [float(r[3]) for r in rows if r[2] == "train"]
+    assert train_losses[-1] < train_losses[0]  # (the steps do train: eager and replayed alike)
 
 
 def test_compute_hr_ndcg_match_reference_fixture():
