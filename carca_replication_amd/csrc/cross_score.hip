@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_score_kernel_w16(const float
       const bool isv = job >= nk;
       const int jj = isv ? job - nk : job;
       const int st = jj % LT;
-      const int ft = (jj / LT + (int)(blockIdx.x >> 3)) % G::NF;  // EXPERIMENT: CUs of an XCD walk the weights staggered
+      const int ft = jj / LT;
       if (!isv)
         proj_tile_feat_major<DPI>(w.wk, w.bk, Ps, G::SI, Ks, G::SO, ft, st, lane,
                                   (saver && sv.kh) ? sv.kh + ubase * G::DPO : nullptr, G::DPO, L);
