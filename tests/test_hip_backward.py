@@ -191,3 +191,40 @@ def test_folded_training_path_matches_reference_gradients(name):
     model.fold_embedding(False)
     y1, _ = _step(model, fx)
     assert torch.equal(y1, y0)  # and switching it off restores the plain path exactly
+
+
+def test_c2_full_batch_gradients_are_the_weighted_sum_of_its_halves():
+    """The bench's train workload at full size (C2: B = 128, n_attrs = 4096: persistent one-block-per-CU weight-gradient
+    kernel, grouped small products) through a size-independent property: the loss is a mean over unmasked targets
+    (carca.py:443), so loss and every gradient of a batch are the mask-count-weighted means of those of its two halves
+    -- which run the B = 64 kernel choices (two workgroups per user, other row splits)."""
+    from carca_replication_amd import engine
+    from carca_replication_amd.synth import eval_batch
+    from tests.model_util import build_model
+
+    B, L, d, g, H, n_items, n_attrs, n_ctx = 128, 50, 90, 450, 3, 12102, 4096, 6
+    torch.manual_seed(0)
+    model = build_model(dict(d=d, H=H, n_blocks=2, encoding="learnable"), n_items, g, n_ctx, n_attrs, L).cuda().train()
+    profile, pos, _ = eval_batch(B, L, L, n_items, n_attrs, n_ctx, seed=77)
+    px = profile[0]
+    o_x = torch.cat([pos[0] * (px != 0), pos[0].flip(1) * (px != 0)], dim=1)
+    o_a = torch.cat([pos[1], pos[1].flip(1)], dim=1)
+    o_c = torch.cat([pos[2], pos[2]], dim=1)
+    y_true = torch.cat([(px != 0).int(), torch.zeros_like(px)], dim=1)
+    batch = tuple(t.cuda() for t in (profile[0], profile[1], profile[2], o_x, o_a, o_c, y_true))
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+
+    def run(lo, hi):
+        sub = tuple(t[lo:hi].contiguous() for t in batch)
+        loss = engine._forward_backward(model, opt, sub, False)
+        n = float((sub[3] != 0).sum())
+        return float(loss), n, {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    lf, nf, gf = run(0, B)
+    l1, n1, g1 = run(0, B // 2)
+    l2, n2, g2 = run(B // 2, B)
+    assert nf == n1 + n2
+    assert lf == pytest.approx((n1 * l1 + n2 * l2) / nf, rel=1e-5)
+    for k in gf:
+        want = (n1 * g1[k] + n2 * g2[k]) / nf
+        assert float((gf[k] - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-7, k

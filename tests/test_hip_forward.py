@@ -346,3 +346,27 @@ def test_big_batch_scoring_variant_is_bitwise_the_same():
     assert torch.equal(outs[0], outs[1])
     want = O.carca_forward(P, cfg, profile, [target], training=False)
     assert float((outs[0] - want).abs().max()) < Y_ATOL
+
+
+def test_c2_full_batch_is_batch_split_invariant():
+    """The bench's exact workload (C2: B = 128 users, n_items = 12102, n_attrs = 4096; one-block-per-CU feature GEMM with
+    the gather riding along, two workgroups per user) through a size-independent property: a user's scores do not depend
+    on who else is in the batch.  The same users in eight batches of 16 take different kernels (tiled feature GEMM, its
+    own gather launch) whose B = 16 results are pinned against the oracle above; the first eight users are checked
+    against the oracle here as well."""
+    cfg = O.CarcaConfig(d=90, H=3, n_blocks=2)
+    n_items, n_attrs, n_ctx, g, L, N, B = 12102, 4096, 6, 450, 50, 101, 128
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    profile, target, _ = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=1234)
+    model = model_from_params(P, cfg).eval()
+    p_dev, t_dev = dev(profile), dev(target)
+    with torch.no_grad():
+        full = model(profile=p_dev, targets=[t_dev]).cpu()
+        parts = [model(profile=tuple(t[i:i + 16] for t in p_dev), targets=[tuple(t[i:i + 16] for t in t_dev)]).cpu()
+                 for i in range(0, B, 16)]
+    split = torch.cat(parts, dim=0)
+    assert full.shape == split.shape == (B, N)
+    assert float((full - split).abs().max()) < 2e-5
+    want = O.carca_forward(P, cfg, tuple(t[:8] for t in profile), [tuple(t[:8] for t in target)], training=False)
+    assert float((full[:8] - want).abs().max()) < Y_ATOL
+    assert torch.equal(O.positive_rank(full[:8]), O.positive_rank(want))
