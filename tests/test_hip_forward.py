@@ -348,14 +348,16 @@ def test_big_batch_scoring_variant_is_bitwise_the_same():
     assert float((outs[0] - want).abs().max()) < Y_ATOL
 
 
-def test_c2_full_batch_is_batch_split_invariant():
-    """The bench's exact workload (C2: B = 128 users, n_items = 12102, n_attrs = 4096; one-block-per-CU feature GEMM with
+@pytest.mark.parametrize("d,H,g", [(90, 3, 450), (128, 4, 640)], ids=["C2", "C4-dims"])
+def test_c2_full_batch_is_batch_split_invariant(d, H, g):
+    """(C4-dims: d = 128, g = 640, H = 4 at the same batch -- the 384 x 128 tiles of the one-block-per-CU kernel.)
+    The bench's exact workload (C2: B = 128 users, n_items = 12102, n_attrs = 4096; one-block-per-CU feature GEMM with
     the gather riding along, two workgroups per user) through a size-independent property: a user's scores do not depend
     on who else is in the batch.  The same users in eight batches of 16 take different kernels (tiled feature GEMM, its
     own gather launch) whose B = 16 results are pinned against the oracle above; the first eight users are checked
     against the oracle here as well."""
-    cfg = O.CarcaConfig(d=90, H=3, n_blocks=2)
-    n_items, n_attrs, n_ctx, g, L, N, B = 12102, 4096, 6, 450, 50, 101, 128
+    cfg = O.CarcaConfig(d=d, H=H, n_blocks=2)
+    n_items, n_attrs, n_ctx, L, N, B = 12102, 4096, 6, 50, 101, 128
     P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
     profile, target, _ = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=1234)
     model = model_from_params(P, cfg).eval()
