@@ -61,8 +61,13 @@ def is_built() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into one shared library (cross-compiles without a GPU)."""
-    with _lock:
-        if not force and is_built():
+    import fcntl
+
+    # one builder at a time ACROSS processes too (torchrun ranks, pytest workers on a fresh checkout): the objects go to
+    # fixed paths under build/, and a rank that links another rank's half-written object gets a corrupt library
+    with _lock, open(os.path.join(_HERE, ".build.lock"), "w") as lockf:
+        fcntl.flock(lockf, fcntl.LOCK_EX)
+        if not force and is_built():  # (re-checked under the lock: another process may just have finished)
             return LIB_PATH
         hipcc = _hipcc()
         if hipcc is None:
@@ -102,7 +107,8 @@ _fp = C.c_void_p  # device pointers travel as integers
 class PackDesc(C.Structure):
     _fields_ = [("src", _fp), ("dst", _fp), ("rows", C.c_int32), ("cols", C.c_int32), ("src_ld", C.c_int32),
                 ("dst_rows", C.c_int32), ("dst_cols", C.c_int32), ("row_dh", C.c_int32), ("row_dhp", C.c_int32),
-                ("col_dh", C.c_int32), ("col_dhp", C.c_int32), ("transposed", C.c_int32), ("frag16", C.c_int32)]
+                ("col_dh", C.c_int32), ("col_dhp", C.c_int32), ("transposed", C.c_int32), ("frag16", C.c_int32),
+                ("fold_vec", _fp), ("fold_H", C.c_int32)]
 
 
 class RowSeg(C.Structure):
@@ -196,7 +202,7 @@ class SaWeights(C.Structure):
 
 
 class CaWeights(C.Structure):
-    _fields_ = [(n, _fp) for n in ("ln_w", "ln_b", "wq", "wk", "wv", "bq", "bk", "bv", "ffn_w_pad", "ffn_w", "ffn_b")]
+    _fields_ = [(n, _fp) for n in ("ln_w", "ln_b", "wq", "wk", "wv", "bq", "bk", "bv", "ffn_w_pad", "ffn_w", "ffn_b", "wu", "cu")]
 
 
 class TargetGroup(C.Structure):

@@ -51,7 +51,7 @@ extern "C" int carca_padded_dims(int d, int H, int* dpi, int* dhp, int* dpo) {
 }
 
 namespace {
-constexpr int PACK_CHUNK = 64;  // descriptors per launch (3.6 KB of kernel arguments): a model's forward packs fit one
+constexpr int PACK_CHUNK = 48;  // descriptors per launch (3.5 KB of kernel arguments): a model's forward packs fit one
 struct PackArgs {
   CarcaPackDesc d[PACK_CHUNK];
 };
@@ -70,7 +70,12 @@ __global__ void pack_kernel(const PackArgs pa) {
     const int r = ds.row_dh > 0 ? unpad_feature(rp, ds.row_dh, ds.row_dhp) : rp;
     const int c = ds.col_dh > 0 ? unpad_feature(cp, ds.col_dh, ds.col_dhp) : cp;
     float v = 0.f;
-    if (r >= 0 && r < ds.rows && c >= 0 && c < ds.cols)
+    if (ds.fold_vec) {  // logical source [fold_H, cols]: rows of src contracted per head with fold_vec
+      if (r >= 0 && r < ds.fold_H && c >= 0 && c < ds.cols) {
+        const int dh = ds.rows / ds.fold_H;
+        for (int j = 0; j < dh; ++j) v += ds.fold_vec[r * dh + j] * ds.src[(size_t)(r * dh + j) * ds.src_ld + c];
+      }
+    } else if (r >= 0 && r < ds.rows && c >= 0 && c < ds.cols)
       v = ds.transposed ? ds.src[(size_t)c * ds.src_ld + r] : ds.src[(size_t)r * ds.src_ld + c];
     ds.dst[i] = v;
   }
@@ -98,7 +103,7 @@ extern "C" int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumul
     const CarcaPackDesc& d = descs[i];
     CARCA_CHECK_ARG(d.src && d.dst && d.rows >= 1 && d.cols >= 1 && d.dst_rows >= 1 && d.dst_cols >= 1,
                     "unpack_grads: descriptor %d malformed", i);
-    CARCA_CHECK_ARG(!d.frag16, "unpack_grads: descriptor %d is in fragment order (forward-only layout)", i);
+    CARCA_CHECK_ARG(!d.frag16 && !d.fold_vec, "unpack_grads: descriptor %d is a forward-only layout (fragment order / fold)", i);
   }
   for (int base = 0; base < n; base += PACK_CHUNK) {
     PackArgs pa{};
@@ -123,6 +128,9 @@ extern "C" int carca_pack_weights(const CarcaPackDesc* descs, int n, void* strea
                     "pack_weights: descriptor %d has inconsistent head padding", i);
     CARCA_CHECK_ARG(!d.frag16 || (d.dst_rows % 16 == 0 && d.dst_cols % 16 == 0),
                     "pack_weights: descriptor %d: fragment order needs dst dims that are multiples of 16", i);
+    CARCA_CHECK_ARG(!d.fold_vec || (d.fold_H >= 1 && d.rows % d.fold_H == 0 && d.row_dh == 0 && !d.transposed &&
+                                    d.dst_rows >= d.fold_H),
+                    "pack_weights: descriptor %d: malformed head fold", i);
   }
   for (int base = 0; base < n; base += PACK_CHUNK) {
     PackArgs pa{};

@@ -33,6 +33,13 @@ __device__ __forceinline__ f32x4 gload4(const float* base, int elem_off) {
   f32x4 f = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
   return f;
 }
+// the same load with the wave-uniform part of the offset kept apart (scalar offset operand of the instruction): one
+// lane-offset register serves every load of a fragment sweep instead of one pre-added register per load
+__device__ __forceinline__ f32x4 gload4s(const float* base, int lane_elem_off, int uniform_elem_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(carca_rsrc(base), lane_elem_off * 4, uniform_elem_off * 4, 0);
+  f32x4 f = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+  return f;
+}
 __device__ __forceinline__ float gload1(const float* base, int elem_off) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(carca_rsrc(base), elem_off * 4, 0, 0));
 }
@@ -85,8 +92,17 @@ __device__ __forceinline__ float quad4_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float wave_sum(float v) { return quad4_sum(row16_sum(v)); }
+// all-reduce inside each 32-lane half of the wave
+__device__ __forceinline__ float half32_sum(float v) {
+  v = row16_sum(v);
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float wave_max(float v) { return quad4_max(row16_max(v)); }
 
+__device__ __forceinline__ int gload1i(const int32_t* base, int elem_off) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(carca_rsrc(base), elem_off * 4, 0, 0);
+}
 __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // head-padded feature index -> original feature index, or -1 for a pad slot

@@ -10,6 +10,7 @@
 //   masking  eval: a target attends every real profile slot; train: tril(diagonal=-1), i.e. target
 //            slot i attends real profile slots j < i, so the first slot attends nothing and scores
 //            sigmoid(w.o + b) (carca.py:339).  Pad targets (id 0) attend nothing.
+#include <hip/hip_ext.h>
 #include "attn_common.h"
 #include "../../include/carca_hip.h"
 
@@ -202,6 +203,524 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_score_kernel_w16(const float
 #undef CA_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Eval-mode kernel (model.eval(): nothing saved, no dropout, every target attends the whole profile).  Same arithmetic
+// contract as the kernel above, restructured:
+//   * decoder.ffn is FOLDED into the value projection.  The block's output is the scalar w . (P V + o) (carca.py:340-345),
+//     and w_h . (P_h V_h) = P_h u_h with u_h[key] = p[key] . wu[h] + cu[h] (wu, cu: CarcaCaWeights, built at pack
+//     time).  V is never formed: phase B projects K (6 feature tiles) and u (ONE tile) instead of K and V (12 tiles),
+//     and a (target tile, head) job ends in a per-lane dot of its softmax numerators with u instead of 32 PV MFMAs;
+//     the softmax normaliser is applied to that one number instead of to 16 probabilities per lane.
+//   * LEADING pad slots are dropped: profiles are left-padded (data.py:113,173), a pad key's weight is an exact 0
+//     (carca.py:251-256), so keys are re-based at the first real slot and only ceil(#slots from there / 16) key tiles
+//     are projected and scored.  Pads inside the kept range stay masked as before.
+//   * masks are ADDED: the score accumulators start from 0 / -1e30 per key (an LDS vector), so the exp2 of a masked
+//     score is an exact 0 without a select per score; rows with no allowed key are zeroed by one select.
+//   * the first job's target rows are requested before phase A, its W_Q fragments before the barrier ahead of phase C.
+struct FoldArgs {
+  const float* p_raw;
+  const int32_t* p_ids;
+  float* p_normed;
+  CarcaTargetGroup g[CARCA_MAX_GROUPS];
+  int tile_start[CARCA_MAX_GROUPS + 1];
+  int ngroups, ldp, ldo, L, d, residual, nparts;
+  const float *ln_w, *ln_b, *wq, *bq, *wk, *bk, *wu, *cu, *ffn_w, *ffn_b;
+  float qscale;  // log2(e) / sqrt(dh): scores leave the Q projection in the exp2 domain
+  int dbg;       // timing experiments (tuning key 5): bit 0 no phase B prefetch, 1 no W_Q DMA, 2 no tile DMA, 3 no LayerNorm
+  unsigned long long* stamps;
+};
+#define FOLD_NEG (-1.0e30f)
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global offsets into 1 KB of LDS at lds_dst + 16 * lane (no registers)
+__device__ __forceinline__ void dma16(const float* base, int lane_elem_off, int uniform_elem_off, float* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(carca_rsrc(base), (__attribute__((address_space(3))) void*)lds_dst, 16,
+                                           lane_elem_off * 4, uniform_elem_off * 4, 0, 0);
+}
+
+// Phase B job = one feature tile x a PAIR of 16-slot tiles: the weight fragments are fetched once (by the caller, so
+// that the first job's can be requested before phase A) and feed two independent accumulator chains.
+//   K:  Ks[16 st + ln][16 ft + 4 mq + r] = sum_k W_K[16 ft + 4 mq + r][k] X[16 st + ln][k] + b_K    (A = W_K, Bt = rows)
+//   u:  Ut[h = ln][16 st + 4 mq + r]     = sum_k X[16 st + 4 mq + r][k] wu[h][k] + cu[h]            (A = rows, Bt = wu)
+template <int DPI>
+struct FoldBW {
+  f32x4 wf[DPI / 16];
+  f32x4 bk4;  // K: b_K[16 ft + 4 mq ..]
+  float cu1;  // u: cu[ln]
+  // (both bias forms are fetched and the choice is made where the job runs: a load under a branch, or a select on a
+  // loaded value, makes hipcc wait for that load -- and for every load issued before it -- right there)
+};
+template <int DPI>
+__device__ __forceinline__ void fold_b_load(FoldBW<DPI>& w, const float* __restrict__ wk, const float* __restrict__ bk,
+                                            const float* __restrict__ wu, const float* __restrict__ cu, int ft, int nf,
+                                            int lane) {
+  const bool isu = ft == nf;  // (uniform)
+  const float* wp = isu ? wu : wk;
+  const int t = isu ? 0 : ft;
+#pragma unroll
+  for (int kg = 0; kg < DPI / 16; ++kg) w.wf[kg] = gload4s(wp, 4 * lane, 256 * (t * (DPI / 16) + kg));
+  w.cu1 = gload1(cu, lane & 15);
+  w.bk4 = gload4s(bk, 4 * (lane >> 4), 16 * t);
+}
+template <int DPI>
+__device__ __forceinline__ void fold_b_job(const FoldBW<DPI>& w, const float* xs, int si, float* Ks, int so, float* Ut,
+                                           int ft, int nf, int st0, int lane, int nh) {
+  const int ln = lane & 15, mq = lane >> 4;
+  const float* x0 = xs + (16 * st0 + ln) * si + 4 * mq;
+  const float* x1 = x0 + 16 * si;  // (the pair's second tile, computed and stored even beyond the profile: its rows are
+                                   // zeros there, and phase C scores key tiles in pairs too, masked)
+  f32x4 acc0, acc1;
+  if (ft == nf) {
+    acc0 = acc1 = f32x4{w.cu1, w.cu1, w.cu1, w.cu1};
+#pragma unroll
+    for (int kg = 0; kg < DPI / 16; ++kg) {
+      const f32x4 a0 = lds4(x0 + 16 * kg), a1 = lds4(x1 + 16 * kg);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc0 = mfma16(a0[s], w.wf[kg][s], acc0);
+        acc1 = mfma16(a1[s], w.wf[kg][s], acc1);
+      }
+    }
+    if (ln < nh) {
+      *reinterpret_cast<f32x4*>(Ut + ln * ATT_SK + 16 * st0 + 4 * mq) = acc0;
+      *reinterpret_cast<f32x4*>(Ut + ln * ATT_SK + 16 * st0 + 16 + 4 * mq) = acc1;
+    }
+  } else {
+    acc0 = acc1 = w.bk4;
+#pragma unroll
+    for (int kg = 0; kg < DPI / 16; ++kg) {
+      const f32x4 b0 = lds4(x0 + 16 * kg), b1 = lds4(x1 + 16 * kg);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc0 = mfma16(w.wf[kg][s], b0[s], acc0);
+        acc1 = mfma16(w.wf[kg][s], b1[s], acc1);
+      }
+    }
+    *reinterpret_cast<f32x4*>(Ks + (16 * st0 + ln) * so + 16 * ft + 4 * mq) = acc0;
+    *reinterpret_cast<f32x4*>(Ks + (16 * st0 + 16 + ln) * so + 16 * ft + 4 * mq) = acc1;
+  }
+}
+
+#define FOLD_TPR_S 8  // target tiles staged in LDS per round (STAGE)
+
+// STAGE (the 16-wave workgroups, alone on their CU): W_Q (d <= 96) and the round's target tiles are brought into LDS by
+// LDS-DMA requested in the kernel's first instructions -- each byte once per workgroup instead of once per (tile, head)
+// job -- and phase C touches global memory only for the targets' ids.  Without it (8-wave workgroups, two or more per
+// CU) jobs fetch their operands themselves and the co-resident workgroup covers the latency.
+template <int DPI, int DHP, int NH, int NW, bool STAGE>
+__global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a) {
+#define CF_STAMP(i)                                                                                  \
+  do {                                                                                               \
+    if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+  CF_STAMP(0);
+  using G = AttGeom<DPI, DHP, NH>;
+  constexpr bool STAGE_W = STAGE && DPI <= 96;
+  constexpr int TPR = STAGE ? FOLD_TPR_S : CROSS_TPR;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ps = lds;                    // [64][SI]  final-normed profile, re-based at the first real slot
+  float* Ks = Ps + ATT_LMAX * G::SI;  // [64][SO]
+  float* Ut = Ks + ATT_LMAX * G::SO;  // [NH][ATT_SK]  u^T
+  float* Km = Ut + NH * ATT_SK;       // [64] additive key mask: 0 real key, FOLD_NEG pad / beyond the profile
+  float* Yp = Km + ATT_LMAX;          // [CROSS_TPR][NH][16] per-head partial logits
+  float* Ot = Yp + CROSS_TPR * NH * 16;               // STAGE: [TPR][NKG][64 lanes x 4] target tiles, fragment order
+  float* Bq = Ot + FOLD_TPR_S * G::NKG * 256;         // STAGE: b_Q [DPO], then decoder.ffn.weight [DPI]
+  float* Fw = Bq + 256;
+  int* Ids = reinterpret_cast<int*>(Fw + 256);        // STAGE: [TPR * 16] target ids of the round
+  float* Wq = Fw + 256 + FOLD_TPR_S * 16;             // STAGE_W: W_Q, fragment order as packed
+
+  const int L = a.L, d = a.d, nparts = a.nparts;
+  const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, mq = lane >> 4;
+  const size_t ubase = (size_t)u * L;
+
+  // the profile's ids first: everything requested after them returns behind them (loads complete in order)
+  // (a buffer load like the ones that follow: hipcc counts on in-order return only among loads of one kind, and waited
+  // for all but three of the fifteen requests behind a global_load here; unconditional: see FoldBW)
+  const int32_t my_id = gload1i(a.p_ids + ubase, lane < L ? lane : L - 1);
+
+  // ---- A0: all requests of the prologue -------------------------------------------------------------------------
+  // Rows travel two per wave instruction: lane (half = row of the pair, c4 = 16-byte column group) loads / normalises /
+  // stores four contiguous features -- a third of the instructions of a row per wave with a value per lane.
+  constexpr int PPW = (ATT_LMAX / 2) / NW;  // row pairs per wave
+  const int half = lane >> 5, c4 = lane & 31;
+  const bool col_ok = 4 * c4 < DPI;
+  const float* p_user = a.p_raw + ubase * a.ldp;  // (per-user bases: lane offsets stay small whatever B is)
+  f32x4 rv[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int r = 2 * (wave + NW * j) + half;
+    rv[j] = gload4(p_user, (r < L ? r : 0) * a.ldp + (col_ok ? 4 * c4 : 0));
+  }
+  // (no request of the prologue sits under a branch: behind one, hipcc no longer knows how many loads are in flight and
+  // turns the counted wait for the FIRST of them into a wait for nearly all; without a final norm b_Q stands in)
+  const f32x4 lnw = gload4(a.ln_w ? a.ln_w : a.bq, col_ok ? 4 * c4 : 0);
+  const f32x4 lnb = gload4(a.ln_w ? a.ln_b : a.bq, col_ok ? 4 * c4 : 0);
+  // phase B jobs: job j = (feature tile j % (NF + 1) [NF = the u tile], slot-tile pair j / (NF + 1)); this wave's first
+  // one gets its weight fragments now
+  constexpr int NFB = G::NF + 1;
+  FoldBW<DPI> bw;
+  fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, wave % NFB, G::NF, lane);
+
+  // tiles of this workgroup
+  const int all_tiles = a.tile_start[a.ngroups];
+  const int per_part = (all_tiles + nparts - 1) / nparts;
+  const int t_lo = part * per_part, t_hi = min(all_tiles, t_lo + per_part);
+  struct Job {
+    int tl, h, gi, qt, n;
+    int lrow;            // the lane's target row inside the user's block of the group (clamped into it)
+    const float* o;      // the user's block of embedded targets of that group
+    const int32_t* ids;
+    bool in_range;
+  };
+  // Group of a PER-LANE tile by selects over the (at most three) groups: indexing a.g[] with a per-lane index makes the
+  // compiler fetch the kernel arguments through vector memory, dependent load after dependent load.
+  struct Grp {
+    int N, ts;
+    const float* o;
+    const int32_t* ids;
+    float* y;
+  };
+  auto group_of = [&](int tile) {
+    Grp g{a.g[0].N, 0, a.g[0].o, a.g[0].ids, a.g[0].y};
+#pragma unroll
+    for (int i = 1; i < CARCA_MAX_GROUPS; ++i) {
+      const bool in = i < a.ngroups && tile >= a.tile_start[i];
+      g.N = in ? a.g[i].N : g.N;
+      g.ts = in ? a.tile_start[i] : g.ts;
+      g.o = in ? a.g[i].o : g.o;
+      g.ids = in ? a.g[i].ids : g.ids;
+      g.y = in ? a.g[i].y : g.y;
+    }
+    return g;
+  };
+  auto decode_tile = [&](int tile, Job& c) {  // (wave-uniform tile: the indexed argument reads are scalar loads)
+    c.gi = 0;
+#pragma unroll
+    for (int i = 1; i < CARCA_MAX_GROUPS; ++i)
+      if (i < a.ngroups && tile >= a.tile_start[i]) c.gi = i;
+    c.qt = tile - a.tile_start[c.gi];
+    c.n = 16 * c.qt + ln;
+    const int N = a.g[c.gi].N;
+    c.in_range = c.n < N;
+    c.lrow = c.in_range ? c.n : N - 1;
+    c.o = a.g[c.gi].o + (size_t)u * N * a.ldo;
+    c.ids = a.g[c.gi].ids + (size_t)u * N;
+  };
+  auto decode = [&](int job, int t0) {
+    Job c;
+    c.tl = job / NH;
+    c.h = job - c.tl * NH;
+    decode_tile(t0 + c.tl, c);
+    return c;
+  };
+  auto stage_tiles = [&](int t0, int nt) {  // one DMA per (tile, 16-column group), dealt over the waves
+    for (int i = wave; i < nt * G::NKG; i += NW) {
+      const int tl = i / G::NKG, kg = i - tl * G::NKG;
+      Job c;
+      decode_tile(t0 + tl, c);
+      dma16(c.o, c.lrow * a.ldo + 4 * mq, 16 * kg, Ot + (tl * G::NKG + kg) * 256);
+    }
+  };
+  // target ids of a round, one per thread (STAGE: they travel through LDS like the tiles)
+  bool tile_id_ok = false;
+  auto load_tile_id = [&](int t0, int nt) {
+    const int tile = t0 + min(tid >> 4, nt - 1);
+    const Grp g = group_of(tile);
+    const int n = 16 * (tile - g.ts) + (tid & 15);
+    tile_id_ok = tid < nt * 16 && n < g.N;
+    return g.ids[(size_t)u * g.N + min(n, g.N - 1)];  // (unconditional load; masked with tile_id_ok where it is stored)
+  };
+  const Job job0 = decode(wave, t_lo);  // this wave's first job of the first round, decoded off the critical path
+  f32x4 qpre[G::NKG];
+  int idpre = 0;
+  bool have_pre = false;
+  int tile_id0 = 0;
+  if constexpr (STAGE) {
+    tile_id0 = load_tile_id(t_lo, min(TPR, t_hi - t_lo));
+  } else if constexpr (DPI <= 96) {
+    // (d > 96: eight fragments per target row and per weight tile; the prefetch would not fit 128 registers)
+    // requested by every wave, job or not (no loads under a branch, see above): a wave without a job fetches job 0's
+    const bool pre_ok = wave < min(TPR, t_hi - t_lo) * NH;
+    const Job c = decode(pre_ok ? wave : 0, t_lo);
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) qpre[kg] = gload4s(c.o, c.lrow * a.ldo + 4 * mq, 16 * kg);
+    idpre = gload1i(c.ids, c.lrow);
+    have_pre = pre_ok;
+  }
+  const unsigned long long pmask = __ballot(lane < L && my_id != 0);
+  // first real slot; keys are re-based there
+  const int s0 = pmask ? (int)__builtin_ctzll(pmask) : L;
+  const int nk = L - s0;
+  const int LTc = (nk + 15) >> 4;
+  CF_STAMP(1);
+
+  // ---- A1: final LayerNorm of the row pairs that hold a slot of the re-based profile, stored at that slot ---------------
+  {
+    const float inv_d = 1.0f / (float)d;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int pr = wave + NW * j;
+      if ((2 * pr + 1 >= s0 || a.p_normed) && 2 * pr < L) {  // (uniform; every row when the normed profile is an output)
+        f32x4 v = rv[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (4 * c4 + e < d) ? v[e] : 0.f;
+        if (a.ln_w && !(a.dbg & 8)) {
+          const float mean = half32_sum((v[0] + v[1]) + (v[2] + v[3])) * inv_d;
+          f32x4 dv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dv[e] = (4 * c4 + e < d) ? v[e] - mean : 0.f;
+          const float var = half32_sum((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * inv_d;
+          const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (4 * c4 + e < d) ? dv[e] * rstd * lnw[e] + lnb[e] : 0.f;
+        }
+        rv[j] = v;
+      }
+    }
+    if constexpr (STAGE) {
+      // Everything phase C reads is requested NOW: behind the loads phases A and B wait for (a CU fetches ~12 B per
+      // cycle whatever the source: rows + phase B's weights are 60 KB, these another 60), and with nothing else of this
+      // wave in flight -- hipcc answers "an ordinary load's result is used while an LDS-DMA is outstanding" with
+      // s_waitcnt vmcnt(0), which would park phase B behind the DMA.  The empty asm statements make the prefetched
+      // registers count as consumed here.
+      CF_STAMP(6);
+#pragma unroll
+      for (int kg = 0; kg < DPI / 16; ++kg) asm volatile("" : "+v"(bw.wf[kg]));
+      asm volatile("" : "+v"(bw.bk4), "+v"(bw.cu1), "+v"(tile_id0));
+      CF_STAMP(5);
+      if constexpr (STAGE_W)
+        if (!(a.dbg & 2))
+          for (int c = wave; c < G::DPO * DPI / 256; c += NW) dma16(a.wq, 4 * lane, 256 * c, Wq + 256 * c);
+      if (!(a.dbg & 4)) stage_tiles(t_lo, min(TPR, t_hi - t_lo));
+      if (wave == NW - 2 && lane < G::DPO / 4) dma16(a.bq, 4 * lane, 0, Bq);
+      if (wave == NW - 3 && lane < DPI / 4) dma16(a.ffn_w, 4 * lane, 0, Fw);
+      if (tid < TPR * 16) Ids[tid] = tile_id_ok ? tile_id0 : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int r = 2 * (wave + NW * j) + half, t = r - s0;
+      if (col_ok && r < L && t >= 0) *reinterpret_cast<f32x4*>(Ps + t * G::SI + 4 * c4) = rv[j];
+      if (a.p_normed && part == 0 && r < L && 4 * c4 < a.ldp) *reinterpret_cast<f32x4*>(a.p_normed + (ubase + r) * a.ldp + 4 * c4) = rv[j];
+    }
+    // rows of the (even number of) key tiles phase B reads beyond the profile: zeros, not LDS garbage
+    for (int t = nk + 2 * wave + half; t < min(ATT_LMAX, 32 * ((LTc + 1) >> 1)); t += 2 * NW)
+      if (col_ok) *reinterpret_cast<f32x4*>(Ps + t * G::SI + 4 * c4) = zero4();
+    if (wave == NW - 1) Km[lane] = (lane < nk && ((pmask >> (lane + s0)) & 1ull)) ? 0.f : FOLD_NEG;
+    // LDS-only barrier, hand-written: the DMA stays in flight across it.  (__syncthreads(), and even a workgroup fence
+    // restricted to LDS, make hipcc wait vmcnt(0) here: an outstanding LDS-DMA counts as a pending LDS write.  Nothing
+    // the DMA writes is read before the __syncthreads() that ends phase B.)
+    CF_STAMP(12);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  CF_STAMP(2);
+  // ---- B: K tiles and the u tiles, two slot tiles per job -----------------------------------------------------------
+  {
+    const int npair = (LTc + 1) >> 1;
+    bool first = true;
+    for (int job = wave; job < NFB * npair; job += NW) {
+      const int pr = job / NFB, ft = job - pr * NFB;
+      if (!first) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, ft, G::NF, lane);
+      first = false;
+      fold_b_job<DPI>(bw, Ps, G::SI, Ks, G::SO, Ut, ft, G::NF, 2 * pr, lane, NH);
+    }
+  }
+  __syncthreads();
+  CF_STAMP(3);
+
+  // ---- C: rounds of TPR target tiles; job = (tile, head) ----------------------------------------------------------------
+  const float ffn_b = a.ffn_b[0];
+  for (int t0 = t_lo; t0 < t_hi; t0 += TPR) {
+    const int nt = min(TPR, t_hi - t0);
+    if (STAGE && t0 != t_lo) {  // (the first round's tiles were requested in the prologue)
+      stage_tiles(t0, nt);
+      const int id = load_tile_id(t0, nt);
+      if (tid < TPR * 16) Ids[tid] = tile_id_ok ? id : 0;
+      __syncthreads();
+    }
+    // (the job body is instantiated twice: once for the prefetched first job, once for the loop -- with one copy the
+    // prefetched fragments would stay live through every iteration and spill)
+    auto run_job = [&](const Job& c, const f32x4 (&qfrag)[G::NKG], int tgt_id) __attribute__((always_inline)) {
+      const int h = c.h;
+      const bool q_ok = c.in_range && tgt_id != 0;
+      const int nkt = LTc;  // eval mode: every target sees all of the re-based profile (carca.py:339: causal = None)
+      CF_STAMP(7);
+      // Q^T tiles of the head, scaled into the exp2 domain
+      f32x4 qt[G::NFH];
+      if constexpr (STAGE_W && G::NFH == 2) {  // both feature tiles' chains interleaved, fragments from LDS
+        const float* w0 = Wq + (h * 2 * G::NKG) * 256 + 4 * lane;
+        f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+        for (int kg = 0; kg < G::NKG; ++kg) {
+          const f32x4 a0 = lds4(w0 + kg * 256), a1 = lds4(w0 + (G::NKG + kg) * 256);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc0 = mfma16(a0[s], qfrag[kg][s], acc0);
+            acc1 = mfma16(a1[s], qfrag[kg][s], acc1);
+          }
+        }
+        qt[0] = (acc0 + lds4(Bq + h * DHP + 4 * mq)) * a.qscale;
+        qt[1] = (acc1 + lds4(Bq + h * DHP + 16 + 4 * mq)) * a.qscale;
+      } else {
+#pragma unroll
+        for (int ft = 0; ft < G::NFH; ++ft) {
+          f32x4 wf[G::NKG];
+#pragma unroll
+          for (int kg = 0; kg < G::NKG; ++kg) {
+            if constexpr (STAGE_W) wf[kg] = lds4(Wq + ((h * G::NFH + ft) * G::NKG + kg) * 256 + 4 * lane);
+            else wf[kg] = gload4s(a.wq, 4 * lane, 256 * ((h * G::NFH + ft) * G::NKG + kg));
+          }
+          const f32x4 bias = STAGE ? lds4(Bq + h * DHP + 16 * ft + 4 * mq) : gload4s(a.bq, 4 * mq, h * DHP + 16 * ft);
+          if constexpr (!STAGE_W) CARCA_PIN_LOADS();
+          f32x4 acc = zero4();
+#pragma unroll
+          for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], qfrag[kg], acc);
+          qt[ft] = (acc + bias) * a.qscale;  // (bias after the chain in every variant: same bits whichever runs)
+        }
+      }
+      CF_STAMP(8);
+      // residual part of the logit (w . o, once per target) behind the projection's MFMAs
+      float ypart = 0.f;
+      if (a.residual && h == 0) {
+#pragma unroll
+        for (int kg = 0; kg < G::NKG; ++kg) {
+          const f32x4 wv = STAGE ? lds4(Fw + 16 * kg + 4 * mq) : gload4s(a.ffn_w, 4 * mq, 16 * kg);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ypart += wv[r] * qfrag[kg][r];
+        }
+        ypart = quad4_sum(ypart);
+      }
+      // scores^T tiles (rows = keys, cols = targets), accumulated on top of the additive mask; two key tiles at a time
+      // (two independent accumulator chains; the second tile of a pair exists in LDS even beyond nkt: masked there)
+      f32x4 sc[ATT_LT];
+      float mx = FOLD_NEG;
+#pragma unroll
+      for (int kp = 0; kp < ATT_LT / 2; ++kp) {
+        if (2 * kp < nkt) {
+          f32x4 acc0 = lds4(Km + 32 * kp + 4 * mq), acc1 = lds4(Km + 32 * kp + 16 + 4 * mq);
+          const float* krow = Ks + (32 * kp + ln) * G::SO + h * DHP + 4 * mq;
+#pragma unroll
+          for (int ft = 0; ft < G::NFH; ++ft) {
+            const f32x4 k0 = lds4(krow + 16 * ft), k1 = lds4(krow + 16 * G::SO + 16 * ft);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+              acc0 = mfma16(k0[s_], qt[ft][s_], acc0);
+              acc1 = mfma16(k1[s_], qt[ft][s_], acc1);
+            }
+          }
+          sc[2 * kp] = acc0;
+          sc[2 * kp + 1] = acc1;
+          mx = fmaxf(fmaxf(mx, fmaxf(acc0[0], acc0[1])), fmaxf(acc0[2], acc0[3]));
+          mx = fmaxf(fmaxf(mx, fmaxf(acc1[0], acc1[1])), fmaxf(acc1[2], acc1[3]));
+        }
+      }
+      CF_STAMP(9);
+      mx = quad4_max(mx);
+      float sum = 0.f, dot = 0.f;
+#pragma unroll
+      for (int kp = 0; kp < ATT_LT / 2; ++kp) {
+        if (2 * kp < nkt) {
+#pragma unroll
+          for (int kt = 2 * kp; kt < 2 * kp + 2; ++kt) {
+            const f32x4 uv = lds4(Ut + h * ATT_SK + 16 * kt + 4 * mq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float e = __builtin_amdgcn_exp2f(sc[kt][r] - mx);
+              sum += e;
+              dot += e * uv[r];
+            }
+          }
+        }
+      }
+      sum = quad4_sum(sum);
+      dot = quad4_sum(dot);
+      // a target with no allowed key (pad target, first slot when training, all-pad profile) attends nothing: exact 0
+      const float attn = (q_ok && mx > 0.5f * FOLD_NEG) ? dot / sum : 0.f;
+      if (mq == 0) Yp[(c.tl * NH + h) * 16 + ln] = attn + ypart;
+      CF_STAMP(10);
+    };
+    int job = wave;
+    if (have_pre) {
+      run_job(STAGE ? job0 : decode(job, t0), qpre, idpre);
+      have_pre = false;
+      job += NW;
+    }
+    for (; job < nt * NH; job += NW) {
+      const Job c = (STAGE && t0 == t_lo && job == wave) ? job0 : decode(job, t0);
+      f32x4 qfrag[G::NKG];
+#pragma unroll
+      for (int kg = 0; kg < G::NKG; ++kg) {
+        if constexpr (STAGE) qfrag[kg] = lds4(Ot + (c.tl * G::NKG + kg) * 256 + 4 * lane);
+        else qfrag[kg] = gload4s(c.o, c.lrow * a.ldo + 4 * mq, 16 * kg);
+      }
+      run_job(c, qfrag, STAGE ? Ids[c.tl * 16 + ln] : c.ids[c.lrow]);
+    }
+    __syncthreads();
+    CF_STAMP(11);
+    if (tid < nt * 16) {
+      const int tl = tid >> 4, l16 = tid & 15;
+      const Grp g = group_of(t0 + tl);
+      const int n = 16 * (t0 + tl - g.ts) + l16;
+      if (n < g.N) {
+        float logit = ffn_b;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) logit += Yp[(tl * NH + h) * 16 + l16];
+        g.y[(size_t)u * g.N + n] = 1.0f / (1.0f + expf(-logit));
+      }
+    }
+    if (t0 + TPR < t_hi) __syncthreads();
+  }
+  CF_STAMP(4);
+#undef CF_STAMP
+}
+
+template <int DPI, int DHP, int NH, bool STAGE>
+constexpr size_t fold_lds_bytes() {
+  using G = AttGeom<DPI, DHP, NH>;
+  size_t f = ATT_LMAX * G::SI + ATT_LMAX * G::SO + NH * ATT_SK + ATT_LMAX + CROSS_TPR * NH * 16;
+  if (STAGE) f += FOLD_TPR_S * G::NKG * 256 + 512 + FOLD_TPR_S * 16 + (DPI <= 96 ? G::DPO * DPI : 0);
+  return sizeof(float) * f;
+}
+
+template <int DPI, int DHP, int NH, int NW, bool STAGE>
+int launch_fold_nw(const FoldArgs& fa, int B, hipStream_t stream) {
+  constexpr size_t lds_bytes = fold_lds_bytes<DPI, DHP, NH, STAGE>();
+  static_assert(lds_bytes <= 160 * 1024, "the staged variant must fit one CU's LDS");
+  auto kern = cross_fold_kernel<DPI, DHP, NH, NW, STAGE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      carca_set_error("cross_score_fwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  hipEvent_t e0, e1;
+  if (carca_take_launch_events(&e0, &e1))  // (timing events bound to this dispatch: carca_forward's ev[2], ev[3])
+    hipExtLaunchKernelGGL(kern, dim3(B * fa.nparts), dim3(NW * 64), lds_bytes, stream, e0, e1, 0, fa);
+  else
+    hipLaunchKernelGGL(kern, dim3(B * fa.nparts), dim3(NW * 64), lds_bytes, stream, fa);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+// Variant choice (tuning key 1 as for the kernel above): two 16-wave workgroups per user while 2 B <= #CUs (latency
+// regime: each takes half the target tiles), one per user up to #CUs -- both with LDS staging; beyond #CUs one 8-wave
+// workgroup per user, two resident per CU.  Tuning key 7 = 1: 16-wave workgroups without staging (A/B).
+template <int DPI, int DHP, int NH>
+int launch_fold(FoldArgs& fa, int B, hipStream_t stream) {
+  const int num_cus = carca_num_cus();
+  const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);
+  const int all_tiles = fa.tile_start[fa.ngroups];
+  fa.nparts = (all_tiles > 1 && tune != 1 && tune != 3 && (tune == 2 || 2 * B <= num_cus)) ? 2 : 1;
+  if (fa.nparts == 1 && (tune == 3 || (tune == 0 && B > num_cus)))
+    return launch_fold_nw<DPI, DHP, NH, 8, false>(fa, B, stream);
+  if (carca_tuning(7) == 1) return launch_fold_nw<DPI, DHP, NH, 16, false>(fa, B, stream);
+  return launch_fold_nw<DPI, DHP, NH, 16, true>(fa, B, stream);
+}
+
 template <int DPI, int DHP, int NH>
 constexpr size_t cross_lds_bytes() {
   using G = AttGeom<DPI, DHP, NH>;
@@ -278,10 +797,26 @@ extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t*
   }
   gd.tile_start[ngroups] = t;
   gd.n = ngroups;
+  CARCA_CHECK_ARG(!(drop && drop->p >= 1.0f), "cross_score_fwd: dropout p must be < 1");
+  // eval mode (nothing saved, no dropout, no causal mask): the folded kernel (tuning key 6 = 1 forces the other one)
+  if (!save && !training && w->wu && w->cu && carca_tuning(6) != 1 && ldp % 4 == 0 && ldp >= dpi) {
+    FoldArgs fa{};
+    fa.p_raw = p_raw; fa.p_ids = p_ids; fa.p_normed = p_normed;
+    for (int i = 0; i < ngroups; ++i) fa.g[i] = gd.g[i];
+    for (int i = 0; i <= ngroups; ++i) fa.tile_start[i] = gd.tile_start[i];
+    fa.ngroups = ngroups; fa.ldp = ldp; fa.ldo = ldo; fa.L = L; fa.d = d; fa.residual = residual;
+    fa.ln_w = w->ln_w; fa.ln_b = w->ln_b; fa.wq = w->wq; fa.bq = w->bq; fa.wk = w->wk; fa.bk = w->bk; fa.wu = w->wu;
+    fa.cu = w->cu; fa.ffn_w = w->ffn_w; fa.ffn_b = w->ffn_b;
+    fa.qscale = (float)(1.4426950408889634 / sqrt((double)(d / H)));
+    fa.stamps = carca_debug_buffer();
+    fa.dbg = carca_tuning(5);
+    CARCA_ATT_DISPATCH(launch_fold, fa, B, stream);
+    carca_set_error("cross_score_fwd: no kernel built for d=%d H=%d (padded %d / head %d)", d, H, dpi, dhp);
+    return CARCA_ERR_UNSUPPORTED;
+  }
   CarcaCaSave sv{};
   if (save) sv = *save;
   const DropCfg dc = make_drop(drop);
-  CARCA_CHECK_ARG(!(drop && drop->p >= 1.0f), "cross_score_fwd: dropout p must be < 1");
   CARCA_ATT_DISPATCH(launch_cross, p_raw, ldp, p_ids, p_normed, gd, ldo, B, L, d, *w, residual, training, sv, dc,
                      drop ? drop->site : 0u, stream);
   carca_set_error("cross_score_fwd: no kernel built for d=%d H=%d (padded %d / head %d)", d, H, dpi, dhp);

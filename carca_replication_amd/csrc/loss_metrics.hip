@@ -37,8 +37,8 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ y, 
       // denom: the mask count of the WHOLE batch when users are sharded over ranks (dist.py), else sum(mask)
       if (denom) b = denom[0];
       loss_out[0] = a / b;  // 0/0 = NaN for an all-pad batch, as in the reference
+      red[0][0] = b;        // lane 0 alone holds the caller's normaliser: the other lanes' b is the local mask count
     }
-    red[0][0] = b;
   }
   if (dy) {
     __syncthreads();

@@ -11,7 +11,7 @@ import torch
 
 from . import dist as cdist
 from . import ops
-from .modules import BinaryCrossEntropy, get_mask
+from .modules import BinaryCrossEntropy, get_mask, note_training_forward
 
 _loss_fn = BinaryCrossEntropy()
 
@@ -95,12 +95,21 @@ class GraphedTrainStep:
                 self.loss = _forward_backward(model, optim, self.inputs, False)
         finally:
             ops.set_dropout_seed_offset(None)
+        # The replayed backward writes into the gradient tensors of the capture.  An eager step in between (train() sends
+        # the short last batch of an epoch through train_step) rebinds every p.grad to fresh memory: remember the graph's
+        # own tensors and hand them back to the parameters before each optimizer step.
+        self.params = [p for p in model.parameters() if p.grad is not None]
+        self.grads = [p.grad for p in self.params]
 
     def __call__(self, batch) -> torch.Tensor:
         for dst, src in zip(self.inputs, batch):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        for p, g in zip(self.params, self.grads):
+            if p.grad is not g:
+                p.grad = g
+        note_training_forward()  # the optimizer below rewrites the weights: packed inference copies are stale
         self.optim.step()
         return self.loss
 

@@ -766,6 +766,11 @@ class CrossAttentionBlock(_PackedModule, Decoder):
         items = self.attn.pack_items(dpi, dhp, dpo)
         items += [ops.PackItem(self.ffn.weight, 1, dpo, col_heads=(dh, dhp)), ops.PackItem(self.ffn.weight, 1, dpi),
                   ops.PackItem(self.ffn.bias, 1, 4)]
+        # decoder.ffn folded into the value projection (CarcaCaWeights.wu / cu): wu[h] = sum_i w[h,i] W_V[h,i,:],
+        # cu[h] = sum_i w[h,i] b_V[h,i] -- the inference kernel scores with P . u instead of w . (P V)
+        fv = self.ffn.weight.view(-1)
+        items += [ops.PackItem(self.attn.WV.weight, 16, dpi, frag16=True, fold_vec=fv, fold_H=H),
+                  ops.PackItem(self.attn.WV.bias.view(-1, 1), 16, 1, fold_vec=fv, fold_H=H)]
         for t in self.__dict__.get("_final_norm_params", ()):
             items.append(ops.PackItem(t, 1, dpi))
         return items
@@ -777,8 +782,9 @@ class CrossAttentionBlock(_PackedModule, Decoder):
         w = _lib.CaWeights()
         for i, n in enumerate(["wq", "wk", "wv", "bq", "bk", "bv", "ffn_w_pad", "ffn_w", "ffn_b"]):
             setattr(w, n, pw.ptr(i))
+        w.wu, w.cu = pw.ptr(9), pw.ptr(10)
         if final_norm is not None:
-            w.ln_w, w.ln_b = pw.ptr(9), pw.ptr(10)
+            w.ln_w, w.ln_b = pw.ptr(11), pw.ptr(12)
         else:
             w.ln_w, w.ln_b = None, None
         w._keepalive = pw

@@ -179,6 +179,8 @@ class PackItem:
     col_heads: Tuple[int, int] = (0, 0)
     transposed: bool = False  # pack src^T (dst_rows/dst_cols and the head maps refer to the transposed matrix)
     frag16: bool = False      # MFMA-fragment order (CarcaPackDesc.frag16): the attention kernels' operand layout
+    fold_vec: Optional[Tensor] = None  # CarcaPackDesc.fold_vec: contract src's rows per head with this [rows] vector ...
+    fold_H: int = 0                    # ... into a logical [fold_H, cols] source
 
 
 class PackedWeights:
@@ -215,11 +217,12 @@ class PackedWeights:
     def _fill(self, tensors) -> list:
         """Point the descriptors at `tensors` (the items' sources, or gradient tensors of the same shapes).  Everything
         that does not depend on the tensors is written once (this runs for ~70 descriptors per train step)."""
-        keep = []
+        keep, extra = [], []
         base = self.buf.data_ptr()
         first = not self.__dict__.get("_static_done")
         # steady state (the same parameters repacked into the same buffer every training step): nothing to rewrite
-        sig = (base,) + tuple((t.data_ptr(), t.shape, t.stride()) for t in tensors)
+        sig = (base,) + tuple((t.data_ptr(), t.shape, t.stride()) for t in tensors) + \
+            tuple(it.fold_vec.data_ptr() for it in self.items if it.fold_vec is not None)
         if not first and self.__dict__.get("_filled_sig") == sig:
             return list(tensors)
         self._filled_sig = None
@@ -233,6 +236,12 @@ class PackedWeights:
             keep.append(src)
             d = self._descs[i]
             d.src, d.dst, d.src_ld = src.data_ptr(), base + 4 * self.offsets[i], src.stride(0)
+            if it.fold_vec is not None:
+                fv = it.fold_vec.detach()
+                if fv.dtype != torch.float32 or not fv.is_cuda or not fv.is_contiguous() or fv.numel() != src.shape[0]:
+                    raise CarcaHipError("pack: fold_vec must be a contiguous fp32 CUDA vector with one entry per source row")
+                extra.append(fv)
+                d.fold_vec, d.fold_H = fv.data_ptr(), it.fold_H
             r, c = (src.shape[1], src.shape[0]) if it.transposed else (src.shape[0], src.shape[1])
             if first:
                 d.rows, d.cols = r, c
@@ -246,7 +255,7 @@ class PackedWeights:
         self._static_done = True
         if all(k.data_ptr() == t.data_ptr() for k, t in zip(keep, tensors)):  # (detach / reshape stand-ins share the memory)
             self._filled_sig = sig
-        return keep
+        return keep + extra
 
     def pack(self) -> None:
         pack_many([self])

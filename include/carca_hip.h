@@ -82,6 +82,12 @@ typedef struct CarcaPackDesc {
                             * of 16): packed element (rp, cp) lives at
                             *   (((rp/16) * (dst_cols/16) + cp/16) * 64 + ((cp%16)/4) * 16 + rp%16) * 4 + cp%4,
                             * i.e. the 64 lanes x 4 floats one wave loads for one 16x16 tile are 1 KB contiguous */
+  /* fold_vec != NULL: the logical source is not src itself but the per-head contraction of its ROWS with a vector,
+   *   S'[h][c] = sum_{i < rows/fold_H} fold_vec[h*(rows/fold_H) + i] * src[h*(rows/fold_H) + i][c],  h < fold_H,
+   * a [fold_H, cols] matrix that is then placed like any other (row_dh must be 0).  This is how decoder.ffn is folded
+   * into the cross-attention's value projection once per weight version (CarcaCaWeights.wu / cu). */
+  const float* fold_vec;
+  int32_t fold_H;
 } CarcaPackDesc;
 int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream);
 
@@ -249,6 +255,12 @@ typedef struct CarcaCaWeights {
   const float* ffn_w_pad;    /* decoder.ffn.weight in head-padded order [DPO] */
   const float* ffn_w;        /* decoder.ffn.weight plain, zero-padded [DPI] */
   const float* ffn_b;        /* [1] */
+  /* decoder.ffn folded into the value projection (the block's output is the scalar w . (PV + o), carca.py:340-345, so
+   * w_h . (P_h V_h) = P_h u_h with u_h[key] = p[key] . wu[h] + cu[h]): wu[h][c] = sum_i w[h*dh+i] W_V[h*dh+i][c]
+   * ([16, DPI], rows >= H zero, fragment order), cu[h] = sum_i w[h*dh+i] b_V[h*dh+i] ([16]).  Built by
+   * carca_pack_weights (CarcaPackDesc.fold_vec).  Used by the inference kernel (save == NULL); may be NULL, which
+   * selects the kernel that materialises V. */
+  const float *wu, *cu;
 } CarcaCaWeights;
 typedef struct CarcaTargetGroup {
   const float* o;     /* embedded targets [B*N, ldo] */

@@ -130,6 +130,28 @@ def test_bce_loss_matches_reference(name):
     assert abs(float(loss2) - float(fx2.outs["loss"])) < 2e-6
 
 
+def test_bce_gradient_uses_the_callers_normaliser():
+    """Sharded steps pass the all-reduced mask count as `denom`: loss AND dL/dy must be scaled by it, not by the local
+    count (round-1 race: every lane of wave 0 stored its own normaliser, only lane 0 held the caller's)."""
+    from carca_replication_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    n = 7 * 100
+    y = torch.rand(n, generator=g) * 0.98 + 0.01
+    y_true = (torch.rand(n, generator=g) < 0.5).int()
+    ids = (torch.rand(n, generator=g) < 0.7).int() * 5
+    mask = (ids != 0).float()
+    for denom in (None, 3.0 * float(mask.sum()), 17.0):
+        yr = y.clone().requires_grad_(True)
+        per = -(y_true * torch.log(yr + 1e-8) + (1 - y_true) * torch.log(1 - yr + 1e-8))
+        want = (per * mask).sum() / (float(mask.sum()) if denom is None else denom)
+        want.backward()
+        dt = None if denom is None else torch.tensor([denom], dtype=torch.float32, device="cuda")
+        loss, dy = ops.bce_fwd(y.cuda(), y_true.cuda(), ids.cuda(), 1e-8, want_grad=True, denom=dt)
+        assert abs(float(loss) - float(want)) < 2e-6 * max(1.0, abs(float(want)))
+        assert torch.allclose(dy.cpu().view(-1), yr.grad, rtol=1e-5, atol=1e-9)
+
+
 # ---- oracle comparisons at shapes the fixtures do not hold ------------------------------------------
 SHAPES = [
     # d, H, g, blocks, B, L, N, n_items, n_attrs, n_ctx

@@ -75,3 +75,26 @@ def test_graphed_step_takes_new_batches():
     want = [engine.train_step(model_e, opt_e, batch).clone(), engine.train_step(model_e, opt_e, other).clone()]
     assert [float(x) for x in got] == pytest.approx([float(x) for x in want], rel=1e-5)
     assert abs(float(got[1]) - float(got[0])) > 1e-4
+
+
+def test_eager_step_between_replays_does_not_orphan_the_graphs_gradients():
+    """train(graphed=True) sends an epoch's short last batch through the eager train_step, whose zero_grad(set_to_none)
+    rebinds every p.grad: the replays after it must still feed the optimizer THEIR gradients (round-1 bug: the
+    optimizer kept applying the eager batch's gradients)."""
+    from carca_replication_amd import engine
+
+    fresh, batch = _setup(0.0)
+    other = tuple(t.roll(2, 0) for t in batch)
+    short = tuple(t[:4].contiguous() for t in batch)
+    model_g, opt_g = fresh()
+    step = engine.GraphedTrainStep(model_g, opt_g, batch)
+    model_e, opt_e = fresh()
+    got, want = [], []
+    for b, graphed in ((batch, True), (short, False), (other, True), (batch, True)):
+        got.append(float(step(b) if graphed else engine.train_step(model_g, opt_g, b)))
+        want.append(float(engine.train_step(model_e, opt_e, b)))
+    assert got == pytest.approx(want, rel=1e-4)
+    for (n, a), (_, b) in zip(model_g.named_parameters(), model_e.named_parameters()):
+        if n.endswith("WK.bias"):  # true gradient 0: Adam turns round-off into +-lr steps (DESIGN section 2)
+            continue
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-5), n
