@@ -282,12 +282,19 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     groups[gi].y = D->y[gi];
     groups[gi].N = D->N[gi];
   }
-  if (ev && ev[2]) (void)hipEventRecord((hipEvent_t)ev[2], stream);
+  // ev[2], ev[3]: bound to the scoring kernel's own dispatch, like ev[0], ev[1] to the feature GEMM's
+  if (ev && ev[2] && ev[3]) carca_arm_launch_events(ev[2], ev[3]);
   CarcaDropout drc{D->p_cross, D->seed, 2000u, D->seed_offset};
   CARCA_TRY(carca_cross_score_fwd(x, D->ld_e, D->segs[0].ids, D->p_normed, groups, D->ngroups, D->ld_e, D->B, D->L,
                                   D->d, D->H, &D->ca, D->ca_residual, D->training, D->save_cross ? &D->ca_save : nullptr,
                                   (D->save_cross && D->p_cross > 0.f) ? &drc : nullptr, stream_));
-  if (ev && ev[3]) (void)hipEventRecord((hipEvent_t)ev[3], stream);
+  {
+    hipEvent_t left0, left1;
+    if (carca_take_launch_events(&left0, &left1)) {
+      carca_set_error("forward: the scoring kernel's launch did not take the timing events");
+      return CARCA_ERR_UNSUPPORTED;
+    }
+  }
 #undef CARCA_TRY
   return CARCA_OK;
 }

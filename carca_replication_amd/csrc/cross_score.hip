@@ -226,7 +226,8 @@ struct FoldArgs {
   int ngroups, ldp, ldo, L, d, residual, nparts;
   const float *ln_w, *ln_b, *wq, *bq, *wk, *bk, *wu, *cu, *ffn_w, *ffn_b;
   float qscale;  // log2(e) / sqrt(dh): scores leave the Q projection in the exp2 domain
-  int dbg;       // timing experiments (tuning key 5): bit 0 no phase B prefetch, 1 no W_Q DMA, 2 no tile DMA, 3 no LayerNorm
+  int dbg;       // timing experiments (tuning key 5; wrong results): bit 1 no W_Q traffic, 2 no tile traffic, 3 no LayerNorm,
+                 // 4 no W_K traffic
   unsigned long long* stamps;
 };
 #define FOLD_NEG (-1.0e30f)
@@ -252,12 +253,12 @@ struct FoldBW {
 template <int DPI>
 __device__ __forceinline__ void fold_b_load(FoldBW<DPI>& w, const float* __restrict__ wk, const float* __restrict__ bk,
                                             const float* __restrict__ wu, const float* __restrict__ cu, int ft, int nf,
-                                            int lane) {
+                                            int lane, bool dbg16 = false) {
   const bool isu = ft == nf;  // (uniform)
   const float* wp = isu ? wu : wk;
   const int t = isu ? 0 : ft;
 #pragma unroll
-  for (int kg = 0; kg < DPI / 16; ++kg) w.wf[kg] = gload4s(wp, 4 * lane, 256 * (t * (DPI / 16) + kg));
+  for (int kg = 0; kg < DPI / 16; ++kg) w.wf[kg] = gload4s(wp, 4 * lane, dbg16 ? 0 : 256 * (t * (DPI / 16) + kg));
   w.cu1 = gload1(cu, lane & 15);
   w.bk4 = gload4s(bk, 4 * (lane >> 4), 16 * t);
 }
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   // one gets its weight fragments now
   constexpr int NFB = G::NF + 1;
   FoldBW<DPI> bw;
-  fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, wave % NFB, G::NF, lane);
+  fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, wave % NFB, G::NF, lane, a.dbg & 16);
 
   // tiles of this workgroup
   const int all_tiles = a.tile_start[a.ngroups];
@@ -415,8 +416,8 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     decode_tile(t0 + c.tl, c);
     return c;
   };
-  auto stage_tiles = [&](int t0, int nt) {  // one DMA per (tile, 16-column group), dealt over the waves
-    for (int i = wave; i < nt * G::NKG; i += NW) {
+  auto stage_tiles = [&](int t0, int nt, int w0 = 0, int nw = NW) {  // one DMA per (tile, 16-column group), dealt over
+    for (int i = wave - w0; i < nt * G::NKG; i += nw) {                  // the waves w0 .. w0 + nw - 1
       const int tl = i / G::NKG, kg = i - tl * G::NKG;
       Job c;
       decode_tile(t0 + tl, c);
@@ -480,22 +481,14 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
       }
     }
     if constexpr (STAGE) {
-      // Everything phase C reads is requested NOW: behind the loads phases A and B wait for (a CU fetches ~12 B per
-      // cycle whatever the source: rows + phase B's weights are 60 KB, these another 60), and with nothing else of this
-      // wave in flight -- hipcc answers "an ordinary load's result is used while an LDS-DMA is outstanding" with
-      // s_waitcnt vmcnt(0), which would park phase B behind the DMA.  The empty asm statements make the prefetched
-      // registers count as consumed here.
+      // The prefetched registers count as consumed from here on (empty asm statements): hipcc answers "an ordinary
+      // load's result is used while an LDS-DMA is outstanding" with s_waitcnt vmcnt(0), and phase B must not wait for
+      // the DMA requested below.
       CF_STAMP(6);
 #pragma unroll
       for (int kg = 0; kg < DPI / 16; ++kg) asm volatile("" : "+v"(bw.wf[kg]));
       asm volatile("" : "+v"(bw.bk4), "+v"(bw.cu1), "+v"(tile_id0));
       CF_STAMP(5);
-      if constexpr (STAGE_W)
-        if (!(a.dbg & 2))
-          for (int c = wave; c < G::DPO * DPI / 256; c += NW) dma16(a.wq, 4 * lane, 256 * c, Wq + 256 * c);
-      if (!(a.dbg & 4)) stage_tiles(t_lo, min(TPR, t_hi - t_lo));
-      if (wave == NW - 2 && lane < G::DPO / 4) dma16(a.bq, 4 * lane, 0, Bq);
-      if (wave == NW - 3 && lane < DPI / 4) dma16(a.ffn_w, 4 * lane, 0, Fw);
       if (tid < TPR * 16) Ids[tid] = tile_id_ok ? tile_id0 : 0;
     }
 #pragma unroll
@@ -515,13 +508,30 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   CF_STAMP(2);
+  if constexpr (STAGE) {
+    // Everything phase C reads is requested NOW, behind the loads phases A and B waited for (a CU takes in ~12 B per
+    // cycle whatever the source: rows + phase B's weights were 60 KB, these are another 60) and after the barrier, so
+    // that no wave's arrival there is delayed by the issue; the requests land under phase B's MFMAs.
+    // The issue itself is ~1.3 k cycles per wave when every wave takes a share: the waves WITHOUT a phase B job
+    // (NW - 2 (NF + 1) of them, where there are any) do all of it while the others start their MFMAs.
+    constexpr int NBJ = 2 * NFB;
+    constexpr int DW0 = NW > NBJ ? NBJ : 0, NDW = NW > NBJ ? NW - NBJ : NW;
+    if (wave >= DW0) {
+      if constexpr (STAGE_W)
+        if (!(a.dbg & 2))
+          for (int c = wave - DW0; c < G::DPO * DPI / 256; c += NDW) dma16(a.wq, 4 * lane, 256 * c, Wq + 256 * c);
+      if (!(a.dbg & 4)) stage_tiles(t_lo, min(TPR, t_hi - t_lo), DW0, NDW);
+      if (wave == NW - 1 && lane < G::DPO / 4) dma16(a.bq, 4 * lane, 0, Bq);
+      if (wave == NW - 1 && lane < DPI / 4) dma16(a.ffn_w, 4 * lane, 0, Fw);
+    }
+  }
   // ---- B: K tiles and the u tiles, two slot tiles per job -----------------------------------------------------------
   {
     const int npair = (LTc + 1) >> 1;
     bool first = true;
     for (int job = wave; job < NFB * npair; job += NW) {
       const int pr = job / NFB, ft = job - pr * NFB;
-      if (!first) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, ft, G::NF, lane);
+      if (!first) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, ft, G::NF, lane, a.dbg & 16);
       first = false;
       fold_b_job<DPI>(bw, Ps, G::SI, Ks, G::SO, Ut, ft, G::NF, 2 * pr, lane, NH);
     }
@@ -541,7 +551,10 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     }
     // (the job body is instantiated twice: once for the prefetched first job, once for the loop -- with one copy the
     // prefetched fragments would stay live through every iteration and spill)
-    auto run_job = [&](const Job& c, const f32x4 (&qfrag)[G::NKG], int tgt_id) __attribute__((always_inline)) {
+    // wpre / bpre: the head's W_Q fragments and bias when the caller fetched them (the pipelined path below), else null;
+    // after_proj(): called once the projection has consumed qfrag / wpre (the caller overwrites them with the next job's)
+    auto run_job = [&](const Job& c, const f32x4 (&qfrag)[G::NKG], const f32x4 (*wpre)[G::NKG], const f32x4* bpre, int tgt_id,
+                       auto after_proj) __attribute__((always_inline)) {
       const int h = c.h;
       const bool q_ok = c.in_range && tgt_id != 0;
       const int nkt = LTc;  // eval mode: every target sees all of the re-based profile (carca.py:339: causal = None)
@@ -562,6 +575,22 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
         }
         qt[0] = (acc0 + lds4(Bq + h * DHP + 4 * mq)) * a.qscale;
         qt[1] = (acc1 + lds4(Bq + h * DHP + 16 + 4 * mq)) * a.qscale;
+      } else if (wpre) {  // the first feature tile's fragments arrived with the target rows; the others are requested
+                          // now and land under the first tile's chain
+        f32x4 wr[G::NFH > 1 ? G::NFH - 1 : 1][G::NKG];
+#pragma unroll
+        for (int ft = 1; ft < G::NFH; ++ft)
+#pragma unroll
+          for (int kg = 0; kg < G::NKG; ++kg)
+            wr[ft - 1][kg] = gload4s(a.wq, 4 * lane, (a.dbg & 2) ? 0 : 256 * ((h * G::NFH + ft) * G::NKG + kg));
+        CARCA_PIN_LOADS();
+#pragma unroll
+        for (int ft = 0; ft < G::NFH; ++ft) {
+          f32x4 acc = zero4();
+#pragma unroll
+          for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(ft == 0 ? wpre[0][kg] : wr[ft > 0 ? ft - 1 : 0][kg], qfrag[kg], acc);
+          qt[ft] = (acc + bpre[ft]) * a.qscale;
+        }
       } else {
 #pragma unroll
         for (int ft = 0; ft < G::NFH; ++ft) {
@@ -569,7 +598,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
 #pragma unroll
           for (int kg = 0; kg < G::NKG; ++kg) {
             if constexpr (STAGE_W) wf[kg] = lds4(Wq + ((h * G::NFH + ft) * G::NKG + kg) * 256 + 4 * lane);
-            else wf[kg] = gload4s(a.wq, 4 * lane, 256 * ((h * G::NFH + ft) * G::NKG + kg));
+            else wf[kg] = gload4s(a.wq, 4 * lane, (a.dbg & 2) ? 0 : 256 * ((h * G::NFH + ft) * G::NKG + kg));
           }
           const f32x4 bias = STAGE ? lds4(Bq + h * DHP + 16 * ft + 4 * mq) : gload4s(a.bq, 4 * mq, h * DHP + 16 * ft);
           if constexpr (!STAGE_W) CARCA_PIN_LOADS();
@@ -591,6 +620,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
         }
         ypart = quad4_sum(ypart);
       }
+      after_proj();
       // scores^T tiles (rows = keys, cols = targets), accumulated on top of the additive mask; two key tiles at a time
       // (two independent accumulator chains; the second tile of a pair exists in LDS even beyond nkt: masked there)
       f32x4 sc[ATT_LT];
@@ -640,21 +670,68 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
       if (mq == 0) Yp[(c.tl * NH + h) * 16 + ln] = attn + ypart;
       CF_STAMP(10);
     };
-    int job = wave;
-    if (have_pre) {
-      run_job(STAGE ? job0 : decode(job, t0), qpre, idpre);
-      have_pre = false;
-      job += NW;
-    }
-    for (; job < nt * NH; job += NW) {
-      const Job c = (STAGE && t0 == t_lo && job == wave) ? job0 : decode(job, t0);
-      f32x4 qfrag[G::NKG];
+    constexpr bool PIPE = !STAGE && G::NFH * G::NKG <= 16;
+    if constexpr (PIPE) {
+      // Software pipeline over this wave's jobs: the operands of job j+1 (target rows, the head's first W_Q tile, bias,
+      // target id) are requested as soon as job j's projection has consumed its own, into the same registers, and
+      // land under job j's scores and softmax -- a job then starts its first chain without waiting for memory.
+      struct Ops {
+        f32x4 q[G::NKG], w[1][G::NKG], b[G::NFH];  // (w: the head's FIRST feature tile; 128 registers do not hold more)
+        int id;
+      } cur;
+      auto load_w = [&](const Job& c) {
 #pragma unroll
-      for (int kg = 0; kg < G::NKG; ++kg) {
-        if constexpr (STAGE) qfrag[kg] = lds4(Ot + (c.tl * G::NKG + kg) * 256 + 4 * lane);
-        else qfrag[kg] = gload4s(c.o, c.lrow * a.ldo + 4 * mq, 16 * kg);
+        for (int kg = 0; kg < G::NKG; ++kg)
+          cur.w[0][kg] = gload4s(a.wq, 4 * lane, (a.dbg & 2) ? 0 : 256 * ((c.h * G::NFH) * G::NKG + kg));
+#pragma unroll
+        for (int ft = 0; ft < G::NFH; ++ft) cur.b[ft] = gload4s(a.bq, 4 * mq, c.h * DHP + 16 * ft);
+      };
+      auto load_q = [&](const Job& c) {
+#pragma unroll
+        for (int kg = 0; kg < G::NKG; ++kg) cur.q[kg] = gload4s(c.o, (a.dbg & 4) ? 0 : c.lrow * a.ldo + 4 * mq, 16 * kg);
+        cur.id = gload1i(c.ids, c.lrow);
+      };
+      const int njobs = nt * NH;
+      if (wave < njobs) {
+        Job cj = decode(wave, t0);
+        if (have_pre) {
+#pragma unroll
+          for (int kg = 0; kg < G::NKG; ++kg) cur.q[kg] = qpre[kg];
+          cur.id = idpre;
+          have_pre = false;
+        } else {
+          load_q(cj);
+        }
+        load_w(cj);
+        for (int job = wave; job < njobs; job += NW) {
+          Job cn;
+          const int tgt_id = cur.id;
+          run_job(cj, cur.q, cur.w, cur.b, tgt_id, [&]() {
+            const int nj = job + NW;
+            cn = decode(nj < njobs ? nj : job, t0);  // (the last job re-requests its own operands: no load under a branch)
+            load_q(cn);
+            load_w(cn);
+          });
+          cj = cn;
+        }
       }
-      run_job(c, qfrag, STAGE ? Ids[c.tl * 16 + ln] : c.ids[c.lrow]);
+    } else {
+      int job = wave;
+      if (have_pre) {
+        run_job(STAGE ? job0 : decode(job, t0), qpre, nullptr, nullptr, idpre, []() {});
+        have_pre = false;
+        job += NW;
+      }
+      for (; job < nt * NH; job += NW) {
+        const Job c = (STAGE && t0 == t_lo && job == wave) ? job0 : decode(job, t0);
+        f32x4 qfrag[G::NKG];
+#pragma unroll
+        for (int kg = 0; kg < G::NKG; ++kg) {
+          if constexpr (STAGE) qfrag[kg] = lds4(Ot + (c.tl * G::NKG + kg) * 256 + 4 * lane);
+          else qfrag[kg] = gload4s(c.o, (a.dbg & 4) ? 0 : c.lrow * a.ldo + 4 * mq, 16 * kg);
+        }
+        run_job(c, qfrag, nullptr, nullptr, STAGE ? Ids[c.tl * 16 + ln] : c.ids[c.lrow], []() {});
+      }
     }
     __syncthreads();
     CF_STAMP(11);
@@ -715,6 +792,8 @@ int launch_fold(FoldArgs& fa, int B, hipStream_t stream) {
   const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);
   const int all_tiles = fa.tile_start[fa.ngroups];
   fa.nparts = (all_tiles > 1 && tune != 1 && tune != 3 && (tune == 2 || 2 * B <= num_cus)) ? 2 : 1;
+  // (Measured and dropped: delaying the first occupant of every CU's second slot by 8-32 k cycles, against the idea that
+  // two workgroups started together stay in lockstep -- the launch got longer by exactly the delay.)
   if (fa.nparts == 1 && (tune == 3 || (tune == 0 && B > num_cus)))
     return launch_fold_nw<DPI, DHP, NH, 8, false>(fa, B, stream);
   if (carca_tuning(7) == 1) return launch_fold_nw<DPI, DHP, NH, 16, false>(fa, B, stream);
@@ -744,8 +823,13 @@ int launch_cross_nw(const float* p_raw, int ldp, const int32_t* p_ids, float* p_
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B * nparts), dim3(NW * 64), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L,
-                     d, d / NH, w, residual, training, sv, dc, site, nparts, carca_debug_buffer());
+  hipEvent_t e0, e1;
+  if (carca_take_launch_events(&e0, &e1))  // (timing events bound to this dispatch: carca_forward's ev[2], ev[3])
+    hipExtLaunchKernelGGL(kern, dim3(B * nparts), dim3(NW * 64), lds_bytes, stream, e0, e1, 0, p_raw, ldp, p_ids, p_normed,
+                          groups, ldo, L, d, d / NH, w, residual, training, sv, dc, site, nparts, carca_debug_buffer());
+  else
+    hipLaunchKernelGGL(kern, dim3(B * nparts), dim3(NW * 64), lds_bytes, stream, p_raw, ldp, p_ids, p_normed, groups, ldo, L,
+                       d, d / NH, w, residual, training, sv, dc, site, nparts, carca_debug_buffer());
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

@@ -494,8 +494,8 @@ int carca_build_train_batch(const int32_t* hist, const int64_t* offs, const floa
  * ev (optional, host array of 4 hipEvent_t, entries may be NULL): so that a benchmark can time exactly these kernels
  * inside its timed region.  ev[0], ev[1] (both or neither) are BOUND to the feature GEMM's dispatch on `stream`
  * (hipExtLaunchKernel: start / end of that kernel, hipEventElapsedTime(ev[0], ev[1]) = its duration; nothing extra is
- * queued).  ev[2], ev[3] are recorded (hipEventRecord) before / after the scoring kernel: a record is a barrier
- * packet of its own and costs ~6 us of GPU time between two kernels. */
+ * queued).  ev[2], ev[3] (both or neither) are bound the same way to the scoring kernel's dispatch (a hipEventRecord
+ * would be a barrier packet of its own: ~6 us of GPU time between two kernels). */
 #define CARCA_MAX_BLOCKS 8
 typedef struct CarcaForwardDesc {
   CarcaRowSeg segs[CARCA_MAX_SEGS];

@@ -75,6 +75,11 @@ for B in [int(b) for b in os.environ.get("BS", "128,256,512,1024,4096").split(",
         t_old = timed(lambda: run(*a, False, False))
         t_new = timed(lambda: run(*a, False, True))
         extra = ""
+        if B > 256:  # one 16-wave workgroup per user with LDS staging instead of two 8-wave ones per CU (tuning key 1 = 1)
+            lib.carca_set_tuning(1, 1)
+            t_16 = timed(lambda: run(*a, False, True))
+            lib.carca_set_tuning(1, 0)
+            extra = f"   one staged 16-wave workgroup per CU {t_16 * 1e6:8.1f} us"
         if B <= 256:  # the 16-wave workgroups without LDS staging (tuning key 7)
             lib.carca_set_tuning(7, 1)
             t_ns = timed(lambda: run(*a, False, True))
@@ -85,9 +90,9 @@ for B in [int(b) for b in os.environ.get("BS", "128,256,512,1024,4096").split(",
 NAMES = ["start", "ids in", "A barrier passed", "B done", "end", "B weights in", "LN done", "job: operands", "job: Q proj", "job: scores",
          "job: softmax", "C barrier passed", "at A barrier"]
 if os.environ.get("STAMPS", "1") != "0":
-    for dbg in [int(x) for x in os.environ.get("DBG", "0,1,2,4,6,8,15").split(",")]:
+    for dbg in [int(x) for x in os.environ.get("DBG", "0,2,4,16,22").split(",")]:
         lib.carca_set_tuning(5, dbg)
-        for B, lengths in ((128, "full"),) if dbg else ((128, "full"), (128, "uniform"), (1024, "full")):
+        for B, lengths in ((128, "full"), (1024, "full")) if dbg else ((128, "full"), (128, "uniform"), (1024, "full")):
             a = inputs(B, lengths)
             for _ in range(5):
                 run(*a, False, True)
