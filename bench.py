@@ -218,23 +218,18 @@ def main():
     fl = flops_per_user(c)
 
 
-    # hipEvent_t quadruples handed to carca_forward: the first pair is bound to the feature GEMM's own dispatch on the
-    # launch stream in every timed step (hipExtLaunchKernel: the kernel's start / end, nothing extra queued), the second
-    # pair is recorded around the scoring kernel
-    pool = [[ops.HipEvent() for _ in range(4)] for _ in range(args.steps)]
+    # Eight hipEvent_t per timed step, handed to carca_forward: pairs BOUND to the dispatch packets (hipExtLaunchKernel:
+    # the kernel's own start / end on the launch stream, nothing extra queued -- an event RECORD would be a barrier packet
+    # of ~6 us between two kernels) of the feature GEMM, the scoring kernel, the first SelfAttentionBlock and the joint
+    # GEMM.  Every timed step carries them: the roofline entries below are measured live, inside the timed region.
+    pool = [[ops.HipEvent() for _ in range(8)] for _ in range(args.steps)]
     used = []
-    ca_pool = [[ops.HipEvent() for _ in range(4)] for _ in range(10)]
-    ca_used = []
 
-    # An event RECORD is a barrier packet of its own: ~6 us of GPU time between two kernels (kernel trace).  The timed
-    # steps therefore carry only the kernel-bound pair of the roofline contract (the feature GEMM, every step); the
-    # scoring kernel is timed with records in a short untimed pass afterwards.
-    def step(record, which="feat"):
+    def step(record):
         if record:
-            evs = pool[len(used)] if which == "feat" else ca_pool[len(ca_used)]
-            (used if which == "feat" else ca_used).append(evs)
-            h = [e.handle for e in evs]
-            ops.set_fused_events(h[:2] + [None, None] if which == "feat" else [None, None] + h[2:])
+            evs = pool[len(used)]
+            used.append(evs)
+            ops.set_fused_events([e.handle for e in evs])
         y = model(profile=profile, targets=[target])
         ops.set_fused_events(None)
         return y
@@ -279,10 +274,6 @@ def main():
         elapsed = time.perf_counter() - t0
         gpu_span_ms = g0.elapsed_time(g1)
         host_issue_ms = 1e3 * (host_done[-1] - t0)
-    with torch.no_grad():  # (untimed) scoring-kernel durations for `roofline_cross_score`
-        for _ in range(len(ca_pool)):
-            step(True, "cross")
-        fence()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -344,21 +335,43 @@ def main():
                                                       graphed=True)
 
     feat_ms = sorted(e[0].elapsed_ms(e[1]) for e in used)
-    ca_ms = sorted(e[2].elapsed_ms(e[3]) for e in ca_used)
+    ca_ms = sorted(e[2].elapsed_ms(e[3]) for e in used)
+    sa_ms = sorted(e[4].elapsed_ms(e[5]) for e in used)
+    joint_ms = sorted(e[6].elapsed_ms(e[7]) for e in used)
     feat_avg = sum(feat_ms) / len(feat_ms)
     ca_avg = sum(ca_ms) / len(ca_ms)
 
-    traffic = None  # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/README.md)
-    tpath = os.path.join(ROOT, "profiles", "r01_l_feat_gemm_traffic.json")
-    if c["B"] == C2["B"] and os.path.exists(tpath):
-        with open(tpath) as fh:
-            traffic = json.load(fh)["hbm_bytes_per_launch"]
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
+    # comes from the NEWEST committed PMC passes (tools/profile_round.sh -> profiles/*_feat_gemm_traffic.json) and is
+    # only reported while the kernel's source is the one those passes measured (sha256 of csrc/gemm.hip in the file);
+    # after any change to the kernel it reads null until the passes are re-run.
+    traffic, traffic_note = None, "no committed PMC pass"
+    import glob
+    import hashlib
+
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_feat_gemm_traffic.json")))
+    if c["B"] == C2["B"] and tfiles:
+        with open(tfiles[-1]) as fh:
+            tj = json.load(fh)
+        with open(os.path.join(ROOT, "carca_replication_amd", "csrc", "gemm.hip"), "rb") as fh:
+            src_hash = hashlib.sha256(fh.read()).hexdigest()
+        if tj.get("gemm_hip_sha256") == src_hash:
+            traffic = tj["hbm_bytes_per_launch"]
+            traffic_note = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
+                            "separate passes, profiles/%s (same csrc/gemm.hip); algorithmic bytes 359 MB"
+                            % os.path.basename(tfiles[-1]))
+        else:
+            traffic_note = ("profiles/%s was measured on another version of csrc/gemm.hip: stale, not reported"
+                            % os.path.basename(tfiles[-1]))
 
     if rank == 0:
         users = world * c["B"] * args.steps
         value = users / elapsed
         feat_tflops = c["B"] * fl["feat"] / (feat_avg * 1e-3) / 1e12
         ca_tflops = c["B"] * fl["ca"] / (ca_avg * 1e-3) / 1e12
+        sa_avg, joint_avg = sum(sa_ms) / len(sa_ms), sum(joint_ms) / len(joint_ms)
+        sa_tflops = c["B"] * (fl["sa"] / c["n_blocks"]) / (sa_avg * 1e-3) / 1e12
+        joint_flops = c["B"] * (c["L"] + c["N"]) * 2 * (c["d"] + c["g"]) * c["d"]
         out = {
             "metric": "scored users/sec (1+100 candidates), CARCA eval forward",
             "value": value, "unit": "users/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -376,19 +389,27 @@ def main():
             "roofline": {"kernel": "gemm_rows_cu_kernel (384x96 tile, one block per CU), feature GEMM launch (AllEmbedding feats_embed, carca.py:86)",
                          "bound": "mfma", "achieved": feat_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
-                                         "WRITE_SIZE, separate passes, profiles/r01_l_feat_gemm_traffic.json; algorithmic "
-                                         "bytes 359 MB",
+                         "traffic_note": traffic_note,
                          "avg_ms": feat_avg, "min_ms": feat_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["feat"] / 1e9},
-            "roofline_cross_score": {"kernel": "cross_score_kernel_w16<96,32,3,16> (final norm + CrossAttentionBlock)",
+            "roofline_cross_score": {"kernel": "cross_fold_kernel<96,32,3,16,staged> (final norm + CrossAttentionBlock, eval mode)",
                                      "bound": "mfma", "achieved": ca_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                                      "unit": "TFLOP/s", "frac": ca_tflops / PEAK_F32_MFMA_TFLOPS, "avg_ms": ca_avg,
                                      "min_ms": ca_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["ca"] / 1e9,
-                                     "note": "timed with its own events in an untimed pass after the timed region; at "
-                                             "B=128 the launch is one latency chain per workgroup (two workgroups per user); "
-                                             "33-39 % at B = 512-4096 with two 8-wave workgroups per CU (tools/scale_attn.py); the 16-wide MFMA tiles execute 1.4x "
-                                             "the algorithmic flops (slots 50->64, targets 101->112, d 90->96, d/H 30->32), "
-                                             "so 71 % is this tiling's ceiling"},
+                                     "note": "the kernel's own dispatch, every timed step.  Algorithmic flops = SURVEY 8d's CA "
+                                             "per user (2 N d^2 + 4 L d^2 + 4 N L d + 2 N d) x users; the kernel executes "
+                                             "fewer: decoder.ffn is folded into the value projection (no V, no P.V) and "
+                                             "leading pad slots of the left-padded profiles are not projected or scored "
+                                             "(exact: their weights are 0).  At B = 128 one launch is one latency chain per "
+                                             "workgroup (two per user); B-scaling in profiles/"},
+            "roofline_sa_block": {"kernel": "sa_block_kernel_w16<96,32,3> (one SelfAttentionBlock, first of %d)" % c["n_blocks"],
+                                  "bound": "mfma", "achieved": sa_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": sa_tflops / PEAK_F32_MFMA_TFLOPS, "avg_ms": sa_avg, "min_ms": sa_ms[0],
+                                  "algorithmic_gflop_per_launch": c["B"] * fl["sa"] / c["n_blocks"] / 1e9},
+            "roofline_joint_gemm": {"kernel": "gemm_rows_kernel (AllEmbedding.joint_embed, carca.py:89)", "bound": "mfma",
+                                    "achieved": joint_flops / (joint_avg * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": joint_flops / (joint_avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                    "avg_ms": joint_avg, "min_ms": joint_ms[0],
+                                    "algorithmic_gflop_per_launch": joint_flops / 1e9},
         }
         if train_info is not None:
             out["train"] = train_info

@@ -222,7 +222,8 @@ class ForwardDesc(C.Structure):
                 ("N", C.c_int32 * MAX_GROUPS), ("p_normed", _fp), ("fold_wc", _fp), ("fold_bias", _fp),
                 ("fold_ldwc", C.c_int32), ("x_out", _fp * MAX_BLOCKS), ("sa_save", SaSave * MAX_BLOCKS), ("ca_save", CaSave),
                 ("save_blocks", C.c_int32), ("save_cross", C.c_int32), ("p_embed", C.c_float), ("p_block", C.c_float),
-                ("p_cross", C.c_float), ("seed", C.c_uint64), ("m_embed", _fp), ("seed_offset", C.c_void_p)]
+                ("p_cross", C.c_float), ("seed", C.c_uint64), ("m_embed", _fp), ("seed_offset", C.c_void_p),
+                ("n_events", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/carca_hip.h declares

@@ -235,8 +235,13 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
       return CARCA_ERR_UNSUPPORTED;
     }
     if (rc != CARCA_OK) return rc;
+    if (ev && D->n_events >= 8 && ev[6] && ev[7]) carca_arm_launch_events(ev[6], ev[7]);
     CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
                               D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_JOINT, stream_));
+    {
+      hipEvent_t l0, l1;
+      (void)carca_take_launch_events(&l0, &l1);  // (a joint product on a kernel that does not take events: leave them unset)
+    }
   } else {
     // folded embedding: e0 = sqrt(d) * E[ids] W_jz^T + bias_c ; e = ([attrs ; ctx] W_c^T + e0 (+ pos)) * mask
     CARCA_CHECK_ARG(D->fold_bias && D->fold_ldwc >= D->n_attrs + D->n_ctx, "forward: folded weights malformed");
@@ -270,6 +275,7 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
   for (int i = 0; i < D->n_blocks; ++i) {
     float* y = D->x_out[i] ? D->x_out[i] : D->x_work[i & 1];
     CarcaDropout dr{D->p_block, D->seed, (uint32_t)(4 * i), D->seed_offset};
+    if (i == 0 && ev && D->n_events >= 8 && ev[4] && ev[5]) carca_arm_launch_events(ev[4], ev[5]);
     CARCA_TRY(carca_sa_block_fwd(x, D->ld_e, D->segs[0].ids, y, D->ld_e, D->B, D->L, D->d, D->H, &D->sa[i],
                                  D->sa_residual[i], D->save_blocks ? &D->sa_save[i] : nullptr,
                                  D->p_block > 0.f ? &dr : nullptr, stream_));

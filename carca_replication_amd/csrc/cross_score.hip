@@ -238,10 +238,13 @@ __device__ __forceinline__ void dma16(const float* base, int lane_elem_off, int 
                                            lane_elem_off * 4, uniform_elem_off * 4, 0, 0);
 }
 
-// Phase B job = one feature tile x a PAIR of 16-slot tiles: the weight fragments are fetched once (by the caller, so
-// that the first job's can be requested before phase A) and feed two independent accumulator chains.
+// Phase B job = one feature tile x ALL slot tiles of the re-based profile (2 or 4 of them: tiles are projected in
+// pairs): the tile's weight fragments are fetched ONCE per workgroup (by the caller, so that the first job's can be
+// requested before phase A) and feed that many independent accumulator chains.
 //   K:  Ks[16 st + ln][16 ft + 4 mq + r] = sum_k W_K[16 ft + 4 mq + r][k] X[16 st + ln][k] + b_K    (A = W_K, Bt = rows)
 //   u:  Ut[h = ln][16 st + 4 mq + r]     = sum_k X[16 st + 4 mq + r][k] wu[h][k] + cu[h]            (A = rows, Bt = wu)
+// Tiles beyond the profile are computed and stored like the others (their rows are zeros; phase C scores key tiles in
+// pairs too and masks them).
 template <int DPI>
 struct FoldBW {
   f32x4 wf[DPI / 16];
@@ -262,42 +265,43 @@ __device__ __forceinline__ void fold_b_load(FoldBW<DPI>& w, const float* __restr
   w.cu1 = gload1(cu, lane & 15);
   w.bk4 = gload4s(bk, 4 * (lane >> 4), 16 * t);
 }
+template <int DPI, int NCH, bool ISU>
+__device__ __forceinline__ void fold_b_chains(const FoldBW<DPI>& w, const float* xs, int si, float* Ks, int so, float* Ut,
+                                              int ft, int lane, int nh) {
+  const int ln = lane & 15, mq = lane >> 4;
+  const float* x0 = xs + ln * si + 4 * mq;
+  f32x4 acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) acc[c] = ISU ? f32x4{w.cu1, w.cu1, w.cu1, w.cu1} : w.bk4;
+#pragma unroll
+  for (int kg = 0; kg < DPI / 16; ++kg) {
+    f32x4 x[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) x[c] = lds4(x0 + 16 * c * si + 16 * kg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        acc[c] = ISU ? mfma16(x[c][s], w.wf[kg][s], acc[c]) : mfma16(w.wf[kg][s], x[c][s], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (ISU) {
+      if (ln < nh) *reinterpret_cast<f32x4*>(Ut + ln * ATT_SK + 16 * c + 4 * mq) = acc[c];
+    } else {
+      *reinterpret_cast<f32x4*>(Ks + (16 * c + ln) * so + 16 * ft + 4 * mq) = acc[c];
+    }
+  }
+}
 template <int DPI>
 __device__ __forceinline__ void fold_b_job(const FoldBW<DPI>& w, const float* xs, int si, float* Ks, int so, float* Ut,
-                                           int ft, int nf, int st0, int lane, int nh) {
-  const int ln = lane & 15, mq = lane >> 4;
-  const float* x0 = xs + (16 * st0 + ln) * si + 4 * mq;
-  const float* x1 = x0 + 16 * si;  // (the pair's second tile, computed and stored even beyond the profile: its rows are
-                                   // zeros there, and phase C scores key tiles in pairs too, masked)
-  f32x4 acc0, acc1;
-  if (ft == nf) {
-    acc0 = acc1 = f32x4{w.cu1, w.cu1, w.cu1, w.cu1};
-#pragma unroll
-    for (int kg = 0; kg < DPI / 16; ++kg) {
-      const f32x4 a0 = lds4(x0 + 16 * kg), a1 = lds4(x1 + 16 * kg);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc0 = mfma16(a0[s], w.wf[kg][s], acc0);
-        acc1 = mfma16(a1[s], w.wf[kg][s], acc1);
-      }
-    }
-    if (ln < nh) {
-      *reinterpret_cast<f32x4*>(Ut + ln * ATT_SK + 16 * st0 + 4 * mq) = acc0;
-      *reinterpret_cast<f32x4*>(Ut + ln * ATT_SK + 16 * st0 + 16 + 4 * mq) = acc1;
-    }
+                                           int ft, int nf, int npair, int lane, int nh) {
+  if (ft == nf) {  // (uniform)
+    if (npair > 1) fold_b_chains<DPI, 4, true>(w, xs, si, Ks, so, Ut, ft, lane, nh);
+    else fold_b_chains<DPI, 2, true>(w, xs, si, Ks, so, Ut, ft, lane, nh);
   } else {
-    acc0 = acc1 = w.bk4;
-#pragma unroll
-    for (int kg = 0; kg < DPI / 16; ++kg) {
-      const f32x4 b0 = lds4(x0 + 16 * kg), b1 = lds4(x1 + 16 * kg);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc0 = mfma16(w.wf[kg][s], b0[s], acc0);
-        acc1 = mfma16(w.wf[kg][s], b1[s], acc1);
-      }
-    }
-    *reinterpret_cast<f32x4*>(Ks + (16 * st0 + ln) * so + 16 * ft + 4 * mq) = acc0;
-    *reinterpret_cast<f32x4*>(Ks + (16 * st0 + 16 + ln) * so + 16 * ft + 4 * mq) = acc1;
+    if (npair > 1) fold_b_chains<DPI, 4, false>(w, xs, si, Ks, so, Ut, ft, lane, nh);
+    else fold_b_chains<DPI, 2, false>(w, xs, si, Ks, so, Ut, ft, lane, nh);
   }
 }
 
@@ -321,8 +325,8 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   float* Ps = lds;                    // [64][SI]  final-normed profile, re-based at the first real slot
   float* Ks = Ps + ATT_LMAX * G::SI;  // [64][SO]
   float* Ut = Ks + ATT_LMAX * G::SO;  // [NH][ATT_SK]  u^T
-  float* Km = Ut + NH * ATT_SK;       // [64] additive key mask: 0 real key, FOLD_NEG pad / beyond the profile
-  float* Yp = Km + ATT_LMAX;          // [CROSS_TPR][NH][16] per-head partial logits
+  float* Km = Ut + NH * ATT_SK;       // [64] additive key mask: 0 real key, FOLD_NEG pad / beyond the profile; then the slot mask (2 words)
+  float* Yp = Km + ATT_LMAX + 4;      // [CROSS_TPR][NH][16] per-head partial logits
   float* Ot = Yp + CROSS_TPR * NH * 16;               // STAGE: [TPR][NKG][64 lanes x 4] target tiles, fragment order
   float* Bq = Ot + FOLD_TPR_S * G::NKG * 256;         // STAGE: b_Q [DPO], then decoder.ffn.weight [DPI]
   float* Fw = Bq + 256;
@@ -335,34 +339,6 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, mq = lane >> 4;
   const size_t ubase = (size_t)u * L;
-
-  // the profile's ids first: everything requested after them returns behind them (loads complete in order)
-  // (a buffer load like the ones that follow: hipcc counts on in-order return only among loads of one kind, and waited
-  // for all but three of the fifteen requests behind a global_load here; unconditional: see FoldBW)
-  const int32_t my_id = gload1i(a.p_ids + ubase, lane < L ? lane : L - 1);
-
-  // ---- A0: all requests of the prologue -------------------------------------------------------------------------
-  // Rows travel two per wave instruction: lane (half = row of the pair, c4 = 16-byte column group) loads / normalises /
-  // stores four contiguous features -- a third of the instructions of a row per wave with a value per lane.
-  constexpr int PPW = (ATT_LMAX / 2) / NW;  // row pairs per wave
-  const int half = lane >> 5, c4 = lane & 31;
-  const bool col_ok = 4 * c4 < DPI;
-  const float* p_user = a.p_raw + ubase * a.ldp;  // (per-user bases: lane offsets stay small whatever B is)
-  f32x4 rv[PPW];
-#pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int r = 2 * (wave + NW * j) + half;
-    rv[j] = gload4(p_user, (r < L ? r : 0) * a.ldp + (col_ok ? 4 * c4 : 0));
-  }
-  // (no request of the prologue sits under a branch: behind one, hipcc no longer knows how many loads are in flight and
-  // turns the counted wait for the FIRST of them into a wait for nearly all; without a final norm b_Q stands in)
-  const f32x4 lnw = gload4(a.ln_w ? a.ln_w : a.bq, col_ok ? 4 * c4 : 0);
-  const f32x4 lnb = gload4(a.ln_w ? a.ln_b : a.bq, col_ok ? 4 * c4 : 0);
-  // phase B jobs: job j = (feature tile j % (NF + 1) [NF = the u tile], slot-tile pair j / (NF + 1)); this wave's first
-  // one gets its weight fragments now
-  constexpr int NFB = G::NF + 1;
-  FoldBW<DPI> bw;
-  fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, wave % NFB, G::NF, lane, a.dbg & 16);
 
   // tiles of this workgroup
   const int all_tiles = a.tile_start[a.ngroups];
@@ -434,35 +410,76 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     return g.ids[(size_t)u * g.N + min(n, g.N - 1)];  // (unconditional load; masked with tile_id_ok where it is stored)
   };
   const Job job0 = decode(wave, t_lo);  // this wave's first job of the first round, decoded off the critical path
+  // Roles (STAGE): the last NDMA waves only REQUEST what phase C reads -- W_Q, the round's target tiles, b_Q, the ffn
+  // weight: 62 LDS-DMA instructions, in flight from the kernel's first cycles until the barrier that ends phase B; a CU
+  // takes in ~12-20 B per cycle whatever the source, so the sooner the better -- and touch nothing else: a wave that
+  // also uses ordinary loads makes hipcc wait vmcnt(0), DMA included, at their first use.  The other NLN waves run the
+  // prologue proper.  Without STAGE every wave does.
+  constexpr int NDMA = STAGE ? 3 : 0, NLN = NW - NDMA;
+  const bool dma_wave = STAGE && wave >= NLN;
+  constexpr int PPW = (ATT_LMAX / 2 + NLN - 1) / NLN;  // row pairs per wave
+  constexpr int NFB = G::NF + 1;                        // phase B jobs: feature tiles of K, then the u tile
+  static_assert(!STAGE || NFB <= NLN, "every phase B job needs a wave of the prologue");
+  const int half = lane >> 5, c4 = lane & 31;
+  const bool col_ok = 4 * c4 < DPI;
+  FoldBW<DPI> bw;
   f32x4 qpre[G::NKG];
   int idpre = 0;
   bool have_pre = false;
-  int tile_id0 = 0;
-  if constexpr (STAGE) {
-    tile_id0 = load_tile_id(t_lo, min(TPR, t_hi - t_lo));
-  } else if constexpr (DPI <= 96) {
-    // (d > 96: eight fragments per target row and per weight tile; the prefetch would not fit 128 registers)
-    // requested by every wave, job or not (no loads under a branch, see above): a wave without a job fetches job 0's
-    const bool pre_ok = wave < min(TPR, t_hi - t_lo) * NH;
-    const Job c = decode(pre_ok ? wave : 0, t_lo);
+  unsigned long long pmask = 0;
+  int* Pm = reinterpret_cast<int*>(Km + ATT_LMAX);
+  if (dma_wave) {
+    if constexpr (STAGE) {
+      if constexpr (STAGE_W)
+        if (!(a.dbg & 2))
+          for (int c = wave - NLN; c < G::DPO * DPI / 256; c += NDMA) dma16(a.wq, 4 * lane, 256 * c, Wq + 256 * c);
+      if (!(a.dbg & 4)) stage_tiles(t_lo, min(TPR, t_hi - t_lo), NLN, NDMA);
+      if (wave == NW - 1 && lane < G::DPO / 4) dma16(a.bq, 4 * lane, 0, Bq);
+      if (wave == NW - 1 && lane < DPI / 4) dma16(a.ffn_w, 4 * lane, 0, Fw);
+    }
+  } else {
+    // ---- A0: every request of the prologue, none under a branch of its own (behind one, hipcc no longer knows how many
+    // loads are in flight and turns the counted wait for the FIRST of them into a wait for nearly all) --------------
+    // the profile's ids first; a buffer load like the rest: hipcc counts on in-order return only among loads of one kind
+    const int32_t my_id = gload1i(a.p_ids + ubase, lane < L ? lane : L - 1);
+    // Rows travel two per wave instruction: lane (half = row of the pair, c4 = 16-byte column group) loads / normalises /
+    // stores four contiguous features -- a third of the instructions of a row per wave with a value per lane.
+    const float* p_user = a.p_raw + ubase * a.ldp;  // (per-user bases: lane offsets stay small whatever B is)
+    f32x4 rv[PPW];
 #pragma unroll
-    for (int kg = 0; kg < G::NKG; ++kg) qpre[kg] = gload4s(c.o, c.lrow * a.ldo + 4 * mq, 16 * kg);
-    idpre = gload1i(c.ids, c.lrow);
-    have_pre = pre_ok;
-  }
-  const unsigned long long pmask = __ballot(lane < L && my_id != 0);
-  // first real slot; keys are re-based there
-  const int s0 = pmask ? (int)__builtin_ctzll(pmask) : L;
-  const int nk = L - s0;
-  const int LTc = (nk + 15) >> 4;
-  CF_STAMP(1);
+    for (int j = 0; j < PPW; ++j) {
+      const int r = 2 * (wave + NLN * j) + half;
+      rv[j] = gload4(p_user, (r < L ? r : 0) * a.ldp + (col_ok ? 4 * c4 : 0));
+    }
+    const f32x4 lnw = gload4(a.ln_w ? a.ln_w : a.bq, col_ok ? 4 * c4 : 0);  // (without a final norm b_Q stands in)
+    const f32x4 lnb = gload4(a.ln_w ? a.ln_b : a.bq, col_ok ? 4 * c4 : 0);
+    // this wave's phase B job (feature tile `wave`) gets its weight fragments now
+    fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, min(wave, NFB - 1), G::NF, lane, a.dbg & 16);
+    int tile_id0 = 0;
+    if constexpr (STAGE) {
+      tile_id0 = load_tile_id(t_lo, min(TPR, t_hi - t_lo));
+    } else if constexpr (DPI <= 96) {
+      // (d > 96: eight fragments per target row and per weight tile; the prefetch would not fit 128 registers)
+      // requested by every wave, job or not: a wave without a job fetches job 0's
+      const bool pre_ok = wave < min(TPR, t_hi - t_lo) * NH;
+      const Job c = decode(pre_ok ? wave : 0, t_lo);
+#pragma unroll
+      for (int kg = 0; kg < G::NKG; ++kg) qpre[kg] = gload4s(c.o, c.lrow * a.ldo + 4 * mq, 16 * kg);
+      idpre = gload1i(c.ids, c.lrow);
+      have_pre = pre_ok;
+    }
+    pmask = __ballot(lane < L && my_id != 0);
+    // first real slot; keys are re-based there
+    const int s0 = pmask ? (int)__builtin_ctzll(pmask) : L;
+    const int nk = L - s0;
+    const int LTc = (nk + 15) >> 4;
+    CF_STAMP(1);
 
-  // ---- A1: final LayerNorm of the row pairs that hold a slot of the re-based profile, stored at that slot ---------------
-  {
+    // ---- A1: final LayerNorm of the row pairs that hold a slot of the re-based profile, stored at that slot -------------
     const float inv_d = 1.0f / (float)d;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-      const int pr = wave + NW * j;
+      const int pr = wave + NLN * j;
       if ((2 * pr + 1 >= s0 || a.p_normed) && 2 * pr < L) {  // (uniform; every row when the normed profile is an output)
         f32x4 v = rv[j];
 #pragma unroll
@@ -480,60 +497,44 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
         rv[j] = v;
       }
     }
-    if constexpr (STAGE) {
-      // The prefetched registers count as consumed from here on (empty asm statements): hipcc answers "an ordinary
-      // load's result is used while an LDS-DMA is outstanding" with s_waitcnt vmcnt(0), and phase B must not wait for
-      // the DMA requested below.
-      CF_STAMP(6);
-#pragma unroll
-      for (int kg = 0; kg < DPI / 16; ++kg) asm volatile("" : "+v"(bw.wf[kg]));
-      asm volatile("" : "+v"(bw.bk4), "+v"(bw.cu1), "+v"(tile_id0));
-      CF_STAMP(5);
+    CF_STAMP(6);
+    if constexpr (STAGE)
       if (tid < TPR * 16) Ids[tid] = tile_id_ok ? tile_id0 : 0;
-    }
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-      const int r = 2 * (wave + NW * j) + half, t = r - s0;
+      const int r = 2 * (wave + NLN * j) + half, t = r - s0;
       if (col_ok && r < L && t >= 0) *reinterpret_cast<f32x4*>(Ps + t * G::SI + 4 * c4) = rv[j];
       if (a.p_normed && part == 0 && r < L && 4 * c4 < a.ldp) *reinterpret_cast<f32x4*>(a.p_normed + (ubase + r) * a.ldp + 4 * c4) = rv[j];
     }
     // rows of the (even number of) key tiles phase B reads beyond the profile: zeros, not LDS garbage
-    for (int t = nk + 2 * wave + half; t < min(ATT_LMAX, 32 * ((LTc + 1) >> 1)); t += 2 * NW)
+    for (int t = nk + 2 * wave + half; t < min(ATT_LMAX, 32 * ((LTc + 1) >> 1)); t += 2 * NLN)
       if (col_ok) *reinterpret_cast<f32x4*>(Ps + t * G::SI + 4 * c4) = zero4();
-    if (wave == NW - 1) Km[lane] = (lane < nk && ((pmask >> (lane + s0)) & 1ull)) ? 0.f : FOLD_NEG;
-    // LDS-only barrier, hand-written: the DMA stays in flight across it.  (__syncthreads(), and even a workgroup fence
-    // restricted to LDS, make hipcc wait vmcnt(0) here: an outstanding LDS-DMA counts as a pending LDS write.  Nothing
-    // the DMA writes is read before the __syncthreads() that ends phase B.)
-    CF_STAMP(12);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  }
-  CF_STAMP(2);
-  if constexpr (STAGE) {
-    // Everything phase C reads is requested NOW, behind the loads phases A and B waited for (a CU takes in ~12 B per
-    // cycle whatever the source: rows + phase B's weights were 60 KB, these are another 60) and after the barrier, so
-    // that no wave's arrival there is delayed by the issue; the requests land under phase B's MFMAs.
-    // The issue itself is ~1.3 k cycles per wave when every wave takes a share: the waves WITHOUT a phase B job
-    // (NW - 2 (NF + 1) of them, where there are any) do all of it while the others start their MFMAs.
-    constexpr int NBJ = 2 * NFB;
-    constexpr int DW0 = NW > NBJ ? NBJ : 0, NDW = NW > NBJ ? NW - NBJ : NW;
-    if (wave >= DW0) {
-      if constexpr (STAGE_W)
-        if (!(a.dbg & 2))
-          for (int c = wave - DW0; c < G::DPO * DPI / 256; c += NDW) dma16(a.wq, 4 * lane, 256 * c, Wq + 256 * c);
-      if (!(a.dbg & 4)) stage_tiles(t_lo, min(TPR, t_hi - t_lo), DW0, NDW);
-      if (wave == NW - 1 && lane < G::DPO / 4) dma16(a.bq, 4 * lane, 0, Bq);
-      if (wave == NW - 1 && lane < DPI / 4) dma16(a.ffn_w, 4 * lane, 0, Fw);
+    if (wave == NLN - 1) Km[lane] = (lane < nk && ((pmask >> (lane + s0)) & 1ull)) ? 0.f : FOLD_NEG;
+    if (STAGE && tid == 0) {  // the slot mask, for the waves that did not see the ids
+      Pm[0] = (int)(unsigned)pmask;
+      Pm[1] = (int)(unsigned)(pmask >> 32);
     }
+    CF_STAMP(12);
   }
-  // ---- B: K tiles and the u tiles, two slot tiles per job -----------------------------------------------------------
+  // LDS-only barrier, hand-written: the DMA stays in flight across it.  (__syncthreads(), and even a workgroup fence
+  // restricted to LDS, make hipcc wait vmcnt(0) here: an outstanding LDS-DMA counts as a pending LDS write.  Nothing the
+  // DMA writes is read before the __syncthreads() that ends phase B.)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  CF_STAMP(2);
+  if (dma_wave)
+    pmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(Pm[1]) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane(Pm[0]);
+  const int s0 = pmask ? (int)__builtin_ctzll(pmask) : L;
+  const int nk = L - s0;
+  const int LTc = (nk + 15) >> 4;
+  // ---- B: K tiles and the u tile, every slot tile in one job ------------------------------------------------------------
   {
     const int npair = (LTc + 1) >> 1;
     bool first = true;
-    for (int job = wave; job < NFB * npair; job += NW) {
-      const int pr = job / NFB, ft = job - pr * NFB;
-      if (!first) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, ft, G::NF, lane, a.dbg & 16);
+    for (int job = wave; job < NFB && npair > 0; job += NW) {
+      if (!first) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, job, G::NF, lane, a.dbg & 16);
       first = false;
-      fold_b_job<DPI>(bw, Ps, G::SI, Ks, G::SO, Ut, ft, G::NF, 2 * pr, lane, NH);
+      fold_b_job<DPI>(bw, Ps, G::SI, Ks, G::SO, Ut, job, G::NF, npair, lane, NH);
     }
   }
   __syncthreads();
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
 template <int DPI, int DHP, int NH, bool STAGE>
 constexpr size_t fold_lds_bytes() {
   using G = AttGeom<DPI, DHP, NH>;
-  size_t f = ATT_LMAX * G::SI + ATT_LMAX * G::SO + NH * ATT_SK + ATT_LMAX + CROSS_TPR * NH * 16;
+  size_t f = ATT_LMAX * G::SI + ATT_LMAX * G::SO + NH * ATT_SK + ATT_LMAX + 4 + CROSS_TPR * NH * 16;
   if (STAGE) f += FOLD_TPR_S * G::NKG * 256 + 512 + FOLD_TPR_S * 16 + (DPI <= 96 ? G::DPO * DPI : 0);
   return sizeof(float) * f;
 }

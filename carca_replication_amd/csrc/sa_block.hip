@@ -7,6 +7,7 @@
 //   C2 LayerNorm2 rows; C3 ffn_1 + LeakyReLU(0.01); C4 ffn_2 + s (carca.py:304-316) -> y
 // Rows that are padding (ids == 0) are computed like any other: the reference does not re-mask after a
 // block (carca.py:318), they carry LayerNorm(0) = beta forward and are never attended.
+#include <hip/hip_ext.h>
 #include "attn_common.h"
 #include "../../include/carca_hip.h"
 
@@ -263,8 +264,13 @@ int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, in
   }
   const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);
   const int nparts = (L > 16 && tune != 1 && (tune == 2 || 2 * B <= num_cus)) ? 2 : 1;
-  hipLaunchKernelGGL((sa_block_kernel_w16<DPI, DHP, NH>), dim3(B * nparts), dim3(1024), lds_bytes, stream, x, ldx, ids,
-                     y, ldy, L, d, d / NH, w, residual, sv, dc, site, carca_debug_buffer(), nparts);
+  hipEvent_t e0, e1;
+  if (carca_take_launch_events(&e0, &e1))  // (timing events bound to this dispatch: carca_forward's ev[4], ev[5])
+    hipExtLaunchKernelGGL((sa_block_kernel_w16<DPI, DHP, NH>), dim3(B * nparts), dim3(1024), lds_bytes, stream, e0, e1, 0, x,
+                          ldx, ids, y, ldy, L, d, d / NH, w, residual, sv, dc, site, carca_debug_buffer(), nparts);
+  else
+    hipLaunchKernelGGL((sa_block_kernel_w16<DPI, DHP, NH>), dim3(B * nparts), dim3(1024), lds_bytes, stream, x, ldx, ids,
+                       y, ldy, L, d, d / NH, w, residual, sv, dc, site, carca_debug_buffer(), nparts);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

@@ -1026,7 +1026,8 @@ class CARCA(_PackedModule, Model):
             D.m_embed = m_embed.data_ptr() if m_embed is not None else None
             train.update(es=plan["es"], zq=plan["zq"], blocks=blocks, enc_out=x_prev, p_normed=p_normed, csave=csave,
                          cw=D.ca, m_embed=m_embed, p_emb=p_emb, keep=(keep, D))
-        ev = (C.c_void_p * 4)(*events) if events is not None else None
+        ev = (C.c_void_p * len(events))(*events) if events is not None else None
+        D.n_events = len(events) if events is not None else 0
         _lib.check(_lib.load().carca_forward(C.byref(D), ev, ops._stream()), "forward")
         return ys
 

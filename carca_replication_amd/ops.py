@@ -26,7 +26,8 @@ def set_stage_events(ev) -> None:
     _stage_events = ev
 
 
-# raw hipEvent_t handles [feat0, feat1, cross0, cross1] for the one-call forward (bench.py), or None
+# raw hipEvent_t handles [feat0, feat1, cross0, cross1(, sa0, sa1, joint0, joint1)] for the one-call forward (bench.py),
+# or None; entries may be None (CarcaForwardDesc.n_events)
 _fused_events = None
 
 

@@ -535,6 +535,9 @@ typedef struct CarcaForwardDesc {
   uint64_t seed;
   uint8_t* m_embed;
   const uint64_t* seed_offset; /* device or NULL, see CarcaDropout */
+  int32_t n_events;            /* entries of carca_forward's `ev` array: 0 or 4 = the four described there, 8 = four more:
+                                * ev[4], ev[5] bound to the FIRST SelfAttentionBlock's dispatch, ev[6], ev[7] to the joint
+                                * GEMM's (AllEmbedding.joint_embed, carca.py:89) */
 } CarcaForwardDesc;
 int carca_forward(const CarcaForwardDesc* desc /*host*/, void* const* ev /*4 hipEvent_t or NULL*/, void* stream);
 /* Event helpers so that a host language without a HIP binding can time kernels on the launch stream. */

@@ -54,6 +54,9 @@ t = {"kernel": "gemm_rows_cu_kernel (feature GEMM launch, grid 255 x 768)",
      "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM), WRITE_SIZE exact, KiB x1024",
      "read_bytes": sum(fe) / len(fe) * 2 * 1024, "write_bytes": sum(wr) / len(wr) * 1024, "algorithmic_bytes": alg}
 t["hbm_bytes_per_launch"] = t["read_bytes"] + t["write_bytes"]
+import hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(out)))
+t["gemm_hip_sha256"] = hashlib.sha256(open(os.path.join(root, "carca_replication_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
 json.dump(t, open(os.path.join(out, "feat_gemm_traffic.json"), "w"), indent=1)
 print(json.dumps(t))
 PY
