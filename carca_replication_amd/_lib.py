@@ -161,7 +161,7 @@ class CrossBwdGroup(C.Structure):
 
 
 class AdamTensor(C.Structure):
-    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("n", C.c_int64)]
+    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("n", C.c_int64), ("row_mask", _fp), ("row_len", C.c_int64)]
 
 
 class SaBwdDesc(C.Structure):
@@ -274,6 +274,9 @@ SIGNATURES = {
     "carca_embed_bwd": (_i, [C.POINTER(EmbedBwdDesc), _fp]),
     "carca_adam_step": (_i, [C.POINTER(AdamTensor), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i,
                         _fp]),
+    "carca_mark_rows": (_i, [_fp, C.c_int64, _fp, C.c_int64, _fp]),
+    "carca_zero_rows": (_i, [_fp, C.c_int64, _i, C.POINTER(_fp), C.POINTER(C.c_int64), _i, _fp]),
+    "carca_concat_ids": (_i, [C.POINTER(_fp), C.POINTER(C.c_int64), _i, _fp, _fp]),
     "carca_build_eval_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,
                                     _fp]),
     "carca_build_train_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,

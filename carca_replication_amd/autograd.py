@@ -33,6 +33,58 @@ def _zeros_like_params(params, extra: int = 0):
     return [flat[o: o + p.numel()].view(p.shape) for o, p in zip(offs, params)], flat[total:]
 
 
+BIG_TABLE_BYTES = 64 * 2 ** 20  # embedding tables above this keep ONE gradient buffer, cleared row-wise (see below)
+
+
+def _grad_buffers(model, params, extra: int, id_lists):
+    """The backward's gradient storage: (views, tail, after) like _zeros_like_params, plus a callable to run once the
+    pass is issued.  A model with an embedding table of 64 MB or more (BASELINE config 4: 1 M items x 128 = 512 MB)
+    keeps ONE flat buffer across steps, the big tables last in it: every step zero-fills the small front (dense
+    parameters + staging areas) and only the table ROWS the previous step's scatter-add touched (carca_zero_rows over
+    that step's ids, which `after` records with carca_concat_ids) -- not 512 MB.  Falls back to a fresh zero-filled
+    buffer per step when there is no such table, when the ids are unknown, or when a previous gradient still lives in
+    the cached buffer (accumulation without zero_grad(set_to_none=True))."""
+    big = [i for i, p in enumerate(params) if p.dim() == 2 and p.numel() * p.element_size() >= BIG_TABLE_BYTES]
+    if not big or id_lists is None:
+        views, tail = _zeros_like_params(params, extra)
+        return views, tail, (lambda: None)
+    c = model.__dict__.get("_grad_cache")
+    key = (tuple((p.data_ptr(), tuple(p.shape)) for p in params), extra, tuple(t.numel() for t in id_lists))
+    if c is not None and (c["key"] != key or any(
+            p.grad is not None and p.grad.untyped_storage().data_ptr() == c["flat"].untyped_storage().data_ptr()
+            for p in params)):
+        c = None  # other shapes, or the cached buffer still holds gradients somebody is accumulating into
+        model.__dict__.pop("_grad_cache", None)
+    small = [i for i in range(len(params)) if i not in big]
+    if c is None:
+        offs, total = {}, 0
+        for i in small + big:  # the dense parameters first (in parameter order: dist._shared_flat walks them), tables last
+            if i == big[0]:
+                total += (extra + 3) // 4 * 4
+                front = total
+            offs[i] = total
+            total += (params[i].numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        small_total = front - (extra + 3) // 4 * 4
+        c = dict(key=key, flat=flat, offs=offs, front=front, small_total=small_total,
+                 dirty=torch.zeros(sum(t.numel() for t in id_lists), dtype=torch.int32, device=params[0].device),
+                 fresh=True)
+        model.__dict__["_grad_cache"] = c
+    flat = c["flat"]
+    if not c["fresh"]:
+        flat[: c["front"]].zero_()
+        for i in big:
+            ops.zero_rows(flat[c["offs"][i]: c["offs"][i] + params[i].numel()].view(params[i].shape), [c["dirty"]])
+    c["fresh"] = False
+    views = [flat[c["offs"][i]: c["offs"][i] + p.numel()].view(p.shape) for i, p in enumerate(params)]
+    tail = flat[c["small_total"]: c["front"]]
+
+    def after():
+        ops.concat_ids(id_lists, c["dirty"])
+
+    return views, tail, after
+
+
 class _Tail:
     """Hands out zeroed slices of the flat buffer's tail (16-byte aligned sizes)."""
 
@@ -240,7 +292,9 @@ class _CarcaFn(torch.autograd.Function):
             dpi_b = ops.padded_dims(d, blk.attn.H)[0]
             bpks.append(plan.add_attn(blk.attn, [ops.PackItem(blk.ffn_1.weight[:, :, 0], dpi_b, dpi_b, transposed=True),
                                                  ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi_b, dpi_b, transposed=True)]))
-        grads, tail_buf = _zeros_like_params(params, plan.staging_floats())
+        # (every id a scatter-add of this pass can touch: known for the embeddings with an item table)
+        id_lists = [sg[0] for sg in st["segs"]] if hasattr(emb, "items_embed") and len(st["segs"]) <= 4 else None
+        grads, tail_buf, after_pass = _grad_buffers(model, params, plan.staging_floats(), id_lists)
         plan.build(dev, _Tail(tail_buf))
         gbp = {id(p): g for p, g in zip(params, grads)}
         ys = ctx.saved_tensors
@@ -278,6 +332,7 @@ class _CarcaFn(torch.autograd.Function):
         wg.launch()
         plan.unpack(gbp)  # head-padded staging areas -> the real WQ / WK / WV / ffn gradients
         emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi)
+        after_pass()
         ctx.st = None
         return (None, None, None) + tuple(grads)
 

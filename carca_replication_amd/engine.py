@@ -37,8 +37,26 @@ def train_step(model, optim, batch, sharded: bool = False) -> torch.Tensor:
     loss = _forward_backward(model, optim, batch, sharded)
     if sharded:
         cdist.allreduce_gradients(model.parameters(), sparse_rows=_sparse_tables(model, p_x, o_x))
+    _mark_touched_rows(model, optim, p_x, o_x, sharded)
     optim.step()
     return loss
+
+
+def _mark_touched_rows(model, optim, p_x, o_x, sharded: bool) -> None:
+    """Big item tables: tell the optimizer which rows this step's gradient can touch (optim.Adam.mark_rows: rows never
+    touched are skipped, bit-exactly).  With users sharded over ranks the rows are the union over ranks -- every rank's
+    ids, gathered -- because the exchanged row gradients land in every replica."""
+    tables = _sparse_tables(model, p_x, o_x)
+    if not tables or not hasattr(optim, "mark_rows"):
+        return
+    for w, ids in tables.items():
+        if sharded and cdist.world_size() > 1:
+            import torch.distributed as dist
+
+            gathered = [torch.empty_like(ids) for _ in range(cdist.world_size())]
+            dist.all_gather(gathered, ids.contiguous())
+            ids = torch.cat(gathered)
+        optim.mark_rows(w, ids)
 
 
 def _forward_backward(model, optim, batch, sharded: bool) -> torch.Tensor:
@@ -100,6 +118,9 @@ class GraphedTrainStep:
         # own tensors and hand them back to the parameters before each optimizer step.
         self.params = [p for p in model.parameters() if p.grad is not None]
         self.grads = [p.grad for p in self.params]
+        # (a model with a big item table: the captured kernels hold pointers into the gradient cache of the capture --
+        # keep it alive even if an eager step of another shape replaces the model's current one)
+        self._grad_cache = model.__dict__.get("_grad_cache")
 
     def __call__(self, batch) -> torch.Tensor:
         for dst, src in zip(self.inputs, batch):
@@ -110,6 +131,7 @@ class GraphedTrainStep:
             if p.grad is not g:
                 p.grad = g
         note_training_forward()  # the optimizer below rewrites the weights: packed inference copies are stale
+        _mark_touched_rows(self.model, self.optim, self.inputs[0], self.inputs[3], False)
         self.optim.step()
         return self.loss
 

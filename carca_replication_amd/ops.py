@@ -942,6 +942,46 @@ def l2norm_bwd(x: Tensor, dy: Tensor, d: int, out_ld: int) -> Tensor:
     return dx
 
 
+def _id_lists(id_lists):
+    keep = [_ids32(t.reshape(-1)) for t in id_lists]
+    for t in keep:
+        _need_cuda(t)
+    n = len(keep)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in keep])
+    counts = (C.c_int64 * n)(*[t.numel() for t in keep])
+    return keep, ptrs, counts, n
+
+
+def mark_rows(mask: Tensor, ids: Tensor) -> None:
+    """mask[ids] = 1 (uint8 row mask of an embedding table: CarcaAdamTensor.row_mask)."""
+    ids32 = _ids32(ids.reshape(-1))
+    _need_cuda(mask, ids32)
+    if mask.dtype != torch.uint8 or not mask.is_contiguous():
+        raise CarcaHipError("mark_rows: mask must be a contiguous uint8 tensor")
+    _lib.check(_lib.load().carca_mark_rows(ids32.data_ptr(), ids32.numel(), mask.data_ptr(), mask.numel(), _stream()),
+               "mark_rows")
+
+
+def zero_rows(table: Tensor, id_lists) -> None:
+    """table[ids] = 0 for up to MAX_SEGS id tensors (the rows a previous scatter-add touched)."""
+    _need_cuda(table)
+    if table.dim() != 2 or not table.is_contiguous() or table.dtype != torch.float32:
+        raise CarcaHipError("zero_rows: table must be a contiguous fp32 [rows, d] tensor")
+    keep, ptrs, counts, n = _id_lists(id_lists)
+    _lib.check(_lib.load().carca_zero_rows(table.data_ptr(), table.shape[0], table.shape[1], ptrs, counts, n, _stream()),
+               "zero_rows")
+    del keep
+
+
+def concat_ids(id_lists, out: Tensor) -> None:
+    """out[: sum of sizes] = the id tensors back to back (int32)."""
+    keep, ptrs, counts, n = _id_lists(id_lists)
+    if out.dtype != torch.int32 or not out.is_contiguous() or out.numel() < sum(t.numel() for t in keep):
+        raise CarcaHipError("concat_ids: out must be a contiguous int32 tensor with room for every id")
+    _lib.check(_lib.load().carca_concat_ids(ptrs, counts, n, out.data_ptr(), _stream()), "concat_ids")
+    del keep
+
+
 def embed_scatter(dz: Tensor, ids: Tensor, d: int, scale: float, d_items: Tensor) -> None:
     lib = _lib.load()
     dz = _row2d(dz, "dz")

@@ -33,11 +33,37 @@ class Adam(torch.optim.Optimizer):
             raise ValueError(f"Invalid weight_decay value: {weight_decay}")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._steps = {}  # id(parameter) -> step count as a python int (state['step'] stays the tensor torch expects)
+        self._marked = set()  # id(parameter) of the tables whose touched rows were announced for the coming step
+
+    def mark_rows(self, param: torch.nn.Parameter, ids: torch.Tensor) -> bool:
+        """Touched-row update of an embedding table: `ids` are the rows this step's gradient
+        can be non-zero in.  The step then skips every row that has never been marked -- exactly the rows whose
+        g = m = v = 0, for which dense Adam's update is exactly 0 -- so parameters and state keep the bits of the dense
+        sweep without moving 7 floats per element of the whole table (1 M x 128: 2.5 GB per step).
+        Must be called before EVERY step from the first one on; a step without it marks the whole table touched (dense
+        from then on: still correct).  Refused (returns False) when weight decay would move untouched rows."""
+        group = next(g for g in self.param_groups if any(q is param for q in g["params"]))
+        if group["weight_decay"] != 0 or param.dim() != 2 or param.shape[1] % 4 != 0:
+            return False
+        st = self.state[param]
+        if "row_touched" not in st:
+            started = bool(st) and float(st.get("step", 0.0)) > 0
+            fill = torch.ones if started else torch.zeros  # (steps already taken densely: every row may carry state)
+            st["row_touched"] = fill(param.shape[0], dtype=torch.uint8, device=param.device)
+            self._fast = {}
+        from . import ops
+
+        ops.mark_rows(st["row_touched"], ids)
+        self._marked.add(id(param))
+        return True
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._steps = {}
         self._fast = {}
+        for st in self.state.values():  # (torch casts every state tensor to the parameter's dtype on load)
+            if "row_touched" in st:
+                st["row_touched"] = (st["row_touched"] != 0).to(torch.uint8)
 
     def state_dict(self):
         sd = super().state_dict()
@@ -69,6 +95,8 @@ class Adam(torch.optim.Optimizer):
                         c = None
                         break
                     arr[i].g = g.data_ptr()
+                if c is not None and c["masked"] and not all(i in self._marked for i in c["masked"]):
+                    c = None  # a masked table was not announced for this step: the slow path below turns it dense
                 if c is not None:
                     c["t"] += 1
                     c["step"] += 1  # ONE CPU tensor shared by the group's state entries (37 separate ones cost 75 us)
@@ -87,6 +115,7 @@ class Adam(torch.optim.Optimizer):
             steps = set()
             arr = (_lib.AdamTensor * len(live))()
             keep = []
+            masked = []
             for i, p in enumerate(live):
                 g = p.grad
                 if g.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
@@ -95,7 +124,7 @@ class Adam(torch.optim.Optimizer):
                     g = g.contiguous()
                     keep.append(g)
                 st = self.state[p]
-                if not st:
+                if "step" not in st:  # (mark_rows may have put the row mask there already)
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
@@ -107,6 +136,11 @@ class Adam(torch.optim.Optimizer):
                 a = arr[i]
                 a.p, a.g, a.m, a.v, a.n = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), \
                     p.numel()
+                if "row_touched" in st:
+                    if id(p) not in self._marked:  # an unannounced step: rows unknown -> every row counts as touched
+                        st["row_touched"].fill_(1)
+                    a.row_mask, a.row_len = st["row_touched"].data_ptr(), p.shape[1]
+                    masked.append(id(p))
             # the kernel writes the parameters behind torch's back: bump their version counters, which is what the
             # modules' packed-weight caches (and autograd's saved-tensor checks) go by
             torch.autograd.graph.increment_version(live)
@@ -119,7 +153,8 @@ class Adam(torch.optim.Optimizer):
                 for p in live:
                     self.state[p]["step"] = shared
                 if len(live) == len(params) and not keep:
-                    fast[gi] = dict(arr=arr, n=len(params), t=t, pp=[p.data_ptr() for p in params], step=shared)
+                    fast[gi] = dict(arr=arr, n=len(params), t=t, pp=[p.data_ptr() for p in params], step=shared,
+                                    masked=masked)
             else:  # parameters that joined later carry their own step count: one launch per count
                 for p in live:
                     self.state[p]["step"] = torch.tensor(float(self._steps[id(p)]), dtype=torch.float32)
@@ -129,4 +164,5 @@ class Adam(torch.optim.Optimizer):
                     _lib.check(lib.carca_adam_step(sub, len(idx), float(group["lr"]), float(b1), float(b2),
                                                    float(group["eps"]), float(group["weight_decay"]), t, _stream()),
                                "adam_step")
+        self._marked.clear()
         return loss

@@ -5,8 +5,11 @@ Same function names, arguments, return values, console lines and `;`-separated C
   * every batch runs the HIP path (engine.train_step / engine.eval_batch);
   * HR@k / NDCG@k come from a sort-free rank count on the device (carca_rank_metrics) and all per-batch
     `.item()` syncs (train.py:21,32,47,97) are gone: sums stay on the device until an epoch / evaluation ends;
-  * the best checkpoint is written with torch.save(model) like the reference (train.py:124) but reloaded with
-    weights_only=False -- the reference's bare torch.load (train.py:142) raises on torch >= 2.6.
+  * the best checkpoint keeps the reference's file name (`<epoch>_<HR>_<NDCG>.pth`, train.py:118-124) but holds
+    state_dicts -- model, optimizer, scheduler, epoch, metrics -- instead of a pickled module: it reloads with
+    torch.load(weights_only=True) (the reference's bare torch.load of a pickled module, train.py:141-142, raises on
+    torch >= 2.6), survives refactors of the module classes, and `resume=` continues a run from it.
+    load_checkpoint() still accepts the reference's pickled-module files.
 """
 from __future__ import annotations
 
@@ -21,6 +24,42 @@ from torch.utils.data import DataLoader
 
 from . import engine, ops
 from .modules import Model, to
+
+
+CHECKPOINT_FORMAT = "carca-state-dict-v1"
+
+
+def save_checkpoint(path: str, model: Model, optim: Optimizer = None, scheduler=None, **meta) -> None:
+    """state_dict checkpoint: tensors + plain python values only, so that
+    torch.load(path, weights_only=True) reads it back."""
+    ck = {"format": CHECKPOINT_FORMAT, "model": model.state_dict(), "meta": dict(meta)}
+    if optim is not None:
+        ck["optimizer"] = optim.state_dict()
+    if scheduler is not None:
+        ck["scheduler"] = scheduler.state_dict()
+    tmp = path + ".tmp"
+    torch.save(ck, tmp)
+    os.replace(tmp, path)  # (an interrupted save never leaves a truncated best checkpoint behind)
+
+
+def load_checkpoint(path: str, model: Model, optim: Optimizer = None, scheduler=None, device=None) -> dict:
+    """Loads `path` into model (and optimizer / scheduler when given and stored); returns the checkpoint's meta dict.
+    A file written by the reference (torch.save(model), train.py:124) is accepted too: its parameters are copied."""
+    try:
+        ck = torch.load(path, map_location=device, weights_only=True)
+    except Exception:  # a pickled nn.Module: the reference's format (trusted input: the user's own run directory)
+        ck = torch.load(path, map_location=device, weights_only=False)
+    if isinstance(ck, torch.nn.Module):
+        model.load_state_dict(ck.state_dict())
+        return {}
+    if not isinstance(ck, dict) or ck.get("format") != CHECKPOINT_FORMAT:
+        raise ValueError(f"{path}: not a {CHECKPOINT_FORMAT} checkpoint")
+    model.load_state_dict(ck["model"])
+    if optim is not None and "optimizer" in ck:
+        optim.load_state_dict(ck["optimizer"])
+    if scheduler is not None and "scheduler" in ck:
+        scheduler.load_state_dict(ck["scheduler"])
+    return ck.get("meta", {})
 
 
 def _positive_columns(y_true: torch.Tensor) -> torch.Tensor:
@@ -54,18 +93,25 @@ def evaluate(model: Model, loader: DataLoader, device: str, k: int) -> Tuple[flo
 
 def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_loader: DataLoader, device: str,
           optim: Optimizer, epochs: int, top_k: int = 10, verbose: int = 1, early_stop: int = 10,
-          datadir: str = "model", scheduler: Union[_LRScheduler, None] = None, graphed: bool = False) -> Model:
-    """src/train.py:56-152.  graphed (extension, off by default): batches of the first batch's shape replay their forward +
-    backward from one hipGraph (engine.GraphedTrainStep); any other shape (a short last batch) takes the eager step."""
+          datadir: str = "model", scheduler: Union[_LRScheduler, None] = None, graphed: bool = False,
+          resume: Union[str, None] = None) -> Model:
+    """src/train.py:56-152.  Extensions, off by default:
+    graphed: batches of the first batch's shape replay their forward + backward from one hipGraph
+      (engine.GraphedTrainStep); any other shape (a short last batch) takes the eager step;
+    resume: path of a checkpoint written by an earlier run (save_checkpoint): model, optimizer and scheduler state are
+      restored and the epoch count continues after the stored one, with the stored best NDCG as the bar to beat."""
     os.makedirs(datadir, exist_ok=True)
     model = model.train().to(device)
-    best, stale = 0.0, 0
+    best, stale, first_epoch = 0.0, 0, 1
+    if resume is not None:
+        meta = load_checkpoint(resume, model, optim, scheduler, device=device)
+        best, first_epoch = float(meta.get("NDCG", 0.0)), int(meta.get("epoch", 0)) + 1
     t0 = datetime.now()
     log = open(f"./{datadir}/{t0.year}-{t0.month}-{t0.day}T{t0.hour}-{t0.minute}-{t0.second}.csv", "a")
     now = lambda: datetime.now().strftime("%H:%M:%S")  # noqa: E731
-    epoch = 0
+    epoch = first_epoch - 1
     captured = None
-    for epoch in range(1, epochs + 1):
+    for epoch in range(first_epoch, epochs + 1):
         loss_sum = torch.zeros((), dtype=torch.float32, device=device)
         for i, batch in enumerate(train_loader, start=1):
             dev_batch = to(*batch, device=device)
@@ -93,7 +139,8 @@ def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_l
                 if f.endswith(".pth"):
                     os.remove(os.path.join(datadir, f))
             best, stale = NDCG, 0
-            torch.save(model, os.path.join(datadir, f"{epoch:03d}_{HR:.4f}_{NDCG:.4f}.pth"))
+            save_checkpoint(os.path.join(datadir, f"{epoch:03d}_{HR:.4f}_{NDCG:.4f}.pth"), model, optim, scheduler,
+                            epoch=epoch, HR=float(HR), NDCG=float(NDCG), val_loss=float(loss))
         else:
             stale += 1
         if verbose in (1, 2):
@@ -105,8 +152,9 @@ def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_l
         log.flush()
 
     saved = [f for f in os.listdir(datadir) if f.endswith(".pth")]
-    if saved:
-        model = torch.load(os.path.join(datadir, saved[0]), weights_only=False).to(device)
+    if saved:  # the best epoch's weights (train.py:141-142); the optimizer keeps the last epoch's state
+        load_checkpoint(os.path.join(datadir, saved[0]), model, device=device)
+        model = model.to(device)
     if test_loader is not None:
         HR, NDCG, loss = evaluate(model, test_loader, device, top_k)
         print(f"{now()} - Epoch {epoch:03d}: Test Loss = {loss:.4f} HR = {HR:.4f}, NDCG = {NDCG:.4f}")

@@ -459,9 +459,24 @@ typedef struct {
   float* m;
   float* v;
   int64_t n;
+  /* Optional row mask of an embedding table [n / row_len, row_len]: rows whose byte is 0 are SKIPPED.  Exact as long as
+   * the caller marks every row that ever received a non-zero gradient and weight_decay is 0: a row with g = m = v = 0
+   * has an update of exactly 0 (m, v stay 0, p -= lr * 0 / (0 + eps)), so skipping it gives the bits of the dense
+   * sweep without reading or writing its four arrays (1 M items x 128: 2.5 GB per step).  NULL = every row. */
+  const uint8_t* row_mask;
+  int64_t row_len;
 } CarcaAdamTensor;
 int carca_adam_step(const CarcaAdamTensor* tensors, int n, double lr, double beta1, double beta2, double eps,
                     double weight_decay, int step, void* stream);
+/* mask[ids[i]] = 1 for i < n (ids outside [0, n_rows) are ignored): the rows a batch touches, for CarcaAdamTensor.row_mask */
+int carca_mark_rows(const int32_t* ids, int64_t n, uint8_t* mask, int64_t n_rows, void* stream);
+/* table[ids[i]][0 .. row_len) = 0 for every id of up to CARCA_MAX_SEGS id lists (ids outside [0, n_rows) ignored): clears
+ * the rows the previous step's scatter-add touched instead of the whole gradient table.  carca_concat_ids copies the
+ * lists back to back into `out` (sum of counts entries): the caller's private record of a step's "dirty" rows. */
+int carca_zero_rows(float* table, int64_t n_rows, int row_len, const int32_t* const* ids /*host [nlists]*/,
+                    const int64_t* counts /*host [nlists]*/, int nlists, void* stream);
+int carca_concat_ids(const int32_t* const* ids /*host [nlists]*/, const int64_t* counts /*host*/, int nlists,
+                     int32_t* out, void* stream);
 
 /* ---- f1: batch construction on the device (data.py:53-192) ---------------------------------------------------
  * The interaction log lives in HBM as CSR: user u owns hist[offs[u] .. offs[u+1]) (item ids in interaction order) and

@@ -1,0 +1,77 @@
+"""BASELINE configs[3] at full table size on one GPU (SURVEY section 8 rows e / f3): n_items = 1,000,001, d = 128, g = 640,
+H = 4.  The train step of a model with a 512 MB item table keeps one gradient buffer cleared row-wise and updates only
+the rows ever touched (optim.Adam.mark_rows) -- and must land on the same parameters as the dense step: fresh
+zero-filled gradients + torch.optim.Adam over every row."""
+import copy
+
+import pytest
+import torch
+
+from tests.model_util import build_model
+
+pytestmark = pytest.mark.gpu
+
+B, L, d, g, H, n_attrs, n_ctx, n_items = 128, 50, 128, 640, 4, 256, 6, 1_000_001
+
+
+def _batch(seed):
+    from carca_replication_amd.synth import eval_batch
+
+    profile, pos, _ = eval_batch(B, L, L, n_items, n_attrs, n_ctx, seed=seed)
+    px = profile[0]
+    o_x = torch.cat([pos[0] * (px != 0), pos[0].flip(1) * (px != 0)], dim=1)
+    return tuple(t.cuda() for t in (profile[0], profile[1], profile[2], o_x, torch.cat([pos[1], pos[1].flip(1)], 1),
+                                    torch.cat([pos[2], pos[2]], 1), torch.cat([(px != 0).int(), torch.zeros_like(px)], 1)))
+
+
+def test_c4_touched_row_step_equals_the_dense_step(monkeypatch):
+    from carca_replication_amd import autograd, engine
+    from carca_replication_amd.optim import Adam
+
+    torch.manual_seed(0)
+    model_a = build_model(dict(d=d, H=H, n_blocks=2), n_items, g, n_ctx, n_attrs, L).cuda().train()
+    model_b = copy.deepcopy(model_a)
+    opt_a = Adam(model_a.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    opt_b = torch.optim.Adam(model_b.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    w0 = model_a.embeds.items_embed.weight.detach().clone()
+    batches = [_batch(7), _batch(8), _batch(7)]  # (step 2 leaves step 1's rows without a gradient: momentum still moves them)
+    assert int(batches[0][0].max()) > 900_000, "ids must reach the far end of the table"
+    touched = torch.zeros(n_items, dtype=torch.bool, device="cuda")
+    for bt in batches:
+        loss_a = engine.train_step(model_a, opt_a, bt)
+        touched[bt[0].reshape(-1).long()] = True
+        touched[bt[3].reshape(-1).long()] = True
+        # the dense step: no gradient cache (fresh zero fill of the whole table), torch's Adam over every row
+        monkeypatch.setattr(autograd, "BIG_TABLE_BYTES", 1 << 62)
+        loss_b = engine.train_step(model_b, opt_b, bt)
+        monkeypatch.undo()
+        assert abs(float(loss_a) - float(loss_b)) < 1e-5 * max(1.0, abs(float(loss_b)))
+    # the sparse machinery really ran: one cached gradient buffer, a row mask with exactly the batches' rows (+ the pad row)
+    assert "_grad_cache" in model_a.__dict__ and "_grad_cache" not in model_b.__dict__
+    mask = opt_a.state[model_a.embeds.items_embed.weight]["row_touched"]
+    assert torch.equal(mask.bool(), touched)
+    wa, wb = model_a.embeds.items_embed.weight.detach(), model_b.embeds.items_embed.weight.detach()
+    assert torch.equal(wa[~touched], w0[~touched])          # untouched rows: bitwise the initial ones
+    assert torch.equal(wb[~touched], w0[~touched])          # (dense Adam does not move them either: update exactly 0)
+    moved = (wa - w0).abs().sum(1) > 0
+    assert int(moved.sum()) > 10_000 and not bool(moved[0])  # pad row 0 never moves (padding_idx, carca.py:73)
+    assert torch.allclose(wa, wb, rtol=0, atol=2e-5), float((wa - wb).abs().max())
+    for (n, a), (_, b) in zip(model_a.named_parameters(), model_b.named_parameters()):
+        if n.endswith("WK.bias"):  # true gradient 0: Adam turns round-off into +-lr steps
+            continue
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-5), n
+    # Adam state agrees too (a checkpoint of either optimizer resumes the other)
+    sa, sb = opt_a.state[model_a.embeds.items_embed.weight], opt_b.state[model_b.embeds.items_embed.weight]
+    assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-3, atol=1e-7)
+    assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-3, atol=1e-10)
+
+
+def test_c4_eval_scores_are_finite_at_full_table_size():
+    from carca_replication_amd.synth import eval_batch
+
+    torch.manual_seed(0)
+    model = build_model(dict(d=d, H=H, n_blocks=2), n_items, g, n_ctx, n_attrs, L).cuda().eval()
+    ep, et, _ = eval_batch(B, L, 101, n_items, n_attrs, n_ctx, seed=8)
+    with torch.no_grad():
+        y = model(profile=tuple(t.cuda() for t in ep), targets=[tuple(t.cuda() for t in et)])
+    assert y.shape == (B, 101) and bool(torch.isfinite(y).all()) and float(y.std()) > 0

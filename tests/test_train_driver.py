@@ -140,3 +140,72 @@ def test_cli_default_model_trains_with_dropout():
     for name, prm in model.named_parameters():
         assert prm.grad is not None and bool(torch.isfinite(prm.grad).all()), name
     assert float(emb.feats_embed.weight.grad.abs().max()) > 0
+
+
+def test_checkpoints_are_state_dicts_and_a_run_resumes(tmp_path, monkeypatch):
+    """the best checkpoint is a state_dict file (model + optimizer + epoch + metrics) that
+    torch.load(weights_only=True) reads, train(resume=...) continues from it, and a reference-style pickled module
+    still loads."""
+    import torch.nn as nn
+    from torch.utils.data import DataLoader
+
+    from carca_replication_amd.optim import Adam
+    from carca_replication_amd.train import load_checkpoint, save_checkpoint
+    from src.carca import CARCA, AllEmbedding, CrossAttentionBlock, IdentityEncoding, SelfAttentionBlock
+    from src.data import CARCADataset, load_attrs, load_ctx, load_profiles, set_datapath
+    from src.train import train
+
+    _write_dataset(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    set_datapath(str(tmp_path))
+    attrs, ctx = load_attrs("attrs.dat"), load_ctx("ctx.dat")
+    user_ids, item_ids, profiles = load_profiles("profiles.txt")
+    n_items, n_ctx, n_attrs = attrs.shape[0], next(iter(ctx.values())).shape[0], attrs.shape[1]
+    random.seed(0)
+    torch.manual_seed(0)
+    mk = lambda mode: DataLoader(CARCADataset(user_ids=user_ids, item_ids=item_ids, profiles=profiles, attrs=attrs, ctx=ctx,  # noqa: E731
+                                              profile_seq_len=8, target_seq_len=20, mode=mode, test=True),
+                                 batch_size=16, shuffle=False, num_workers=0)
+
+    def fresh():
+        torch.manual_seed(0)
+        emb = AllEmbedding(n_items, 64, 48, n_ctx, n_attrs, IdentityEncoding())
+        enc = nn.ModuleList([SelfAttentionBlock(64, 2, 0.0, True) for _ in range(2)])
+        m = CARCA(d=64, p=0.0, emb=emb, enc=enc, dec=CrossAttentionBlock(64, 2, 0.0, True)).to("cuda")
+        return m, Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.98))
+
+    model, optim = fresh()
+    train(model=model, train_loader=mk("train"), val_loader=mk("val"), test_loader=None, device="cuda", optim=optim,
+          epochs=2, early_stop=20, datadir="run_a", verbose=0)
+    (ck_name,) = [f for f in os.listdir("run_a") if f.endswith(".pth")]
+    ck = torch.load(os.path.join("run_a", ck_name), weights_only=True)  # no pickled code objects inside
+    assert ck["format"] == "carca-state-dict-v1" and set(ck) >= {"model", "optimizer", "meta"}
+    assert set(ck["model"]) == set(model.state_dict()) and ck["meta"]["epoch"] in (1, 2)
+    assert ck_name.startswith(f"{ck['meta']['epoch']:03d}_")
+    # the returned model carries the checkpoint's weights
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), ck["model"][k].cpu()), k
+
+    # resume: a second run from that file starts after its epoch, with optimizer state restored
+    m2, o2 = fresh()
+    meta = load_checkpoint(os.path.join("run_a", ck_name), m2, o2, device="cuda")
+    assert meta["epoch"] == ck["meta"]["epoch"]
+    p0 = next(iter(m2.parameters()))
+    assert o2.state[p0]["exp_avg"].abs().sum() > 0 and float(o2.state[p0]["step"]) > 0
+    m3, o3 = fresh()
+    train(model=m3, train_loader=mk("train"), val_loader=mk("val"), test_loader=None, device="cuda", optim=o3,
+          epochs=ck["meta"]["epoch"] + 1, early_stop=20, datadir="run_b", verbose=1, resume=os.path.join("run_a", ck_name))
+    rows = [ln.strip().split(";") for f in os.listdir("run_b") if f.endswith(".csv") for ln in open(os.path.join("run_b", f))]
+    assert [r[1] for r in rows if r[2] == "train"] == [str(ck["meta"]["epoch"] + 1)]  # exactly one more epoch was run
+
+    # a reference-style checkpoint (pickled module, train.py:124) still loads
+    torch.save(model, "ref_style.pth")
+    m4, _ = fresh()
+    with torch.no_grad():
+        for prm in m4.parameters():
+            prm.add_(1.0)
+    load_checkpoint("ref_style.pth", m4, device="cuda")
+    for (k, a), (_, b) in zip(m4.state_dict().items(), model.state_dict().items()):
+        assert torch.equal(a, b), k
+    save_checkpoint("plain.pth", m4)
+    assert set(torch.load("plain.pth", weights_only=True)) == {"format", "model", "meta"}

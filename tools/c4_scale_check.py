@@ -40,6 +40,32 @@ touched = touched[touched != 0]
 missing = touched[~torch.isin(touched, moved)]
 assert torch.isin(moved, touched).all() and missing.numel() <= B and torch.isin(missing, batch[0][:, -1].long()).all(), \
     (moved.numel(), touched.numel())
+# steady-state step time: the touched-row path (gradient cache + optim.Adam.mark_rows) against the dense one
+from carca_replication_amd import autograd  # noqa: E402
+
+
+def steps_ms(n=20):
+    for _ in range(3):
+        engine.train_step(model, opt, batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        engine.train_step(model, opt, batch)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+sparse_ms = steps_ms()
+keep = autograd.BIG_TABLE_BYTES
+autograd.BIG_TABLE_BYTES = 1 << 62   # fresh 512 MB zero fill per step ...
+opt._marked_off = True
+_mark = opt.mark_rows
+opt.mark_rows = lambda *a, **k: False  # ... and Adam over every row
+opt.state[model.embeds.items_embed.weight].pop("row_touched", None)
+opt._fast = {}
+dense_ms = steps_ms()
+autograd.BIG_TABLE_BYTES, opt.mark_rows = keep, _mark
+print(f"train step at C4 table size: {sparse_ms:.2f} ms touched-row path, {dense_ms:.2f} ms dense path", flush=True)
 model.eval()
 ep, et, _ = eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=8)
 with torch.no_grad():
