@@ -193,7 +193,8 @@ class EmbedBwdSeg(C.Structure):
 class EmbedBwdDesc(C.Structure):
     _fields_ = ([("seg", EmbedBwdSeg * MAX_SEGS)] + [(n, C.c_int32) for n in ("nseg", "d", "g", "n_attrs", "n_ctx", "ld_de", "L")]
                 + [("zq", _fp), ("joint_wt", _fp), ("ld_joint_wt", C.c_int32)]
-                + [(n, _fp) for n in ("g_items", "g_feats_w", "g_feats_b", "g_joint_w", "g_joint_b", "g_pos", "workspace")])
+                + [(n, _fp) for n in ("g_items", "g_feats_w", "g_feats_b", "g_joint_w", "g_joint_b", "g_pos", "workspace",
+                                      "ev_early")])
 
 
 class SaWeights(C.Structure):
@@ -257,6 +258,7 @@ SIGNATURES = {
     "carca_event_create": (_i, [C.POINTER(_fp)]),
     "carca_event_destroy": (_i, [_fp]),
     "carca_event_elapsed_ms": (_i, [_fp, _fp, C.POINTER(C.c_float)]),
+    "carca_stream_wait_event": (_i, [_fp, _fp]),
     "carca_bce_fwd": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp, _fp]),
     "carca_rank_metrics": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
     "carca_layernorm_fwd": (_i, [_fp, _i, _fp, _i, _i, _i, _fp, _fp, _fp]),

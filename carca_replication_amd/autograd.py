@@ -18,71 +18,78 @@ from . import ops
 from ._lib import MAX_BLOCKS, MAX_GROUPS, CarcaHipError
 
 
-def _zeros_like_params(params, extra: int = 0):
-    """One zero-filled flat buffer cut into per-parameter views (one fill launch instead of one per parameter; every
-    view starts on a 16-byte boundary), plus `extra` zeroed floats behind them for the backward's staging areas.
-    Returns (views, tail)."""
-    if not params:
-        return [], None
-    offs, total = [], 0
-    for p in params:
-        offs.append(total)
-        total += (p.numel() + 3) // 4 * 4
-    flat = torch.zeros(total + extra, dtype=params[0].dtype, device=params[0].device)
-    # (dist.allreduce_gradients recognises this layout by storage and offsets and reduces the flat buffer itself)
-    return [flat[o: o + p.numel()].view(p.shape) for o, p in zip(offs, params)], flat[total:]
-
-
 BIG_TABLE_BYTES = 64 * 2 ** 20  # embedding tables above this keep ONE gradient buffer, cleared row-wise (see below)
 
 
-def _grad_buffers(model, params, extra: int, id_lists):
-    """The backward's gradient storage: (views, tail, after) like _zeros_like_params, plus a callable to run once the
-    pass is issued.  A model with an embedding table of 64 MB or more (BASELINE config 4: 1 M items x 128 = 512 MB)
-    keeps ONE flat buffer across steps, the big tables last in it: every step zero-fills the small front (dense
-    parameters + staging areas) and only the table ROWS the previous step's scatter-add touched (carca_zero_rows over
-    that step's ids, which `after` records with carca_concat_ids) -- not 512 MB.  Falls back to a fresh zero-filled
-    buffer per step when there is no such table, when the ids are unknown, or when a previous gradient still lives in
-    the cached buffer (accumulation without zero_grad(set_to_none=True))."""
+def _grad_buffers(model, params, extra: int, id_lists, late=()):
+    """The backward's gradient storage: ONE flat fp32 buffer cut into per-parameter views (every view starts on a
+    16-byte boundary), laid out for what happens to the gradients afterwards:
+
+        [ early parameters | late parameters | staging (extra floats) | big tables ]
+
+      early    everything whose gradient is final before the pass's LAST launch; in parameter order
+      late     `late`: the parameters that last launch produces (AllEmbedding: feats_embed.weight / .bias, a kernel as
+               long as the forward's feature GEMM) -- a sharded step all-reduces the early range UNDER that kernel
+               (engine.train_step), then the late range
+      staging  the backward's head-padded staging areas (zeroed with the rest, never reduced)
+      big      embedding tables of 64 MB or more (BASELINE config 4: 1 M items x 128 = 512 MB): exchanged row-wise between
+               ranks, and -- when the ids a pass can touch are known (id_lists) -- never re-zeroed as a whole: the model
+               keeps the buffer across steps and a step clears only the table ROWS the previous step's scatter-add touched
+               (carca_zero_rows over that step's ids, recorded by `after` with carca_concat_ids) plus the small front.
+    The layout is published as model._flat_grad (dist.allreduce_flat reads it).  Returns (views, staging, after).
+    Falls back to a fresh zero-filled buffer per step when there is no big table, when the ids are unknown, or when a
+    previous gradient still lives in the cached buffer (accumulation without zero_grad(set_to_none=True))."""
+    if not params:
+        return [], None, (lambda: None)
     big = [i for i, p in enumerate(params) if p.dim() == 2 and p.numel() * p.element_size() >= BIG_TABLE_BYTES]
-    if not big or id_lists is None:
-        views, tail = _zeros_like_params(params, extra)
-        return views, tail, (lambda: None)
-    c = model.__dict__.get("_grad_cache")
-    key = (tuple((p.data_ptr(), tuple(p.shape)) for p in params), extra, tuple(t.numel() for t in id_lists))
-    if c is not None and (c["key"] != key or any(
-            p.grad is not None and p.grad.untyped_storage().data_ptr() == c["flat"].untyped_storage().data_ptr()
-            for p in params)):
-        c = None  # other shapes, or the cached buffer still holds gradients somebody is accumulating into
-        model.__dict__.pop("_grad_cache", None)
-    small = [i for i in range(len(params)) if i not in big]
-    if c is None:
-        offs, total = {}, 0
-        for i in small + big:  # the dense parameters first (in parameter order: dist._shared_flat walks them), tables last
-            if i == big[0]:
-                total += (extra + 3) // 4 * 4
-                front = total
-            offs[i] = total
-            total += (params[i].numel() + 3) // 4 * 4
-        flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
-        small_total = front - (extra + 3) // 4 * 4
-        c = dict(key=key, flat=flat, offs=offs, front=front, small_total=small_total,
-                 dirty=torch.zeros(sum(t.numel() for t in id_lists), dtype=torch.int32, device=params[0].device),
-                 fresh=True)
-        model.__dict__["_grad_cache"] = c
-    flat = c["flat"]
-    if not c["fresh"]:
-        flat[: c["front"]].zero_()
-        for i in big:
-            ops.zero_rows(flat[c["offs"][i]: c["offs"][i] + params[i].numel()].view(params[i].shape), [c["dirty"]])
-    c["fresh"] = False
-    views = [flat[c["offs"][i]: c["offs"][i] + p.numel()].view(p.shape) for i, p in enumerate(params)]
-    tail = flat[c["small_total"]: c["front"]]
+    late_i = [i for i, p in enumerate(params) if any(p is q for q in late) and i not in big]
+    early_i = [i for i in range(len(params)) if i not in big and i not in late_i]
+    r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+    offs, total = {}, 0
+    for i in early_i:
+        offs[i] = total
+        total += r4(params[i].numel())
+    n_early = total
+    for i in late_i:
+        offs[i] = total
+        total += r4(params[i].numel())
+    n_late = total
+    total += r4(extra)
+    front = total
+    for i in big:
+        offs[i] = total
+        total += r4(params[i].numel())
+    dev, dt = params[0].device, params[0].dtype
+    cached = bool(big) and id_lists is not None
+    c = model.__dict__.get("_grad_cache") if cached else None
+    if cached:
+        key = (tuple((p.data_ptr(), tuple(p.shape)) for p in params), extra, tuple(t.numel() for t in id_lists), n_early, n_late)
+        if c is not None and (c["key"] != key or any(
+                p.grad is not None and p.grad.untyped_storage().data_ptr() == c["flat"].untyped_storage().data_ptr()
+                for p in params)):
+            c = None  # other shapes, or the cached buffer still holds gradients somebody is accumulating into
+            model.__dict__.pop("_grad_cache", None)
+        if c is None:
+            c = dict(key=key, flat=torch.zeros(total, dtype=dt, device=dev),
+                     dirty=torch.zeros(sum(t.numel() for t in id_lists), dtype=torch.int32, device=dev), fresh=True)
+            model.__dict__["_grad_cache"] = c
+        flat = c["flat"]
+        if not c["fresh"]:
+            flat[:front].zero_()
+            for i in big:
+                ops.zero_rows(flat[offs[i]: offs[i] + params[i].numel()].view(params[i].shape), [c["dirty"]])
+        c["fresh"] = False
+    else:
+        flat = torch.zeros(total, dtype=dt, device=dev)  # one fill launch for every gradient and staging area
+    views = [flat[offs[i]: offs[i] + p.numel()].view(p.shape) for i, p in enumerate(params)]
+    model.__dict__["_flat_grad"] = dict(flat=flat, early=(0, n_early), late=(n_early, n_late),
+                                        big=[(params[i], views[i]) for i in big], n_params=len(params))
 
     def after():
-        ops.concat_ids(id_lists, c["dirty"])
+        if cached:
+            ops.concat_ids(id_lists, c["dirty"])
 
-    return views, tail, after
+    return views, flat[n_late:front], after
 
 
 class _Tail:
@@ -294,7 +301,8 @@ class _CarcaFn(torch.autograd.Function):
                                                  ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi_b, dpi_b, transposed=True)]))
         # (every id a scatter-add of this pass can touch: known for the embeddings with an item table)
         id_lists = [sg[0] for sg in st["segs"]] if hasattr(emb, "items_embed") and len(st["segs"]) <= 4 else None
-        grads, tail_buf, after_pass = _grad_buffers(model, params, plan.staging_floats(), id_lists)
+        late = emb.late_grad_params(st["emb_saved"]) if hasattr(emb, "late_grad_params") else ()
+        grads, tail_buf, after_pass = _grad_buffers(model, params, plan.staging_floats(), id_lists, late)
         plan.build(dev, _Tail(tail_buf))
         gbp = {id(p): g for p, g in zip(params, grads)}
         ys = ctx.saved_tensors

@@ -170,6 +170,16 @@ extern "C" int carca_event_elapsed_ms(void* start, void* stop, float* ms_out) {
   return CARCA_OK;
 }
 
+extern "C" int carca_stream_wait_event(void* stream, void* event) {
+  CARCA_CHECK_ARG(event, "stream_wait_event: null event");
+  hipError_t rc = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+  if (rc != hipSuccess) {
+    carca_set_error("hipStreamWaitEvent: %s", hipGetErrorString(rc));
+    return (int)rc;
+  }
+  return CARCA_OK;
+}
+
 namespace {
 thread_local hipEvent_t g_armed_start = nullptr, g_armed_stop = nullptr;
 }

@@ -304,5 +304,9 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
       return rc;
   wf.ld_dy = ldz; wf.ld_x = D->n_attrs; wf.ld_x1 = D->n_ctx; wf.N = g; wf.K = D->n_attrs; wf.K1 = D->n_ctx;
   wf.dw = D->g_feats_w; wf.ldw = D->n_attrs + D->n_ctx; wf.db = D->g_feats_b;
+  if (D->ev_early && hipEventRecord((hipEvent_t)D->ev_early, (hipStream_t)stream) != hipSuccess) {
+    carca_set_error("embed_bwd: cannot record the early-gradients event");
+    return CARCA_ERR_BADARG;
+  }
   return carca_gemm_wgrad(&wf, stream);
 }

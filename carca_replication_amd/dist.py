@@ -13,9 +13,11 @@ is per-user (batch dimension only, carca.py:411-431), so users shard with NO dat
          the single-process batch loss, so R ranks x B/R users reproduce the reference's B-user step.
 
 xGMI on an 8-GPU MI355X node is a point-to-point mesh (7 links x ~153 GB/s per GPU).  The C2 gradient
-is 12.4 MB: one bucket, one RCCL call (latency-bound; splitting it only adds launches), issued on the flat
-gradient buffer the backward pass already produced (autograd.py: no gather / scatter copies).  Buckets are
-capped at `bucket_mb` so that bigger models pipeline their reduce-scatter/all-gather phases over all 7 links.
+is 12.4 MB, reduced IN PLACE in the flat buffer the backward pass produced it in (autograd._grad_buffers: no gather /
+scatter copies) as two RCCL calls: everything but feats_embed.{weight, bias} (5 MB) as soon as the backward's last
+launch -- the 0.6 ms weight-gradient kernel of feats_embed -- has been issued, so that it runs UNDER that kernel
+(engine.train_step), then feats_embed's 7.4 MB.  Ranges are cut at `bucket_mb` so that bigger models pipeline their
+reduce-scatter/all-gather phases over all 7 links.
 A C4-sized item table (1 M items x 128 = 512 MB dense) is not all-reduced at all: a step touches at most
 B*3L rows per rank, so ranks all-gather (row ids, row gradients) -- ~10 MB per rank -- and add them locally
 (`sparse_rows`), which is exactly the dense sum.
@@ -61,7 +63,7 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 def global_mask_count(ids: torch.Tensor) -> torch.Tensor:
     """sum over ALL ranks of the number of non-pad target slots: the loss normaliser of carca.py:443."""
     cnt = torch.count_nonzero(ids).to(torch.float32).reshape(1)
-    if world_size() > 1:
+    if _active():
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     return cnt
 
@@ -80,32 +82,50 @@ def _buckets(grads: List[torch.Tensor], cap_bytes: int) -> List[List[torch.Tenso
     return out
 
 
-def _shared_flat(grads: List[torch.Tensor]) -> Optional[torch.Tensor]:
-    """The one flat buffer all gradients are views of, in order, each starting on a 4-element boundary
-    (autograd._zeros_like_params hands the backward's results out that way; autograd keeps the storage), or None."""
-    if not grads:
+# Test hook: run the collectives of a sharded step even in a 1-rank group (a 1-GPU box can then execute the HIP flat
+# gradient buffer -> in-place all-reduce -> optimizer chain end to end); `last_reduce` says which path a step took.
+FORCE_COLLECTIVES = False
+last_reduce: dict = {}
+
+
+def _active() -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
+def flat_layout(model, params: List[torch.nn.Parameter]) -> Optional[dict]:
+    """model._flat_grad (autograd._grad_buffers: ONE flat buffer, [early | late | staging | big tables]) when every
+    .grad of `params` still is a view of it, else None."""
+    info = getattr(model, "__dict__", {}).get("_flat_grad")
+    if not info or info["n_params"] != len(params):
         return None
-    st = grads[0].untyped_storage()
-    off = 0
-    for g in grads:
-        if (g.untyped_storage().data_ptr() != st.data_ptr() or not g.is_contiguous() or g.storage_offset() != off or
-                g.dtype != grads[0].dtype):
-            return None
-        off += (g.numel() + 3) // 4 * 4
-    if off * grads[0].element_size() > st.nbytes():
+    st = info["flat"].untyped_storage().data_ptr()
+    if any(p.grad is None or p.grad.untyped_storage().data_ptr() != st for p in params):
         return None
-    return grads[0].new_empty(0).set_(st, 0, (off,), (1,))
+    return info
+
+
+def allreduce_range(flat: torch.Tensor, lo: int, hi: int, bucket_mb: float = 64.0) -> list:
+    """Asynchronous in-place all-reduce(sum) of flat[lo:hi], in chunks of at most bucket_mb; returns the work handles."""
+    step = max(1, int(bucket_mb * 2 ** 20) // flat.element_size())
+    return [dist.all_reduce(flat[off: min(off + step, hi)], op=dist.ReduceOp.SUM, async_op=True)
+            for off in range(lo, hi, step)]
 
 
 def allgather_row_gradients(grad: torch.Tensor, ids: torch.Tensor) -> None:
     """Sum over ranks of a gradient that is non-zero only in the rows `ids` touches (an embedding table):
     every rank contributes (ids, grad[ids]) with duplicates zeroed, all-gathers them and adds the lot into its own
     table.  Same result as a dense all-reduce(sum); traffic ~ world x len(ids) x (d + 1) floats instead of the table.
-    `ids` must have the same length on every rank (it has: B x 3L slots of the batch, pads included)."""
-    world = world_size()
-    if world == 1:
+    Ranks may hold different numbers of ids (B % world != 0, a short last batch): the lists are padded with id 0 --
+    the pad row, whose gradient is zero by construction (nn.Embedding(padding_idx=0), carca.py:73) -- to the longest."""
+    if not _active():
         return
+    world = dist.get_world_size()
     flat_ids = ids.reshape(-1).to(torch.int64)
+    n_max = torch.tensor([flat_ids.numel()], dtype=torch.int64, device=flat_ids.device)
+    dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+    pad = int(n_max.item()) - flat_ids.numel()
+    if pad > 0:
+        flat_ids = torch.cat([flat_ids, flat_ids.new_zeros(pad)])
     srt, _ = torch.sort(flat_ids)
     first = torch.ones_like(srt, dtype=torch.bool)
     first[1:] = srt[1:] != srt[:-1]
@@ -121,40 +141,50 @@ def allgather_row_gradients(grad: torch.Tensor, ids: torch.Tensor) -> None:
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, average: bool = False,
-                        sparse_rows: Optional[dict] = None) -> None:
-    """Sum (or average) .grad over ranks: flat fp32 buckets, asynchronously issued, then waited.
+                        sparse_rows: Optional[dict] = None, flat_info: Optional[dict] = None,
+                        early_work: Optional[list] = None) -> None:
+    """Sum (or average) .grad over ranks.
+    flat_info (flat_layout): the gradients are views of the backward's own flat buffer -- its [early | late] ranges are
+      reduced IN PLACE (no gather / scatter copies), asynchronously, in chunks of bucket_mb; early_work: handles of an
+      early-range reduction the caller already started (engine.train_step starts it under the backward's last kernel).
+    Otherwise: flat fp32 buckets of copies.
     sparse_rows: {parameter: ids} for embedding tables whose gradient is exchanged row-wise instead
-    (allgather_row_gradients)."""
-    world = world_size()
-    if world == 1:
+    (allgather_row_gradients); with flat_info these are its `big` tables."""
+    global last_reduce
+    if not _active():
         return
+    world = dist.get_world_size()
     params = [p for p in params if p.grad is not None]
     sparse_rows = sparse_rows or {}
     sparse = [p for p in params if any(p is q for q in sparse_rows)]
-    dense = [p.grad for p in params if not any(p is q for q in sparse_rows)]
     cap = int(bucket_mb * 2 ** 20)
-    work = []
-    flat_all = _shared_flat([p.grad for p in params]) if not sparse else None
-    if flat_all is not None:  # the backward's own flat buffer: reduce it in place, in chunks of the bucket size
-        step = max(1, cap // flat_all.element_size())
-        for off in range(0, flat_all.numel(), step):
-            chunk = flat_all[off: off + step]
-            work.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True), chunk, None))
+    work, flat_handles, flat_range = [], [], None
+    if flat_info is not None and all(any(p is q for q in sparse_rows) for p, _ in flat_info["big"]):
+        flat = flat_info["flat"]
+        handles = list(early_work) if early_work is not None else allreduce_range(flat, *flat_info["early"], bucket_mb)
+        handles += allreduce_range(flat, *flat_info["late"], bucket_mb)
+        flat_handles, flat_range = handles, flat[flat_info["early"][0]: flat_info["late"][1]]
+        last_reduce = dict(path="flat-inplace", floats=flat_info["late"][1], early_overlapped=early_work is not None,
+                           launches=len(handles), sparse_tables=len(sparse))
     else:
+        dense = [p.grad for p in params if not any(p is q for q in sparse_rows)]
         for bucket in _buckets(dense, cap):
             flat = torch.cat([g.reshape(-1) for g in bucket])
             work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
+        last_reduce = dict(path="bucket-copies", launches=len(work), sparse_tables=len(sparse), early_overlapped=False)
     for p in sparse:
         ids = next(v for q, v in sparse_rows.items() if q is p)
         allgather_row_gradients(p.grad, ids)
         if average:
             p.grad.div_(world)
+    for h in flat_handles:
+        h.wait()
+    if average and flat_range is not None:
+        flat_range.div_(world)
     for h, flat, bucket in work:
         h.wait()
         if average:
             flat.div_(world)
-        if bucket is None:
-            continue
         off = 0
         for g in bucket:
             n = g.numel()
@@ -164,6 +194,6 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_mb: float =
 
 def allreduce_sums(sums: torch.Tensor) -> torch.Tensor:
     """Metric sums [HR, NDCG, loss, users, ...] -> summed over ranks (train.py:49-53 across shards)."""
-    if world_size() > 1:
+    if _active():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     return sums

@@ -34,12 +34,50 @@ def train_step(model, optim, batch, sharded: bool = False) -> torch.Tensor:
     Returns the (device) loss: the global batch loss's local share when sharded.
     """
     p_x, o_x = batch[0], batch[3]
-    loss = _forward_backward(model, optim, batch, sharded)
-    if sharded:
-        cdist.allreduce_gradients(model.parameters(), sparse_rows=_sparse_tables(model, p_x, o_x))
+    if not (sharded and cdist._active()):
+        loss = _forward_backward(model, optim, batch, None)
+    else:
+        # 1. the loss normaliser of the WHOLE batch (carca.py:443), 2. local forward / backward with it, 3. gradients
+        # summed over ranks, in place in the backward's flat buffer -- the early range started under the backward's last
+        # kernel: an event recorded right before that launch (CarcaEmbedBwdDesc.ev_early) gates a side stream, RCCL's
+        # own stream queues behind the side stream, and the call returns to issue the late range behind the kernel.
+        denom = cdist.global_mask_count(o_x)
+        ev = _early_event() if p_x.is_cuda else None
+        ops.early_event = ev
+        try:
+            loss = _forward_backward(model, optim, batch, denom)
+        finally:
+            ops.early_event = None
+        params = list(model.parameters())
+        info = cdist.flat_layout(model, [p for p in params if p.grad is not None])
+        early = None
+        if info is not None and ev is not None and info["late"][1] > info["late"][0]:
+            side = _side_stream(p_x.device)
+            from . import _lib
+
+            _lib.check(_lib.load().carca_stream_wait_event(side.cuda_stream, ev.handle), "stream_wait_event")
+            with torch.cuda.stream(side):
+                early = cdist.allreduce_range(info["flat"], *info["early"])
+        cdist.allreduce_gradients(params, sparse_rows=_sparse_tables(model, p_x, o_x), flat_info=info, early_work=early)
     _mark_touched_rows(model, optim, p_x, o_x, sharded)
     optim.step()
     return loss
+
+
+_EV, _SIDE = [], {}
+
+
+def _early_event():
+    if not _EV:
+        _EV.append(ops.HipEvent())
+    return _EV[0]
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 def _mark_touched_rows(model, optim, p_x, o_x, sharded: bool) -> None:
@@ -59,7 +97,8 @@ def _mark_touched_rows(model, optim, p_x, o_x, sharded: bool) -> None:
         optim.mark_rows(w, ids)
 
 
-def _forward_backward(model, optim, batch, sharded: bool) -> torch.Tensor:
+def _forward_backward(model, optim, batch, denom: Optional[torch.Tensor]) -> torch.Tensor:
+    """denom: the loss normaliser (device float[1]: the all-reduced mask count of a sharded step), None = this batch's own."""
     p_x, p_a, p_c, o_x, o_a, o_c, y_true = batch
     half = o_x.shape[1] // 2
     pos = tuple(t[:, :half] for t in (o_x, o_a, o_c))  # train.py:86-88
@@ -69,7 +108,6 @@ def _forward_backward(model, optim, batch, sharded: bool) -> torch.Tensor:
         pos, neg = (ids2[0],) + pos[1:], (ids2[1],) + neg[1:]
     optim.zero_grad(set_to_none=True)
     y = model(profile=(p_x, p_a, p_c), targets=[pos, neg])
-    denom = cdist.global_mask_count(o_x) if sharded else None
     if o_x.dtype == torch.int32:  # BinaryCrossEntropy(y, y_true, get_mask(o_x)) without materialising the float mask
         from .autograd import bce_with_grad
 
@@ -90,14 +128,19 @@ class GraphedTrainStep:
     The batch is copied into the graph's own input tensors `.inputs`; a loader that fills those tensors itself and passes
     them back skips the copy (dense C2 batches are 315 MB: ~0.1 ms of HBM time per step; ids-only batches over a registered
     attribute table are a few hundred KB).
-    Single-process steps only (a sharded step has its gradient exchange between backward and optimizer: use train_step).
+    sharded=True (users sharded over ranks): the graph holds forward + backward normalised by a device scalar that every
+    call refills with the all-reduced mask count; the gradient all-reduce (in place, not overlapped here) and the
+    optimizer run behind each replay, outside the graph.
     Dropout: the seeds are launch arguments, which a replay repeats; the graph's first node increments a device counter
     that every dropout kernel adds to its seed (ops.set_dropout_seed_offset), so replay t draws the masks an eager step
     with seed + t would."""
 
-    def __init__(self, model, optim, example_batch, warmup: int = 3):
-        self.model, self.optim = model, optim
+    def __init__(self, model, optim, example_batch, warmup: int = 3, sharded: bool = False):
+        self.model, self.optim, self.sharded = model, optim, sharded
         self.inputs = tuple(t.clone() for t in example_batch)
+        self.denom = torch.ones(1, dtype=torch.float32, device=self.inputs[0].device) if sharded else None
+        if sharded:
+            self.denom.copy_(cdist.global_mask_count(self.inputs[3]))
         self.replays = torch.zeros(1, dtype=torch.int64, device=self.inputs[0].device)
         ops.set_dropout_seed_offset(self.replays)
         try:
@@ -105,12 +148,12 @@ class GraphedTrainStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):  # lazily built state (code objects, workspaces, descriptor rings) first
                 for _ in range(warmup):
-                    _forward_backward(model, optim, self.inputs, False)
+                    _forward_backward(model, optim, self.inputs, self.denom)
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.replays.add_(1)
-                self.loss = _forward_backward(model, optim, self.inputs, False)
+                self.loss = _forward_backward(model, optim, self.inputs, self.denom)
         finally:
             ops.set_dropout_seed_offset(None)
         # The replayed backward writes into the gradient tensors of the capture.  An eager step in between (train() sends
@@ -126,12 +169,17 @@ class GraphedTrainStep:
         for dst, src in zip(self.inputs, batch):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        if self.sharded:
+            self.denom.copy_(cdist.global_mask_count(self.inputs[3]))
         self.graph.replay()
         for p, g in zip(self.params, self.grads):
             if p.grad is not g:
                 p.grad = g
+        if self.sharded:
+            cdist.allreduce_gradients(self.params, sparse_rows=_sparse_tables(self.model, self.inputs[0], self.inputs[3]),
+                                      flat_info=cdist.flat_layout(self.model, self.params))
         note_training_forward()  # the optimizer below rewrites the weights: packed inference copies are stale
-        _mark_touched_rows(self.model, self.optim, self.inputs[0], self.inputs[3], False)
+        _mark_touched_rows(self.model, self.optim, self.inputs[0], self.inputs[3], self.sharded)
         self.optim.step()
         return self.loss
 

@@ -306,6 +306,11 @@ class AllEmbedding(Embedding):
         ops.gemm_wgrad([dict(dy=g_t.view(0), x=wf_t)], d, g_feats, g_joint_w[:, d:], None)
         g_joint_w[:, d:].addmm_(cs.view(d, 1), bf.view(1, g_feats))
 
+    def late_grad_params(self, saved):
+        """The parameters whose gradient the backward's LAST launch produces (autograd._grad_buffers lays them out behind
+        the others so that a sharded step can reduce everything else under that launch)."""
+        return () if isinstance(saved, str) else (self.feats_embed.weight, self.feats_embed.bias)
+
     def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int) -> None:
         """Backward of embed_segments (carca.py:85-95): des[i] = d e of segment i, [rows, dpi], NOT yet masked;
         accumulates into the gradient buffers gbp[id(param)].  One host call (carca_embed_bwd): position-encoding

@@ -724,6 +724,11 @@ def cross_score_bwd(groups, p_ids: Tensor, kh: Tensor, vh: Tensor, p_normed: Ten
     return dx, des
 
 
+# A HipEvent the NEXT embed_bwd call records right before its last launch (CarcaEmbedBwdDesc.ev_early): set by the sharded
+# train step, which starts its first gradient all-reduce behind that event (engine.train_step)
+early_event = None
+
+
 def embed_bwd(des, segs, zq: Tensor, joint_wt: Tensor, grads: dict, table: Optional[Tensor], d: int, g: int, n_attrs: int,
               n_ctx: int, L: int, g_pos: Optional[Tensor]) -> None:
     """Backward of AllEmbedding.forward over all segments as ONE host call (carca_embed_bwd).  des[i]: d e [rows, ld]
@@ -761,6 +766,7 @@ def embed_bwd(des, segs, zq: Tensor, joint_wt: Tensor, grads: dict, table: Optio
         setattr(D, k, t.data_ptr())
     D.g_pos = _ptr(g_pos)
     D.workspace = ws.data_ptr()
+    D.ev_early = early_event.handle if early_event is not None else None
     _lib.check(lib.carca_embed_bwd(C.byref(D), _stream()), "embed_bwd")
     del keep
 

@@ -444,6 +444,9 @@ typedef struct CarcaEmbedBwdDesc {
   float *g_items, *g_feats_w, *g_feats_b, *g_joint_w, *g_joint_b; /* accumulated into (caller zeroes) */
   float* g_pos;           /* [L, d] gradient of LearnableEncoding.encoding.weight, or NULL */
   float* workspace;       /* carca_embed_bwd_workspace(...) floats */
+  void* ev_early;         /* optional hipEvent_t recorded on `stream` right BEFORE the last launch (d feats_embed, as long as
+                           * the whole forward GEMM): behind it every other gradient of the model is final, so a gradient
+                           * all-reduce of everything but feats_embed.{weight,bias} can start under that kernel */
 } CarcaEmbedBwdDesc;
 size_t carca_embed_bwd_workspace(const int32_t* rows /*host [nseg]*/, int nseg, int d, int g);
 int carca_embed_bwd(const CarcaEmbedBwdDesc* desc /*host*/, void* stream);
@@ -559,6 +562,7 @@ int carca_forward(const CarcaForwardDesc* desc /*host*/, void* const* ev /*4 hip
 int carca_event_create(void** ev_out);
 int carca_event_destroy(void* ev);
 int carca_event_elapsed_ms(void* start, void* stop, float* ms_out); /* both must have completed */
+int carca_stream_wait_event(void* stream, void* event);            /* hipStreamWaitEvent */
 
 /* ---- a8: BinaryCrossEntropy.forward (carca.py:441-444) -----------------------------------------
  * loss = sum(l * m) / sum(m), l = -(t log(y+eps) + (1-t) log(1-y+eps)), m = (ids != 0).

@@ -55,7 +55,13 @@ def test_c4_touched_row_step_equals_the_dense_step(monkeypatch):
     assert torch.equal(wb[~touched], w0[~touched])          # (dense Adam does not move them either: update exactly 0)
     moved = (wa - w0).abs().sum(1) > 0
     assert int(moved.sum()) > 10_000 and not bool(moved[0])  # pad row 0 never moves (padding_idx, carca.py:73)
-    assert torch.allclose(wa, wb, rtol=0, atol=2e-5), float((wa - wb).abs().max())
+    # Same trajectory: 2 M touched elements agree to 2e-5 -- all but a handful.  Adam's first steps move an element by
+    # +-lr whatever the size of its gradient, so an element whose gradient is round-off sized (cancelling contributions:
+    # ~1e-7 of them per step at this size) follows the summation order of the fp32 atomics, which differs run to run in
+    # BOTH paths; such an element is at most 3 steps of lr away.
+    diff = (wa - wb).abs()
+    assert int((diff > 2e-5).sum()) <= 32 and float(diff.max()) <= 3.1e-3, (int((diff > 2e-5).sum()), float(diff.max()))
+    assert float(diff.mean()) < 1e-8
     for (n, a), (_, b) in zip(model_a.named_parameters(), model_b.named_parameters()):
         if n.endswith("WK.bias"):  # true gradient 0: Adam turns round-off into +-lr steps
             continue

@@ -78,27 +78,43 @@ def _worker(rank, world, port, ret):
                     else float((p.grad - ref).abs().max()))
     sums = torch.tensor([float(rank + 1), 2.0])
     cdist.allreduce_sums(sums)
-    # (a) gradients that are views of one flat buffer (what the HIP backward hands out) are reduced in place
+    # (a) gradients that are views of one flat buffer laid out [early | late | staging] (what the HIP backward hands out,
+    # autograd._grad_buffers) are reduced in place: the early range through handles the caller started itself (the
+    # sharded step starts them under the backward's last kernel), the late range by allreduce_gradients; the staging
+    # floats behind them are nobody's gradient and must come back untouched
     shapes = [(5, 3), (7,), (2, 2, 2)]
-    tot = sum((torch.Size(sh).numel() + 3) // 4 * 4 for sh in shapes)
-    flat = torch.arange(tot, dtype=torch.float32) * (rank + 1)
+    r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+    tot = sum(r4(torch.Size(sh).numel()) for sh in shapes)
+    flat = torch.arange(tot + 8, dtype=torch.float32) * (rank + 1)
     ps, off = [], 0
     for sh in shapes:
         n = torch.Size(sh).numel()
         p = torch.nn.Parameter(torch.zeros(sh))
         p.grad = flat[off: off + n].view(sh)
         ps.append(p)
-        off += (n + 3) // 4 * 4
-    assert cdist._shared_flat([p.grad for p in ps]) is not None
-    cdist.allreduce_gradients(ps, bucket_mb=1e-5)  # several chunks of the flat buffer
-    ok_flat = bool(torch.equal(flat, torch.arange(tot, dtype=torch.float32) * 3.0))
+        off += r4(n)
+    n_early = r4(15) + r4(7)
+
+    class _M:  # (stands in for the model: flat_layout reads model.__dict__["_flat_grad"])
+        pass
+
+    m = _M()
+    m.__dict__["_flat_grad"] = dict(flat=flat, early=(0, n_early), late=(n_early, tot), big=[], n_params=3)
+    info = cdist.flat_layout(m, ps)
+    assert info is not None and cdist.flat_layout(m, ps[:2]) is None
+    early = cdist.allreduce_range(flat, *info["early"], bucket_mb=1e-5)  # several chunks
+    cdist.allreduce_gradients(ps, bucket_mb=1e-5, flat_info=info, early_work=early)
+    want_flat = torch.arange(tot + 8, dtype=torch.float32) * 3.0
+    want_flat[tot:] = torch.arange(tot, tot + 8, dtype=torch.float32) * (rank + 1)
+    ok_flat = bool(torch.equal(flat, want_flat)) and cdist.last_reduce["path"] == "flat-inplace" and \
+        cdist.last_reduce["early_overlapped"]
     # (b) an embedding table's gradient exchanged as (row ids, row gradients) equals the dense all-reduce
     g = torch.Generator().manual_seed(10 + rank)
     table = torch.nn.Parameter(torch.zeros(50, 6))
-    ids = torch.randint(0, 50, (4, 9), generator=g)
+    ids = torch.randint(0, 50, (4 + rank, 9), generator=g)  # (ranks hold different numbers of ids: B % world != 0)
     ids[0, :3] = 0
     dense = torch.zeros(50, 6)
-    dense.index_add_(0, ids.reshape(-1), torch.randn(36, 6, generator=g))
+    dense.index_add_(0, ids.reshape(-1), torch.randn(ids.numel(), 6, generator=g))
     dense[0] = 0  # the pad row never gets a gradient (nn.Embedding(padding_idx=0))
     other = torch.nn.Parameter(torch.zeros(3))
     table.grad, other.grad = dense.clone(), torch.full((3,), float(rank + 1))

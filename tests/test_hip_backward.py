@@ -216,7 +216,7 @@ def test_c2_full_batch_gradients_are_the_weighted_sum_of_its_halves():
 
     def run(lo, hi):
         sub = tuple(t[lo:hi].contiguous() for t in batch)
-        loss = engine._forward_backward(model, opt, sub, False)
+        loss = engine._forward_backward(model, opt, sub, None)
         n = float((sub[3] != 0).sum())
         return float(loss), n, {k: p.grad.detach().clone() for k, p in model.named_parameters()}
 

@@ -162,3 +162,61 @@ def test_fused_torch_adam_does_not_leave_stale_packed_weights():
     fresh.fold_embedding(True)
     with torch.no_grad():
         assert torch.equal(model(profile=profile, targets=[pos, neg]), fresh(profile=profile, targets=[pos, neg]))
+
+
+def test_sharded_step_reduces_the_flat_buffer_in_place_and_equals_the_plain_step():
+    """The N > 1 train step on the HIP path, executed with a 1-rank process group (dist.FORCE_COLLECTIVES): global mask
+    count -> forward / backward normalised by it -> the backward's flat gradient buffer all-reduced IN PLACE, its early
+    range on a side stream gated by the event carca_embed_bwd records before its last launch -> one-launch Adam.
+    A 1-rank sum is the identity, so parameters must equal the unsharded step's bit for bit -- while every pointer, view
+    and stream hand-off of the sharded path has run.  Also through the hipGraph (GraphedTrainStep(sharded=True))."""
+    import copy
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from carca_replication_amd import dist as cdist
+    from carca_replication_amd import engine
+    from carca_replication_amd.optim import Adam
+    from tests.test_hip_graph import _setup
+
+    fresh, batch = _setup(0.0)
+    other = tuple(t.roll(1, 0) for t in batch)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cdist.FORCE_COLLECTIVES = True
+        model_p, opt_p = fresh()
+        model_s = copy.deepcopy(model_p)
+        opt_s = Adam(model_s.parameters(), lr=1e-3, betas=(0.9, 0.98))
+        model_g = copy.deepcopy(model_p)
+        opt_g = Adam(model_g.parameters(), lr=1e-3, betas=(0.9, 0.98))
+        step_g = engine.GraphedTrainStep(model_g, opt_g, batch, sharded=True)
+        for bt in (batch, other, batch):
+            cdist.last_reduce = {}
+            ls = engine.train_step(model_s, opt_s, bt, sharded=True)
+            assert cdist.last_reduce.get("path") == "flat-inplace" and cdist.last_reduce["early_overlapped"], cdist.last_reduce
+            assert cdist.last_reduce["launches"] == 2  # early range + late range (12 MB model: one chunk each)
+            cdist.last_reduce = {}
+            lg = step_g(bt)
+            assert cdist.last_reduce.get("path") == "flat-inplace" and not cdist.last_reduce["early_overlapped"]
+            cdist.FORCE_COLLECTIVES = False
+            lp = engine.train_step(model_p, opt_p, bt)
+            cdist.FORCE_COLLECTIVES = True
+            assert float(ls) == pytest.approx(float(lp), rel=1e-5) and float(lg) == pytest.approx(float(lp), rel=1e-5)
+        info = cdist.flat_layout(model_s, list(model_s.parameters()))
+        fw = model_s.embeds.feats_embed.weight
+        assert info["late"][1] - info["late"][0] >= fw.numel() and fw.grad.storage_offset() >= info["late"][0]
+        for (n, a), (_, b), (_, c) in zip(model_s.named_parameters(), model_p.named_parameters(), model_g.named_parameters()):
+            if n.endswith("WK.bias"):  # true gradient 0: Adam turns round-off (fp32 atomics) into +-lr steps
+                continue
+            assert torch.allclose(a, b, rtol=1e-3, atol=2e-5), n
+            assert torch.allclose(c, b, rtol=1e-3, atol=2e-5), n
+    finally:
+        cdist.FORCE_COLLECTIVES = False
+        dist.destroy_process_group()
