@@ -171,6 +171,85 @@ __global__ __launch_bounds__(256) void knn_score_kernel(const float* __restrict_
 
 inline int row_blocks(int rows) { return min((rows + 3) / 4, 4096); }
 
+__global__ void add_positions_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ pos,
+                                     float* __restrict__ out, int ldo, long rows, int T, int d) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * d) return;
+  const long r = i / d;
+  const int c = (int)(i - r * d);
+  out[r * ldo + c] = x[r * ldx + c] + pos[(r % T) * d + c];
+}
+
+// One wave per (user b, head h, query t): lanes walk the keys in strides of 64; scores are kept in registers for up to
+// MHA_KPL x 64 keys and recomputed beyond (never needed at the reference's sizes).  Same arithmetic order as
+// carca.py:251-259: additive mask before the scale, softmax, re-mask.
+#define MHA_KPL 16
+__global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                       const float* __restrict__ v, int ldk,
+                                                       const int32_t* __restrict__ q_ids, const int32_t* __restrict__ k_ids,
+                                                       int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
+                                                       float* __restrict__ out, int ldo, float* __restrict__ w_out) {
+  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wid >= (long)B * H * Tq) return;
+  const int t = (int)(wid % Tq);
+  const int h = (int)((wid / Tq) % H);
+  const int b = (int)(wid / ((long)Tq * H));
+  const int dh = d / H;
+  const float* qr = q + ((long)b * Tq + t) * ldq + h * dh;
+  const bool q_ok = q_ids[(long)b * Tq + t] != 0;
+  const float sqrt_dh = sqrtf((float)dh);
+  float sc[MHA_KPL];
+  bool ok[MHA_KPL];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < MHA_KPL; ++i) {
+    const int j = lane + 64 * i;
+    sc[i] = -3.0e38f;
+    ok[i] = false;
+    if (j < Tk) {
+      const float* kr = k + ((long)b * Tk + j) * ldk + h * dh;
+      float dot = 0.f;
+      for (int c = 0; c < dh; ++c) dot += qr[c] * kr[c];
+      ok[i] = q_ok && k_ids[(long)b * Tk + j] != 0 && (!has_causal || j - t <= causal);
+      sc[i] = ((ok[i] ? 0.0f : -4294967296.0f) + dot) / sqrt_dh;
+      mx = fmaxf(mx, sc[i]);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MHA_KPL; ++i)
+    if (lane + 64 * i < Tk) {
+      sc[i] = expf(sc[i] - mx);
+      sum += sc[i];
+    }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int i = 0; i < MHA_KPL; ++i) {
+    const int j = lane + 64 * i;
+    if (j < Tk) {
+      sc[i] = ok[i] ? sc[i] / sum : 0.f;  // softmax, then "* attn_mask" (carca.py:256)
+      if (w_out) w_out[(((long)h * B + b) * Tq + t) * Tk + j] = sc[i];
+    }
+  }
+  // out[c] = sum_j W[j] v[j][c]: a lane owns the head's columns lane and lane + 64; the weights travel by shuffle, which
+  // every lane executes (the key loop is uniform)
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MHA_KPL; ++i)
+    for (int l = 0; l < 64 && l + 64 * i < Tk; ++l) {
+      const float wj = __shfl(sc[i], l);
+      const float* vr = v + ((long)b * Tk + l + 64 * i) * ldk + h * dh;
+      if (lane < dh) acc0 += wj * vr[lane];
+      if (lane + 64 < dh) acc1 += wj * vr[lane + 64];
+    }
+  float* orow = out + ((long)b * Tq + t) * ldo + h * dh;
+  if (lane < dh) orow[lane] = acc0;
+  if (lane + 64 < dh) orow[lane + 64] = acc1;
+}
+
+
 }  // namespace
 
 extern "C" int carca_layernorm_fwd(const float* x, int ldx, float* y, int ldy, int rows, int d, const float* w,
@@ -254,6 +333,31 @@ extern "C" int carca_l2norm_bwd(const float* x, int ldx, const float* dy, int ld
   CARCA_CHECK_SUPPORTED(d <= 128 && ld_dx <= 128, "l2norm_bwd: d=%d / ld_dx=%d > 128", d, ld_dx);
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream_, x, ldx, dy, ld_dy, dx,
                      ld_dx, rows, d);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_add_positions(const float* x, int ldx, const float* pos, float* out, int ldo, int B, int T, int d,
+                                   void* stream_) {
+  CARCA_CHECK_ARG(x && pos && out && B >= 1 && T >= 1 && d >= 1 && ldx >= d && ldo >= d, "add_positions: bad arguments");
+  const long n = (long)B * T * d;
+  hipLaunchKernelGGL(add_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, ldx,
+                     pos, out, ldo, (long)B * T, T, d);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_mha_core(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
+                              const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
+                              float* out, int ldo, float* w_out, void* stream_) {
+  CARCA_CHECK_ARG(q && k && v && q_ids && k_ids && out, "mha_core: null pointer");
+  CARCA_CHECK_ARG(B >= 1 && Tq >= 1 && Tk >= 1 && d >= 1 && H >= 1 && d % H == 0 && ldq >= d && ldk >= d && ldo >= d,
+                  "mha_core: bad dims");
+  CARCA_CHECK_SUPPORTED(Tk <= 64 * MHA_KPL && d / H <= 128, "mha_core: Tk=%d > %d keys per query, or d/H=%d > 128", Tk,
+                        64 * MHA_KPL, d / H);
+  const long waves = (long)B * H * Tq;
+  hipLaunchKernelGGL(mha_core_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, q, ldq, k, v, ldk,
+                     q_ids, k_ids, B, Tq, Tk, d, H, has_causal, causal, out, ldo, w_out);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

@@ -91,6 +91,12 @@ def to(*tensors: Tensor, device: str) -> Tuple[Tensor, ...]:
 # ------------------------------------------------------------------------------------------------
 
 
+def _no_standalone_grad(x: Tensor, module: nn.Module) -> None:
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())):
+        raise CarcaHipError(f"{type(module).__name__}.forward on its own is built for inference (torch.no_grad()): the "
+                            "backward pass of the hot path runs through CARCA.forward")
+
+
 class IdentityEncoding(Encoding):
     def position_table(self, T: int) -> Optional[Tensor]:
         return None
@@ -112,7 +118,10 @@ class LearnableEncoding(Encoding):
         return self.encoding.weight[:T]
 
     def forward(self, x: Tensor) -> Tensor:
-        raise CarcaHipError("LearnableEncoding is applied inside the fused embedding kernel; call AllEmbedding/CARCA")
+        """Stand-alone use of the ABC (abstract.py:31, carca.py:25-31): x [B, T, d] + encoding[:T].  Inside CARCA the
+        table rides in the embedding GEMM's epilogue instead.  Inference only: gradients flow through CARCA.forward."""
+        _no_standalone_grad(x, self)
+        return ops.add_positions(x, self.position_table(x.shape[1]))
 
 
 class PositionalEncoding(Encoding):
@@ -131,7 +140,9 @@ class PositionalEncoding(Encoding):
         return self.pe[0, :T]
 
     def forward(self, x: Tensor) -> Tensor:
-        raise CarcaHipError("PositionalEncoding is applied inside the fused embedding kernel; call AllEmbedding/CARCA")
+        """Stand-alone use of the ABC (abstract.py:31, carca.py:54-60): x [B, T, d] + pe[:, :T]."""
+        _no_standalone_grad(x, self)
+        return ops.add_positions(x, self.position_table(x.shape[1]))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -618,8 +629,21 @@ class MultiHeadAttention(nn.Module):
         return mats + vecs
 
     def forward(self, query, key, value, q_mask, k_mask, causal: int = None, return_w: bool = False):
-        raise CarcaHipError("MultiHeadAttention runs fused inside SelfAttentionBlock / CrossAttentionBlock kernels; "
-                            "call the block instead")
+        """Stand-alone MultiHeadAttention.forward (carca.py:228-265), inference only: three row GEMMs for the projections
+        and carca_mha_core for the attention (the blocks' fused kernels never come here).  Returns the merged heads
+        [B, Tq, d], or (weights [H*B, Tq, Tk] before dropout, output) with return_w -- the reference's order."""
+        _no_standalone_grad(query, self)
+        if self.training and self.dropout.p > 0:
+            raise CarcaHipError("stand-alone MultiHeadAttention applies no dropout: call it in eval mode")
+        ops._need_cuda(query, key, value, q_mask, k_mask)
+        d = self.d
+        proj = []
+        for x, lin in ((query, self.WQ), (key, self.WK), (value, self.WV)):
+            x2 = ops._f32(x).reshape(-1, x.shape[-1])
+            (y,) = ops.gemm_rows([dict(a0=x2)], lin.weight.detach(), d, d, d, bias=lin.bias.detach())
+            proj.append(y.view(x.shape[0], x.shape[1], d))
+        out, w = ops.mha_core(proj[0], proj[1], proj[2], q_mask != 0, k_mask != 0, self.H, causal, return_w)
+        return (w, out) if return_w else out
 
 
 # Packed / composed weight caches are keyed on (data_ptr, _version) of their parameters -- but not every optimizer bumps

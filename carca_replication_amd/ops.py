@@ -881,6 +881,37 @@ def dot_score_bwd(p: Tensor, o: Tensor, y: Tensor, dy: Tensor, dp: Tensor, B: in
     return d_o
 
 
+def add_positions(x: Tensor, pos: Tensor) -> Tensor:
+    """Encoding.forward (carca.py:25-31, 54-60): x [B, T, d] + pos [T, d]."""
+    _need_cuda(x, pos)
+    x, pos = _f32(x), _f32(pos.detach()).contiguous()
+    if x.dim() != 3 or x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1) or pos.shape != (x.shape[1], x.shape[2]):
+        raise CarcaHipError("add_positions: x must be [B, T, d] with dense rows and pos [T, d]")
+    B, T, d = x.shape
+    out = torch.empty(B, T, d, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().carca_add_positions(x.data_ptr(), x.stride(1), pos.data_ptr(), out.data_ptr(), d, B, T, d,
+                                               _stream()), "add_positions")
+    return out
+
+
+def mha_core(q: Tensor, k: Tensor, v: Tensor, q_ids: Tensor, k_ids: Tensor, H: int, causal: Optional[int],
+             want_w: bool):
+    """Attention core of MultiHeadAttention.forward (carca.py:242-260) on projected q [B, Tq, d], k / v [B, Tk, d]."""
+    _need_cuda(q, k, v, q_ids, k_ids)
+    B, Tq, d = q.shape
+    Tk = k.shape[1]
+    q2, k2, v2 = (_f32(t).reshape(-1, d) for t in (q, k, v))
+    if k2.stride(0) != v2.stride(0):
+        raise CarcaHipError("mha_core: k and v must share their row stride")
+    qi, ki = _ids32(q_ids.reshape(-1)), _ids32(k_ids.reshape(-1))
+    out = torch.empty(B, Tq, d, dtype=torch.float32, device=q.device)
+    w = torch.empty(H * B, Tq, Tk, dtype=torch.float32, device=q.device) if want_w else None
+    _lib.check(_lib.load().carca_mha_core(q2.data_ptr(), q2.stride(0), k2.data_ptr(), v2.data_ptr(), k2.stride(0),
+                                          qi.data_ptr(), ki.data_ptr(), B, Tq, Tk, d, H, int(causal is not None),
+                                          int(causal or 0), out.data_ptr(), d, _ptr(w), _stream()), "mha_core")
+    return out, w
+
+
 def _user_rows(t: Tensor, name: str) -> Tensor:
     """[B, T, F] fp32 with contiguous rows per user (any user stride): as is; anything else: one contiguous copy."""
     _need_cuda(t)

@@ -354,6 +354,20 @@ int carca_l2norm_bwd(const float* x, int ldx, const float* dy, int ld_dy, float*
  * HBM-bound: B*T*F*4 bytes streamed once. */
 int carca_knn_score(const float* p_a, int64_t p_bstride, const float* o_a, int64_t o_bstride, const int32_t* p_x,
                     const int32_t* o_x, int table_rows, float* y, int B, int L, int T, int F, void* stream);
+/* ---- stand-alone pieces of the reference's module surface (abstract.py:31, carca.py:25-31, 54-60, 228-265) ----------
+ * The hot path never runs these (encodings ride in the embedding GEMM's epilogue, attention is fused into K2 / K4);
+ * they exist so that a caller who uses the modules the way the ABCs allow gets the reference's numbers instead of an
+ * exception.
+ * carca_add_positions: Encoding.forward(x): out[b][t][:] = x[b][t][:] + pos[t][:] for x [B*T, ldx], pos [T, d]. */
+int carca_add_positions(const float* x, int ldx, const float* pos, float* out, int ldo, int B, int T, int d, void* stream);
+/* carca_mha_core: the attention core of MultiHeadAttention.forward (carca.py:242-260) on PROJECTED inputs (plain feature
+ * order, head h = columns [h d/H, (h+1) d/H)): q [B*Tq, ldq], k, v [B*Tk, ldk]; mask = (q_ids != 0) x (k_ids != 0),
+ * lower-triangular with diagonal `causal` when has_causal; W = softmax((mask ? 0 : -2^32+1) + q k^T) / sqrt(d/H)) * mask;
+ * out [B*Tq, ldo] = W v with heads merged back; w_out (optional) [H*B, Tq, Tk], head-major like the reference's
+ * return_w (head h of user b at index h*B + b).  One wave per (user, head, query); any Tq, Tk. */
+int carca_mha_core(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
+                   const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal, float* out,
+                   int ldo, float* w_out /*or NULL*/, void* stream);
 /* Inverse of carca_pack_weights for gradients: real[r][c] (+)= packed[rp][cp] (same descriptor fields:
  * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
 int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);

@@ -56,11 +56,13 @@ def test_c4_touched_row_step_equals_the_dense_step(monkeypatch):
     moved = (wa - w0).abs().sum(1) > 0
     assert int(moved.sum()) > 10_000 and not bool(moved[0])  # pad row 0 never moves (padding_idx, carca.py:73)
     # Same trajectory: 2 M touched elements agree to 2e-5 -- all but a handful.  Adam's first steps move an element by
-    # +-lr whatever the size of its gradient, so an element whose gradient is round-off sized (cancelling contributions:
-    # ~1e-7 of them per step at this size) follows the summation order of the fp32 atomics, which differs run to run in
-    # BOTH paths; such an element is at most 3 steps of lr away.
+    # +-lr whatever the size of its gradient, so an element (or a whole item row: an item that only reaches the loss
+    # through vanishing attention weights) whose gradient is round-off sized follows the summation order of the fp32
+    # atomics, which differs run to run in BOTH paths: seen as one 128-element row 2.6e-3 apart in two runs of nine.
+    # Such elements are at most 2 lr per step apart.
     diff = (wa - wb).abs()
-    assert int((diff > 2e-5).sum()) <= 32 and float(diff.max()) <= 3.1e-3, (int((diff > 2e-5).sum()), float(diff.max()))
+    n_off = int((diff > 2e-5).sum())
+    assert n_off <= 2 * d + 32 and float(diff.max()) <= 6.1e-3, (n_off, float(diff.max()))
     assert float(diff.mean()) < 1e-8
     for (n, a), (_, b) in zip(model_a.named_parameters(), model_b.named_parameters()):
         if n.endswith("WK.bias"):  # true gradient 0: Adam turns round-off into +-lr steps

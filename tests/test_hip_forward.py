@@ -394,3 +394,56 @@ def test_c2_full_batch_is_batch_split_invariant(d, H, g):
     want = O.carca_forward(P, cfg, tuple(t[:8] for t in profile), [tuple(t[:8] for t in target)], training=False)
     assert float((full[:8] - want).abs().max()) < Y_ATOL
     assert torch.equal(O.positive_rank(full[:8]), O.positive_rank(want))
+
+
+# ---- the stand-alone module surface of the ABCs (abstract.py:31, carca.py:25-31, 54-60, 228-265) -----------------------
+@pytest.mark.parametrize("name", ["d90h3", "d64h2"])
+def test_standalone_mha_returns_the_references_decoder_weights(name):
+    """MultiHeadAttention.forward(..., return_w=True) on its own: the weights equal fixture G1's `dec_w0` (captured from
+    the reference's decoder.attn with return_w=True, carca.py:262-263) and the output equals the oracle's."""
+    fx = load("g1_" + name)
+    model = model_from_fixture(fx).eval()
+    o_e, p_e = fx.outs["o_embed0"].cuda(), fx.outs["p_final"].cuda()
+    o_mask, p_mask = (fx.ins["o_x"] != 0).float().cuda(), fx.outs["p_mask"].cuda()
+    with torch.no_grad():
+        w, out = model.decoder.attn(o_e, p_e, p_e, q_mask=o_mask, k_mask=p_mask, causal=None, return_w=True)
+        out_only = model.decoder.attn(o_e, p_e, p_e, q_mask=o_mask, k_mask=p_mask)
+    B, H = o_e.shape[0], model.decoder.attn.H
+    assert w.shape == (H * B, o_e.shape[1], p_e.shape[1])  # head-major, head h of user b at h*B + b (carca.py:242-244)
+    got = torch.stack(torch.split(w, B, dim=0), dim=1).cpu()
+    assert float((got - fx.outs["dec_w0"]).abs().max()) < 2e-6
+    P = {k: v for k, v in fx.params.items()}
+    w_o, out_o = O.mha(P, "decoder.attn.", H, fx.outs["o_embed0"], fx.outs["p_final"], fx.outs["p_final"],
+                       (fx.ins["o_x"] != 0).float(), fx.outs["p_mask"], None)
+    assert float((out.cpu() - out_o).abs().max()) < 1e-5 and torch.equal(out, out_only)
+    # causal variants (what the blocks pass: 0 in SelfAttentionBlock, -1 in the training decoder)
+    L = p_e.shape[1]
+    with torch.no_grad():
+        for causal in (0, -1):
+            wc, oc = model.encoder[0].attn(p_e, p_e, p_e, q_mask=p_mask, k_mask=p_mask, causal=causal, return_w=True)
+            w_r, o_r = O.mha(P, "encoder.0.attn.", H, fx.outs["p_final"], fx.outs["p_final"], fx.outs["p_final"],
+                             fx.outs["p_mask"], fx.outs["p_mask"], causal)
+            assert float((torch.stack(torch.split(wc, B, dim=0), dim=1).cpu() - w_r).abs().max()) < 2e-6
+            assert float((oc.cpu() - o_r).abs().max()) < 1e-5
+    assert L == fx.dim["L"]
+
+
+def test_standalone_encodings_add_their_table():
+    """Encoding.forward(x) (abstract.py:31): Identity returns x, Learnable / Positional add their first T rows."""
+    from carca_replication_amd import CarcaHipError
+    from carca_replication_amd import modules as M
+
+    torch.manual_seed(0)
+    x = torch.randn(3, 7, 10, device="cuda")
+    assert M.IdentityEncoding()(x) is x
+    le = M.LearnableEncoding(10, 9).cuda()
+    pe = M.PositionalEncoding(10, 9).cuda()
+    with torch.no_grad():
+        assert torch.equal(le(x), x + le.encoding.weight[:7])
+        assert torch.equal(pe(x), x + pe.pe[:, :7])
+        view = torch.randn(3, 7, 16, device="cuda")[..., :10]  # rows of a padded buffer
+        assert torch.equal(pe(view), view + pe.pe[:, :7])
+        with pytest.raises(CarcaHipError):
+            le(torch.randn(3, 12, 10, device="cuda"))  # longer than max_len
+    with pytest.raises(CarcaHipError):  # gradients flow through CARCA.forward, not through the stand-alone module
+        le(x)
