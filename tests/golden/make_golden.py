@@ -17,6 +17,7 @@ seeded inputs and storing inputs, weights and outputs as small .npz files:
   g6_shapes.npz  squeeze() quirks, B=1 and N=1             (carca.py:346)
   g7_<variant>.npz learnable / positional encoding, residual=False
   g8_ranking.npz briefly trained weights -> per-user rank, HR@10, NDCG@10
+  g11_ranking_c2dims.npz the same at BASELINE config 2's model dimensions (d 90, g 450, H 3, L 50, N 101)
   g9_<variant>.npz ablation embeddings (attrctx, attr, id, mlpid) and decoders (dot, wdot, wdot + l2 norm):
                  eval scores + loss, train-mode scores + loss + all grads   (carca.py:98-198,352-399)
 
@@ -379,8 +380,42 @@ def main_g10():
     save("g10_knn", {}, dict(B=6, L=12, N=21), {}, ins, outs)
 
 
+def main_g11():
+    """G11: G8 at the MODEL dimensions of BASELINE config 2 (d = 90, g = 450, H = 3, 2 blocks, L = 50, N = 1 + 100): trained
+    weights, so that the scores are spread like a real model's, and every user's rank of the positive.  n_attrs / n_items
+    are small (the fixture must stay ~1 MB); the profile lengths are BASELINE's U{3..L}."""
+    cfg = CFGS["d90h3"]
+    L, N, n_items, n_attrs, n_ctx = 50, 101, 600, 16, 6
+    assert cfg["d"] == 90 and cfg["g"] == 450 and cfg["H"] == 3 and cfg["n_blocks"] == 2
+    model = build(cfg, n_items, n_attrs, n_ctx, L, p=0.0, seed=6)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    for step in range(30):
+        xt = make_inputs(24, L, N, n_items, n_attrs, n_ctx, seed=300 + step, train_shape=True)
+        train_trace(model, xt)
+        opt.step()
+    model.eval()
+    for seed in range(19, 60):  # the first batch whose every positive is at least 3e-6 away from its nearest competitor:
+        # "the same rank" is only well defined beyond the fp32 round-off of two correct implementations (~5e-7)
+        x = make_inputs(48, L, N, n_items, n_attrs, n_ctx, seed=seed, distinct=True)
+        with torch.no_grad():
+            y = model.forward((x["p_x"], x["p_a"], x["p_c"]), [(x["o_x"], x["o_a"], x["o_c"])])
+        rank = (y[:, 1:] > y[:, :1]).sum(1)
+        ties = int((y[:, 1:] == y[:, :1]).sum())
+        gap = (y[:, 1:] - y[:, :1]).abs().min(dim=1).values
+        if ties == 0 and float(gap.min()) > 3e-6:
+            break
+    print("G11 input seed", seed)
+    outs = dict(y=y, rank=rank, ties=np.array(ties), min_gap=gap, hr10=np.float64(RT.compute_HR(y, x["y_true"], 10)),
+                ndcg10=np.float64(RT.compute_NDCG(y, x["y_true"], 10)))
+    print("G11: ranks", rank.tolist(), "ties", ties, "smallest gap", float(gap.min()), "y range", float(y.min()), float(y.max()))
+    save("g11_ranking_c2dims", cfg, dict(B=48, L=L, N=N, n_items=n_items, n_attrs=n_attrs, n_ctx=n_ctx), model.state_dict(),
+         x, outs)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "g11"):
+        main_g11()
     if which in ("all", "main"):
         main()
     if which in ("all", "g9"):

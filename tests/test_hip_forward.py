@@ -105,6 +105,31 @@ def test_g8_ranking_hr_ndcg_identical():
     assert float(sums[2]) == 0.0
 
 
+def test_g11_ranking_at_c2_model_dims_is_identical():
+    """The same at BASELINE config 2's model dimensions (d = 90, g = 450, H = 3, 2 blocks, L = 50, N = 1 + 100, profile
+    lengths U{3..L}) with trained weights: every user's rank of the positive, HR@10 and NDCG@10 equal the reference's;
+    the folded scoring kernel and the V-materialising one agree on them too."""
+    from carca_replication_amd import _lib, ops
+
+    fx = load("g11_ranking_c2dims")
+    assert (fx.cfg["d"], fx.cfg["g"], fx.cfg["H"], fx.dim["L"], fx.dim["N"]) == (90, 450, 3, 50, 101)
+    model = model_from_fixture(fx).eval()
+    lib = _lib.load()
+    try:
+        for force_materialised in (0, 1):
+            lib.carca_set_tuning(6, force_materialised)
+            with torch.no_grad():
+                y = model(*_eval_in(fx))
+            assert float((y.cpu() - fx.outs["y"]).abs().max()) < Y_ATOL
+            sums, rank = ops.rank_metrics(y, 10, want_rank=True)
+            assert torch.equal(rank.cpu().long(), fx.outs["rank"].long())
+            sums = sums.cpu()
+            assert float(sums[0]) == float(fx.outs["hr10"]) and float(sums[2]) == 0.0
+            assert abs(float(sums[1]) - float(fx.outs["ndcg10"])) < 1e-4
+    finally:
+        lib.carca_set_tuning(6, 0)
+
+
 def test_g4_rank_metrics_kernel():
     from carca_replication_amd import ops
 

@@ -172,8 +172,9 @@ def test_g10_knn_baseline(tag):
     assert torch.allclose(yt, fx.outs[tag + "/train/y"], atol=1e-5, rtol=1e-6)
 
 
-def test_g8_ranking_after_training():
-    fx = load("g8_ranking")
+@pytest.mark.parametrize("name", ["g8_ranking", "g11_ranking_c2dims"])
+def test_g8_ranking_after_training(name):
+    fx = load(name)
     cfg = oracle_config(fx.cfg)
     profile, targets = _eval_inputs(fx.ins)
     y = O.carca_forward(fx.params, cfg, profile, targets, training=False)
