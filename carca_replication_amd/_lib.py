@@ -157,7 +157,7 @@ class CaSave(C.Structure):
 
 class CrossBwdGroup(C.Structure):
     _fields_ = [("qh", _fp), ("y", _fp), ("dy", _fp), ("ids", _fp), ("dqh", _fp), ("dlogit", _fp), ("m_attn", _fp),
-                ("N", C.c_int32)]
+                ("N", C.c_int32), ("ld_y", C.c_int32)]
 
 
 class AdamTensor(C.Structure):
@@ -173,7 +173,7 @@ class SaBwdDesc(C.Structure):
 
 
 class CrossBwdIn(C.Structure):
-    _fields_ = [(n, _fp) for n in ("qh", "y", "dy", "ids", "o", "m_attn", "de")] + [("N", C.c_int32)]
+    _fields_ = [(n, _fp) for n in ("qh", "y", "dy", "ids", "o", "m_attn", "de")] + [("N", C.c_int32), ("ld_y", C.c_int32)]
 
 
 class CrossBwdDesc(C.Structure):
@@ -207,7 +207,7 @@ class CaWeights(C.Structure):
 
 
 class TargetGroup(C.Structure):
-    _fields_ = [("o", _fp), ("ids", _fp), ("y", _fp), ("N", C.c_int32)]
+    _fields_ = [("o", _fp), ("ids", _fp), ("y", _fp), ("N", C.c_int32), ("ldy", C.c_int32)]
 
 
 MAX_BLOCKS = 8
@@ -220,7 +220,7 @@ class ForwardDesc(C.Structure):
                 ("joint_w", _fp), ("joint_b", _fp), ("pos", _fp), ("zq", _fp), ("x_work", _fp * 2),
                 ("sa", SaWeights * MAX_BLOCKS), ("sa_residual", C.c_int32 * MAX_BLOCKS), ("ca", CaWeights),
                 ("ca_residual", C.c_int32), ("training", C.c_int32), ("y", _fp * MAX_GROUPS),
-                ("N", C.c_int32 * MAX_GROUPS), ("p_normed", _fp), ("fold_wc", _fp), ("fold_bias", _fp),
+                ("N", C.c_int32 * MAX_GROUPS), ("ldy", C.c_int32), ("p_normed", _fp), ("fold_wc", _fp), ("fold_bias", _fp),
                 ("fold_ldwc", C.c_int32), ("x_out", _fp * MAX_BLOCKS), ("sa_save", SaSave * MAX_BLOCKS), ("ca_save", CaSave),
                 ("save_blocks", C.c_int32), ("save_cross", C.c_int32), ("p_embed", C.c_float), ("p_block", C.c_float),
                 ("p_cross", C.c_float), ("seed", C.c_uint64), ("m_embed", _fp), ("seed_offset", C.c_void_p),

@@ -222,6 +222,13 @@ class _CarcaFn(torch.autograd.Function):
             ctx.model = model
             ctx.params = params
             ctx.st = st
+            joint = getattr(ys, "joint", None)
+            if joint is not None and len(ys) > 1:
+                # one output tensor [B, sum N] whose column blocks are the groups' scores: autograd then hands the
+                # backward ONE gradient tensor, read in place through a row stride (no cat forward, no split copies back)
+                st["Ns"] = [int(y.shape[1]) for y in ys]
+                ctx.save_for_backward(joint)
+                return joint
             ctx.save_for_backward(*ys)
             return tuple(ys)
         if emb.__dict__.get("_fold_train"):  # CARCA.fold_embedding(True, training=True): the re-associated embedding
@@ -307,7 +314,15 @@ class _CarcaFn(torch.autograd.Function):
         gbp = {id(p): g for p, g in zip(params, grads)}
         ys = ctx.saved_tensors
         ngroups = st["ngroups"]
-        dys = [dys[gi].contiguous() if dys[gi] is not None else torch.zeros_like(ys[gi]) for gi in range(ngroups)]
+        if "Ns" in st:  # joint output: per-group views of the one score / gradient tensor
+            dy_all = dys[0] if dys[0] is not None else torch.zeros_like(ys[0])
+            if dy_all.stride(1) != 1 or dy_all.stride(0) != ys[0].stride(0):
+                dy_all = dy_all.contiguous()
+            cuts = [sum(st["Ns"][:i]) for i in range(ngroups + 1)]
+            ys = [ys[0][:, cuts[i]: cuts[i + 1]] for i in range(ngroups)]
+            dys = [dy_all[:, cuts[i]: cuts[i + 1]] for i in range(ngroups)]
+        else:
+            dys = [dys[gi].contiguous() if dys[gi] is not None else torch.zeros_like(ys[gi]) for gi in range(ngroups)]
         # the small weight-gradient products feed nothing downstream: collected, then issued as ONE grouped launch
         wg = ops.WgradGroup()
         if st["is_ca"]:
@@ -353,7 +368,18 @@ def carca_forward_with_grad(model, profile, targets) -> List[Tensor]:
     if any(t is not None and t.requires_grad for t in profile) or \
             any(t is not None and t.requires_grad for grp in targets for t in grp):
         raise CarcaHipError("gradients with respect to the input tensors (ids/attrs/ctx) are not produced")
-    return list(_CarcaFn.apply(model, tuple(profile), [tuple(g) for g in targets], *params))
+    out = _CarcaFn.apply(model, tuple(profile), [tuple(g) for g in targets], *params)
+    if isinstance(out, Tensor):  # the groups' scores as column blocks of one tensor (modules.JointScores)
+        from .modules import JointScores
+
+        ys = JointScores()
+        ys.joint = out
+        off = 0
+        for grp in targets:
+            ys.append(out[:, off: off + grp[0].shape[1]])
+            off += grp[0].shape[1]
+        return ys
+    return list(out)
 
 
 class _BceFn(torch.autograd.Function):

@@ -297,6 +297,7 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     groups[gi].ids = D->segs[gi + 1].ids;
     groups[gi].y = D->y[gi];
     groups[gi].N = D->N[gi];
+    groups[gi].ldy = D->ldy;
   }
   // ev[2], ev[3]: bound to the scoring kernel's own dispatch, like ev[0], ev[1] to the feature GEMM's
   if (ev && ev[2] && ev[3]) carca_arm_launch_events(ev[2], ev[3]);

@@ -461,6 +461,7 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
     for (int n0 = 0; n0 < grp.N; n0 += 64) {
       const int nq = min(64, grp.N - n0), QT = (nq + 15) >> 4;
       const size_t gbase = (size_t)u * grp.N + n0;
+      const size_t ybase = (size_t)u * (grp.ld_y ? grp.ld_y : grp.N) + n0;  // y and dy may be column blocks of [B, sum N]
       __syncthreads();  // previous chunk's phase 2 is done with Qs / dls
       for (int i = tid; i < 16 * QT * V4; i += 512) {
         const int r = i / V4, c4 = i - r * V4;
@@ -471,8 +472,8 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
       if (tid < 64) {
         float dl = 0.f;
         if (tid < nq) {
-          const float yv = grp.y[gbase + tid];
-          dl = grp.dy[gbase + tid] * yv * (1.0f - yv);  // d sigmoid
+          const float yv = grp.y[ybase + tid];
+          dl = grp.dy[ybase + tid] * yv * (1.0f - yv);  // d sigmoid
           if (grp.dlogit && part == 0) grp.dlogit[gbase + tid] = dl;
         }
         dls[tid] = dl;

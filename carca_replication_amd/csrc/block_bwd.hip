@@ -186,6 +186,7 @@ extern "C" int carca_cross_score_bwd(const CarcaCrossBwdDesc* D, CarcaWgradDesc*
     grp[g].dlogit = dls[g] = ws;         ws += (gr + 3) / 4 * 4;
     grp[g].m_attn = drop ? in.m_attn : nullptr;
     grp[g].N = in.N;
+    grp[g].ld_y = in.ld_y;
   }
   int rc;
   // attention core + sigmoid(ffn(.)) head: dQ per group, dK, dV, dlogit, the attention part of d ffn.weight

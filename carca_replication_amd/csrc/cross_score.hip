@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_score_kernel_w16(const float
         float logit = ffn_b;
 #pragma unroll
         for (int h = 0; h < NH; ++h) logit += Yp[(tl * NH + h) * 16 + l16];
-        grp.y[(size_t)u * grp.N + n] = 1.0f / (1.0f + expf(-logit));
+        grp.y[(size_t)u * (grp.ldy ? grp.ldy : grp.N) + n] = 1.0f / (1.0f + expf(-logit));
       }
     }
     __syncthreads();
@@ -354,17 +354,18 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   // Group of a PER-LANE tile by selects over the (at most three) groups: indexing a.g[] with a per-lane index makes the
   // compiler fetch the kernel arguments through vector memory, dependent load after dependent load.
   struct Grp {
-    int N, ts;
+    int N, ts, ldy;
     const float* o;
     const int32_t* ids;
     float* y;
   };
   auto group_of = [&](int tile) {
-    Grp g{a.g[0].N, 0, a.g[0].o, a.g[0].ids, a.g[0].y};
+    Grp g{a.g[0].N, 0, a.g[0].ldy ? a.g[0].ldy : a.g[0].N, a.g[0].o, a.g[0].ids, a.g[0].y};
 #pragma unroll
     for (int i = 1; i < CARCA_MAX_GROUPS; ++i) {
       const bool in = i < a.ngroups && tile >= a.tile_start[i];
       g.N = in ? a.g[i].N : g.N;
+      g.ldy = in ? (a.g[i].ldy ? a.g[i].ldy : a.g[i].N) : g.ldy;
       g.ts = in ? a.tile_start[i] : g.ts;
       g.o = in ? a.g[i].o : g.o;
       g.ids = in ? a.g[i].ids : g.ids;
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
         float logit = ffn_b;
 #pragma unroll
         for (int h = 0; h < NH; ++h) logit += Yp[(tl * NH + h) * 16 + l16];
-        g.y[(size_t)u * g.N + n] = 1.0f / (1.0f + expf(-logit));
+        g.y[(size_t)u * g.ldy + n] = 1.0f / (1.0f + expf(-logit));
       }
     }
     if (t0 + TPR < t_hi) __syncthreads();
@@ -874,8 +875,9 @@ extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t*
   GroupsDev gd{};
   int t = 0;
   for (int i = 0; i < ngroups; ++i) {
-    CARCA_CHECK_ARG(groups[i].o && groups[i].ids && groups[i].y && groups[i].N >= 1, "cross_score_fwd: group %d malformed",
-                    i);
+    CARCA_CHECK_ARG(groups[i].o && groups[i].ids && groups[i].y && groups[i].N >= 1 &&
+                        (groups[i].ldy == 0 || groups[i].ldy >= groups[i].N),
+                    "cross_score_fwd: group %d malformed", i);
     gd.g[i] = groups[i];
     gd.tile_start[i] = t;
     t += (groups[i].N + 15) / 16;

@@ -108,12 +108,14 @@ def _forward_backward(model, optim, batch, denom: Optional[torch.Tensor]) -> tor
         pos, neg = (ids2[0],) + pos[1:], (ids2[1],) + neg[1:]
     optim.zero_grad(set_to_none=True)
     y = model(profile=(p_x, p_a, p_c), targets=[pos, neg])
-    if o_x.dtype == torch.int32:  # BinaryCrossEntropy(y, y_true, get_mask(o_x)) without materialising the float mask
-        from .autograd import bce_with_grad
-
-        loss = bce_with_grad(y, y_true, None, 1e-8, denom, ids=o_x)
-    else:
-        loss = _loss_fn(y, y_true, get_mask(o_x), denom=denom)
+    if o_x.dtype == torch.int32 and y.dim() == 2 and y.shape == o_x.shape and y.is_contiguous():
+        # BinaryCrossEntropy(y, y_true, get_mask(o_x)) (carca.py:441-444) and its derivative from ONE kernel, the backward
+        # pass seeded with that derivative: no float mask, no autograd node for the loss, no ones-fill / multiply for
+        # d loss / d loss = 1
+        loss, dy = ops.bce_fwd(y.detach(), y_true, o_x, 1e-8, want_grad=True, denom=denom)
+        torch.autograd.backward(y, dy.view_as(y))
+        return loss
+    loss = _loss_fn(y, y_true, get_mask(o_x), denom=denom)
     loss.backward()
     return loss.detach()
 

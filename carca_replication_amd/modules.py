@@ -847,6 +847,11 @@ class CrossAttentionBlock(_PackedModule, Decoder):
         return y.squeeze()  # bare squeeze, as carca.py:346
 
 
+class JointScores(list):
+    """The per-group score tensors of one forward, views of `.joint` [B, sum N] (column blocks in group order)."""
+    joint: Optional[Tensor] = None
+
+
 def _pad_cols(t: Tensor, width: int) -> Tensor:
     """[.., w] -> contiguous [.., width] with zero pad columns (data movement only)."""
     if t.shape[-1] == width and t.is_contiguous():
@@ -897,6 +902,10 @@ class CARCA(_PackedModule, Model):
             ys = carca_forward_with_grad(self, profile, targets)
         else:
             ys = self.forward_nograd(profile, targets)
+        joint = getattr(ys, "joint", None)
+        if joint is not None and isinstance(self.decoder, CrossAttentionBlock) and joint.shape[0] > 1 and \
+                all(y.shape[1] > 1 for y in ys):
+            return joint  # = torch.cat([y.squeeze() for y in ys], -1): no size-1 dimension for the squeeze to drop
         # each group's scores are squeezed the way CrossAttentionBlock does (carca.py:346), then joined (carca.py:431);
         # the dot decoders return [B, T] unsqueezed (carca.py:361-367)
         if isinstance(self.decoder, CrossAttentionBlock):
@@ -1009,11 +1018,17 @@ class CARCA(_PackedModule, Model):
         D.ca = dec.weights_struct(dev, self.norm, repack)
         ops.pack_many(repack)
         D.ca_residual, D.training = int(bool(dec.residual)), int(bool(self.training))
-        ys = []
+        # the groups' scores are written as column blocks of ONE [B, sum N] tensor: what carca.py:431's torch.cat builds,
+        # without the copy (and without the split / re-gather of its gradient in the backward pass)
+        ys = JointScores()
+        ys.joint = torch.empty(B, sum(Ns), dtype=torch.float32, device=dev)
+        off = 0
         for gi, N in enumerate(Ns):
-            y = torch.empty(B, N, dtype=torch.float32, device=dev)
+            y = ys.joint[:, off: off + N]
             ys.append(y)
             D.y[gi], D.N[gi] = y.data_ptr(), N
+            off += N
+        D.ldy = sum(Ns)
         D.p_normed = None
         if train is not None:
             _, _, dpo = ops.padded_dims(d, H)

@@ -696,13 +696,18 @@ def cross_score_bwd(groups, p_ids: Tensor, kh: Tensor, vh: Tensor, p_normed: Ten
     ws = torch.empty(lib.carca_cross_score_bwd_workspace(B, L, d, H, Ns, ng), dtype=torch.float32, device=kh.device)
     keep, des = [ws], []
     for i, (qh, y, dy, ids, o, m_attn) in enumerate(groups):
-        y, dy, ids32 = _f32(y), _f32(dy), _ids32(ids)
+        # y / dy: [B, N] dense, or column blocks of a [B, sum N] tensor (same row stride for both)
+        if y.dtype != torch.float32 or dy.dtype != torch.float32 or y.stride(1) != 1 or dy.stride(1) != 1 or \
+                y.stride(0) != dy.stride(0):
+            y, dy = _f32(y.contiguous()), _f32(dy.contiguous())
+        ids32 = _ids32(ids)
         de = torch.empty(o.shape[0], dpi, dtype=torch.float32, device=o.device)
         if o.stride(0) != dpi or o.stride(1) != 1:
             raise CarcaHipError("cross_score_bwd: embedded targets must be [rows, DPI] dense")
         G = D.group[i]
         G.qh, G.y, G.dy, G.ids, G.o, G.de, G.N = (qh.data_ptr(), y.data_ptr(), dy.data_ptr(), ids32.data_ptr(), o.data_ptr(),
                                                   de.data_ptr(), y.shape[1])
+        G.ld_y = y.stride(0)
         G.m_attn = m_attn.data_ptr() if (m_attn is not None and drop_p > 0) else None
         keep += [qh, y, dy, ids32, o, m_attn]
         des.append(de)

@@ -265,8 +265,10 @@ typedef struct CarcaCaWeights {
 typedef struct CarcaTargetGroup {
   const float* o;     /* embedded targets [B*N, ldo] */
   const int32_t* ids; /* [B*N] */
-  float* y;           /* [B*N] */
+  float* y;           /* [B, N], row stride ldy */
   int32_t N;
+  int32_t ldy;        /* elements between users in y; 0 = N (dense).  > N: the groups' scores are column blocks of ONE
+                       * [B, sum N] tensor (what CARCA.forward's torch.cat would build, carca.py:431) */
 } CarcaTargetGroup;
 typedef struct CarcaCaSave {
   float *kh, *vh;              /* [B*L, DPO] */
@@ -311,6 +313,7 @@ typedef struct CarcaCrossBwdGroup {
   float* dlogit;      /* [B*N] out, or NULL */
   const uint8_t* m_attn; /* [B, H, N, L] keep-mask saved by the forward, or NULL */
   int32_t N;
+  int32_t ld_y;          /* elements between users in y AND dy; 0 = N (see CarcaTargetGroup.ldy) */
 } CarcaCrossBwdGroup;
 int carca_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids, const CarcaCrossBwdGroup* groups,
                          int ngroups, const float* ffn_w_pad, float* dkh, float* dvh, float* d_ffn_w_pad, int B, int L,
@@ -413,6 +416,7 @@ typedef struct CarcaCrossBwdIn {
   const uint8_t* m_attn; /* keep-mask of the forward (drop_p > 0) or NULL */
   float* de;             /* out [B*N, DPI]: gradient of the embedded targets */
   int32_t N;
+  int32_t ld_y;          /* elements between users in y AND dy; 0 = N */
 } CarcaCrossBwdIn;
 typedef struct CarcaCrossBwdDesc {
   int32_t B, L, d, H, ngroups, residual, training;
@@ -540,8 +544,9 @@ typedef struct CarcaForwardDesc {
   int32_t sa_residual[CARCA_MAX_BLOCKS];
   CarcaCaWeights ca;
   int32_t ca_residual, training;
-  float* y[CARCA_MAX_GROUPS];   /* [B, N_g] outputs */
+  float* y[CARCA_MAX_GROUPS];   /* [B, N_g] outputs, row stride ldy */
   int32_t N[CARCA_MAX_GROUPS];
+  int32_t ldy;                  /* 0 = every group dense [B, N_g]; else the groups are column blocks of one [B, ldy] tensor */
   float* p_normed;              /* optional [B*L, ld_e] */
   /* Optional FOLDED embedding (inference with frozen weights).  AllEmbedding has no nonlinearity (carca.py:86-89),
    * so e = z W_jz^T + [a;c] (W_jq W_f)^T + (W_jq b_f + b_j): with fold_wc = W_jq W_f [d, F] (row stride

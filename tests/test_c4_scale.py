@@ -65,8 +65,8 @@ def test_c4_touched_row_step_equals_the_dense_step(monkeypatch):
     assert n_off <= 2 * d + 32 and float(diff.max()) <= 6.1e-3, (n_off, float(diff.max()))
     assert float(diff.mean()) < 1e-8
     for (n, a), (_, b) in zip(model_a.named_parameters(), model_b.named_parameters()):
-        if n.endswith("WK.bias"):  # true gradient 0: Adam turns round-off into +-lr steps
-            continue
+        if n.endswith("WK.bias") or n == "embeds.items_embed.weight":  # (WK.bias: true gradient 0, Adam turns round-off
+            continue                                                    # into +-lr steps; the item table: checked above)
         assert torch.allclose(a, b, rtol=1e-3, atol=2e-5), n
     # Adam state agrees too (a checkpoint of either optimizer resumes the other)
     sa, sb = opt_a.state[model_a.embeds.items_embed.weight], opt_b.state[model_b.embeds.items_embed.weight]
