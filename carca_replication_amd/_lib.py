@@ -18,7 +18,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libcarca_hip.so")
 _STAMP = LIB_PATH + ".srchash"
-SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip", "block_bwd.hip", "optim.hip"]
+SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "sa_eval.hip", "cross_score.hip", "loss_metrics.hip", "backward.hip", "block_bwd.hip", "optim.hip"]
 HEADERS = ["carca_common.h", "attn_common.h"]
 
 MAX_SEGS = 4
@@ -243,6 +243,7 @@ SIGNATURES = {
     "carca_gemm_wgrad_group": (_i, [C.POINTER(WgradDesc), _i, _fp]),
     "carca_sa_block_fwd": (_i, [_fp, _i, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SaWeights), _i, C.POINTER(SaSave),
                                 C.POINTER(Dropout), _fp]),
+    "carca_sa_block_eval": (_i, [_fp, _i, _fp, _fp, _i, _i, _i, _i, _i, C.POINTER(SaWeights), _i, _i, _fp]),
     "carca_cross_score_fwd": (_i, [_fp, _i, _fp, _fp, C.POINTER(TargetGroup), _i, _i, _i, _i, _i, _i,
                                    C.POINTER(CaWeights), _i, _i, C.POINTER(CaSave), C.POINTER(Dropout), _fp]),
     "carca_dropout_fwd": (_i, [_fp, _i, _i, _i, C.POINTER(Dropout), _fp, _fp]),

@@ -286,9 +286,15 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     float* y = D->x_out[i] ? D->x_out[i] : D->x_work[i & 1];
     CarcaDropout dr{D->p_block, D->seed, (uint32_t)(4 * i), D->seed_offset};
     if (i == 0 && ev && D->n_events >= 8 && ev[4] && ev[5]) carca_arm_launch_events(ev[4], ev[5]);
-    CARCA_TRY(carca_sa_block_fwd(x, D->ld_e, D->segs[0].ids, y, D->ld_e, D->B, D->L, D->d, D->H, &D->sa[i],
-                                 D->sa_residual[i], D->save_blocks ? &D->sa_save[i] : nullptr,
-                                 D->p_block > 0.f ? &dr : nullptr, stream_));
+    if (!D->save_blocks && !(D->p_block > 0.f) && !(D->p_embed > 0.f))
+      // eval: the profile's leading pad rows are equal here (zeros out of the masked embedding, carca.py:94, then each
+      // block's own image of them): the kernel computes one of them per user
+      CARCA_TRY(carca_sa_block_eval(x, D->ld_e, D->segs[0].ids, y, D->ld_e, D->B, D->L, D->d, D->H, &D->sa[i],
+                                    D->sa_residual[i], 1, stream_));
+    else
+      CARCA_TRY(carca_sa_block_fwd(x, D->ld_e, D->segs[0].ids, y, D->ld_e, D->B, D->L, D->d, D->H, &D->sa[i],
+                                   D->sa_residual[i], D->save_blocks ? &D->sa_save[i] : nullptr,
+                                   D->p_block > 0.f ? &dr : nullptr, stream_));
     x = y;
   }
   CarcaTargetGroup groups[CARCA_MAX_GROUPS];

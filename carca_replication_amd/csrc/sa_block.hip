@@ -277,18 +277,41 @@ int launch_sa(const float* x, int ldx, const int32_t* ids, float* y, int ldy, in
 
 }  // namespace
 
+int carca_sa_eval_launch(const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d, int H,
+                         const CarcaSaWeights* w, int residual, int pads_uniform, hipStream_t stream);  // sa_eval.hip
+
+static int sa_check(const char* who, const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d,
+                    int H, const CarcaSaWeights* w, int* dpi) {
+  CARCA_CHECK_ARG(x && ids && y && w, "%s: null pointer", who);
+  CARCA_CHECK_ARG(B >= 1 && L >= 1 && d >= 1 && H >= 1 && d % H == 0, "%s: bad dims B=%d L=%d d=%d H=%d", who, B, L, d, H);
+  CARCA_CHECK_SUPPORTED(L <= CARCA_MAX_L, "%s: L=%d > %d profile slots per workgroup", who, L, CARCA_MAX_L);
+  int dhp, dpo;
+  if (carca_padded_dims(d, H, dpi, &dhp, &dpo) != CARCA_OK) return CARCA_ERR_UNSUPPORTED;
+  CARCA_CHECK_ARG(ldx >= d && ldy >= *dpi && ldy % 4 == 0, "%s: need ldx >= d, ldy >= %d and ldy %% 4 == 0", who, *dpi);
+  return CARCA_OK;
+}
+
+extern "C" int carca_sa_block_eval(const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d, int H,
+                                   const CarcaSaWeights* w, int residual, int pads_uniform, void* stream_) {
+  int dpi;
+  if (int rc = sa_check("sa_block_eval", x, ldx, ids, y, ldy, B, L, d, H, w, &dpi)) return rc;
+  // (the eval kernel reads rows with 16-byte loads: padded internal buffers; anything else, and tuning key 6 = 1, takes
+  // the training kernel without its extras)
+  if (ldx % 4 == 0 && ldx >= dpi && carca_tuning(6) != 1)
+    return carca_sa_eval_launch(x, ldx, ids, y, ldy, B, L, d, H, w, residual, pads_uniform, (hipStream_t)stream_);
+  return carca_sa_block_fwd(x, ldx, ids, y, ldy, B, L, d, H, w, residual, nullptr, nullptr, stream_);
+}
+
 extern "C" int carca_sa_block_fwd(const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d,
                                   int H, const CarcaSaWeights* w, int residual, const CarcaSaSave* save,
                                   const CarcaDropout* drop, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  CARCA_CHECK_ARG(x && ids && y && w, "sa_block_fwd: null pointer");
-  CARCA_CHECK_ARG(B >= 1 && L >= 1 && d >= 1 && H >= 1 && d % H == 0, "sa_block_fwd: bad dims B=%d L=%d d=%d H=%d", B,
-                  L, d, H);
-  CARCA_CHECK_SUPPORTED(L <= CARCA_MAX_L, "sa_block_fwd: L=%d > %d profile slots per workgroup", L, CARCA_MAX_L);
-  int dpi, dhp, dpo;
-  if (carca_padded_dims(d, H, &dpi, &dhp, &dpo) != CARCA_OK) return CARCA_ERR_UNSUPPORTED;
-  CARCA_CHECK_ARG(ldx >= d && ldy >= dpi && ldy % 4 == 0, "sa_block_fwd: need ldx >= d, ldy >= %d and ldy %% 4 == 0",
-                  dpi);
+  int dpi;
+  if (int rc = sa_check("sa_block_fwd", x, ldx, ids, y, ldy, B, L, d, H, w, &dpi)) return rc;
+  if (!save && !(drop && drop->p > 0.f) && ldx % 4 == 0 && ldx >= dpi && carca_tuning(6) != 1)
+    return carca_sa_eval_launch(x, ldx, ids, y, ldy, B, L, d, H, w, residual, 0, stream);
+  int dhp, dpo;
+  carca_padded_dims(d, H, &dpi, &dhp, &dpo);
   CarcaSaSave sv{};
   if (save) sv = *save;
   const DropCfg dc = make_drop(drop);

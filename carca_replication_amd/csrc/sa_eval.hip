@@ -1,0 +1,392 @@
+// K2, eval mode: SelfAttentionBlock.forward (carca.py:297-318) incl. MultiHeadAttention.forward (carca.py:228-265, causal =
+// 0) with nothing saved and no dropout -- the kernel carca_sa_block_fwd launches when save == NULL and p = 0.
+// Same arithmetic contract as sa_block.hip (which stays the training kernel), restructured like the eval scoring
+// kernel (cross_score.hip, cross_fold_kernel):
+//   * LEADING pad slots are dropped.  Profiles are left-padded (data.py:113,173); a pad slot is never attended and its
+//     own output is a function of its input row alone (its attention is exactly 0: carca.py:251-256).  Rows are re-based
+//     at the first real slot; when the caller vouches that all leading pad rows of a user are EQUAL
+//     (pads_uniform: true inside carca_forward -- the masked embedding is 0 there, and equal rows stay equal through a
+//     block) ONE of them is computed, as an extra row behind the real ones, and written to every leading pad slot.
+//     Without that promise no row is dropped.  Pads inside the kept range are computed like any other row.
+//   * masks are ADDED (score accumulators start from 0 / -1e30 per key, the causal compare only in the diagonal tile),
+//     scores leave the Q projection in the exp2 domain, the softmax normaliser multiplies the O^T tiles (8 values per
+//     lane) instead of 16 probabilities.
+//   * K / V^T jobs take one feature tile over ALL slot tiles: the weight fragments are fetched once per workgroup and
+//     feed up to four independent accumulator chains; each wave's first job gets them before phase A.
+//   * the prologue's requests are branch-free buffer loads (counted waits), rows travel in pairs (16 B per lane).
+#include <hip/hip_ext.h>
+#include "attn_common.h"
+#include "../../include/carca_hip.h"
+
+namespace {
+
+#define SAE_NEG (-1.0e30f)
+
+struct SaEvalArgs {
+  const float* x;
+  const int32_t* ids;
+  float* y;
+  int ldx, ldy, L, d, residual, nparts, pads_uniform;
+  CarcaSaWeights w;
+  float qscale;  // log2(e) / sqrt(dh)
+  unsigned long long* stamps;
+};
+
+// one feature tile of K (ISV = false: Ks[slot][feature]) or V^T (ISV = true: Vt[feature][slot]) over NCH slot tiles
+template <int DPI, int NCH, bool ISV>
+__device__ __forceinline__ void sae_kv_chains(const f32x4 (&wf)[DPI / 16], f32x4 bias4, float bias1, const float* xs, int si,
+                                              float* Ks, int so, float* Vt, int ft, int lane) {
+  const int ln = lane & 15, mq = lane >> 4;
+  const float* x0 = xs + ln * si + 4 * mq;
+  f32x4 acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) acc[c] = ISV ? f32x4{bias1, bias1, bias1, bias1} : bias4;
+#pragma unroll
+  for (int kg = 0; kg < DPI / 16; ++kg) {
+    f32x4 x[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) x[c] = lds4(x0 + 16 * c * si + 16 * kg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = ISV ? mfma16(x[c][s], wf[kg][s], acc[c]) : mfma16(wf[kg][s], x[c][s], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (ISV) *reinterpret_cast<f32x4*>(Vt + (16 * ft + ln) * ATT_SK + 16 * c + 4 * mq) = acc[c];
+    else *reinterpret_cast<f32x4*>(Ks + (16 * c + ln) * so + 16 * ft + 4 * mq) = acc[c];
+  }
+}
+
+template <int DPI, int DHP, int NH>
+__global__ __launch_bounds__(1024) void sa_eval_kernel(const SaEvalArgs a) {
+  using G = AttGeom<DPI, DHP, NH>;
+  static_assert(G::SO >= G::SI, "H1 reuses the K image");
+  constexpr int NW = 16;
+#define SAE_STAMP(i)                                                                                 \
+  do {                                                                                               \
+    if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+  SAE_STAMP(0);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xs = lds;                    // [64][SI]  x (re-based rows) -> R -> S2
+  float* Qn = Xs + ATT_LMAX * G::SI;  // [64][SI]  LayerNorm1(x)
+  float* Ks = Qn + ATT_LMAX * G::SI;  // [64][SO]  K -> H1
+  float* Vt = Ks + ATT_LMAX * G::SO;  // [DPO][ATT_SK]
+  float* Km = Vt + G::DPO * ATT_SK;   // [64] additive key mask
+
+  const int L = a.L, d = a.d, nparts = a.nparts;
+  const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, mq = lane >> 4;
+  const size_t ubase = (size_t)u * L;
+  const int dh = d / NH;
+
+  // ---- A0: requests (branch-free buffer loads: counted waits) -------------------------------------------------------
+  const int32_t my_id = gload1i(a.ids + ubase, lane < L ? lane : L - 1);
+  constexpr int PPW = (ATT_LMAX / 2) / NW;  // row pairs per wave
+  const int half = lane >> 5, c4 = lane & 31;
+  const bool col_ok = 4 * c4 < DPI;
+  const float* x_user = a.x + ubase * a.ldx;
+  f32x4 rv[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int r = 2 * (wave + NW * j) + half;
+    rv[j] = gload4(x_user, (r < L ? r : 0) * a.ldx + (col_ok ? 4 * c4 : 0));
+  }
+  const f32x4 ln1w = gload4(a.w.ln1_w, col_ok ? 4 * c4 : 0), ln1b = gload4(a.w.ln1_b, col_ok ? 4 * c4 : 0);
+  // phase B jobs: j < NF: K feature tile j; j >= NF: V^T feature tile j - NF.  This wave's first one gets its weights now.
+  constexpr int NBJ = 2 * G::NF;
+  f32x4 bwf[G::NKG], bb4;
+  float bb1;
+  {
+    const int j = wave < NBJ ? wave : 0;
+    const bool isv = j >= G::NF;
+    const int ft = isv ? j - G::NF : j;
+    const float* wp = isv ? a.w.wv : a.w.wk;
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) bwf[kg] = gload4s(wp, 4 * lane, 256 * (ft * G::NKG + kg));
+    bb4 = gload4s(a.w.bk, 4 * mq, 16 * ft);
+    bb1 = gload1(a.w.bv, 16 * ft + ln);
+  }
+  const unsigned long long pmask = __ballot(lane < L && my_id != 0);
+  // re-basing: s0 leading pads dropped, one of them kept as row nk when the caller vouches they are equal
+  const int s0 = a.pads_uniform ? (pmask ? (int)__builtin_ctzll(pmask) : L) : 0;
+  const int nk = L - s0;
+  const int rep = s0 > 0 ? 1 : 0;
+  const int nrows = nk + rep;
+  const int LT = (nrows + 15) >> 4;
+  // own query tiles (bit t of tmask), their list, and the number of key tiles they need (causal)
+  const unsigned tmask = nparts == 1 ? (1u << LT) - 1u
+                         : LT == 4   ? (part == 0 ? 0x6u : 0x9u)
+                         : LT == 3   ? (part == 0 ? 0x4u : 0x3u)
+                         : LT == 2   ? (part == 0 ? 0x2u : 0x1u)
+                                     : (part == 0 ? 0x1u : 0x0u);
+  if (tmask == 0) return;  // (a one-tile profile: the second workgroup has nothing to do; no barrier has been reached)
+  unsigned own_packed = 0;
+  int n_own = 0, kmax = 0;
+#pragma unroll
+  for (int t = 0; t < ATT_LT; ++t)
+    if (t < LT && ((tmask >> t) & 1u)) {
+      own_packed |= (unsigned)t << (4 * n_own);
+      ++n_own;
+      kmax = t + 1;
+    }
+  auto own = [&](int i) { return (int)((own_packed >> (4 * i)) & 15u); };
+  SAE_STAMP(1);
+
+  // ---- A1: rows -> Xs at their re-based slot, LayerNorm1 -> Qn -------------------------------------------------------
+  {
+    const float inv_d = 1.0f / (float)d;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int r = 2 * (wave + NW * j) + half;
+      // slot r lands at row r - s0; the kept pad (slot 0 when s0 > 0) at row nk; other leading pads nowhere
+      const int t = r >= s0 ? r - s0 : (r == 0 ? nk : -1);
+      const bool keep = r < L && t >= 0;
+      f32x4 v = rv[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (4 * c4 + e < d) ? v[e] : 0.f;
+      const float mean = half32_sum((v[0] + v[1]) + (v[2] + v[3])) * inv_d;
+      f32x4 dv, q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dv[e] = (4 * c4 + e < d) ? v[e] - mean : 0.f;
+      const float var = half32_sum((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * inv_d;
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[e] = (4 * c4 + e < d) ? dv[e] * rstd * ln1w[e] + ln1b[e] : 0.f;
+      if (keep && col_ok) {
+        *reinterpret_cast<f32x4*>(Xs + t * G::SI + 4 * c4) = v;
+        *reinterpret_cast<f32x4*>(Qn + t * G::SI + 4 * c4) = q;
+      }
+    }
+    for (int t = nrows + 2 * wave + half; t < 16 * LT; t += 2 * NW)  // rows of the last tile beyond the profile
+      if (col_ok) {
+        *reinterpret_cast<f32x4*>(Xs + t * G::SI + 4 * c4) = zero4();
+        *reinterpret_cast<f32x4*>(Qn + t * G::SI + 4 * c4) = zero4();
+      }
+    if (wave == NW - 1) Km[lane] = (lane < nk && ((pmask >> (lane + s0)) & 1ull)) ? 0.f : SAE_NEG;
+    __syncthreads();
+  }
+  SAE_STAMP(2);
+  // ---- B: K and V^T, one feature tile over the key tiles the own queries can attend -------------------------------------
+  {
+    bool first = true;
+    for (int job = wave; job < NBJ; job += NW) {
+      const bool isv = job >= G::NF;
+      const int ft = isv ? job - G::NF : job;
+      if (!first) {
+        const float* wp = isv ? a.w.wv : a.w.wk;
+#pragma unroll
+        for (int kg = 0; kg < G::NKG; ++kg) bwf[kg] = gload4s(wp, 4 * lane, 256 * (ft * G::NKG + kg));
+        bb4 = gload4s(a.w.bk, 4 * mq, 16 * ft);
+        bb1 = gload1(a.w.bv, 16 * ft + ln);
+      }
+      first = false;
+      if (isv) {
+        if (kmax > 3) sae_kv_chains<DPI, 4, true>(bwf, bb4, bb1, Xs, G::SI, Ks, G::SO, Vt, ft, lane);
+        else if (kmax > 2) sae_kv_chains<DPI, 3, true>(bwf, bb4, bb1, Xs, G::SI, Ks, G::SO, Vt, ft, lane);
+        else sae_kv_chains<DPI, 2, true>(bwf, bb4, bb1, Xs, G::SI, Ks, G::SO, Vt, ft, lane);
+      } else {
+        if (kmax > 3) sae_kv_chains<DPI, 4, false>(bwf, bb4, bb1, Xs, G::SI, Ks, G::SO, Vt, ft, lane);
+        else if (kmax > 2) sae_kv_chains<DPI, 3, false>(bwf, bb4, bb1, Xs, G::SI, Ks, G::SO, Vt, ft, lane);
+        else sae_kv_chains<DPI, 2, false>(bwf, bb4, bb1, Xs, G::SI, Ks, G::SO, Vt, ft, lane);
+      }
+    }
+  }
+  __syncthreads();
+  SAE_STAMP(3);
+
+  // ---- C1: attention per (query tile, head) -> R = attention (+ q) into the dead x image, plain feature order ----------
+  // (Measured and dropped: dealing the jobs -- 48 + 32 (qt + 1) MFMAs each, causal -- longest first over four bins of
+  // waves w, w + 4, w + 8, ... on the assumption that those share a SIMD: tiles {0, 3} x 3 heads took 12.4 k cycles that
+  // way against 9.5 k in index order.)
+  for (int job = wave; job < n_own * NH; job += NW) {
+    const int qi = job / NH, h = job - qi * NH;
+    const int qt = own(qi);
+    const int q = 16 * qt + ln;
+    f32x4 qfrag[G::NKG];
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) qfrag[kg] = lds4(Qn + q * G::SI + 16 * kg + 4 * mq);
+    // Q^T tiles of the head, in the exp2 domain
+    f32x4 qh[G::NFH];
+#pragma unroll
+    for (int ft = 0; ft < G::NFH; ++ft) {
+      f32x4 wf[G::NKG];
+#pragma unroll
+      for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4s(a.w.wq, 4 * lane, 256 * ((h * G::NFH + ft) * G::NKG + kg));
+      const f32x4 bias = gload4s(a.w.bq, 4 * mq, h * DHP + 16 * ft);
+      CARCA_PIN_LOADS();
+      f32x4 acc = zero4();
+#pragma unroll
+      for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], qfrag[kg], acc);
+      qh[ft] = (acc + bias) * a.qscale;
+    }
+    // scores^T tiles on top of the additive key mask; the causal compare (key <= query, carca.py:250) only bites in the
+    // diagonal tile
+    f32x4 sc[ATT_LT];
+    float mx = SAE_NEG;
+#pragma unroll
+    for (int kt = 0; kt < ATT_LT; ++kt) {
+      if (kt <= qt) {
+        f32x4 acc = lds4(Km + 16 * kt + 4 * mq);
+        if (kt == qt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = (4 * mq + r <= ln) ? acc[r] : SAE_NEG;
+        }
+        const float* krow = Ks + (16 * kt + ln) * G::SO + h * DHP + 4 * mq;
+#pragma unroll
+        for (int ft = 0; ft < G::NFH; ++ft) acc = mfma16_group(lds4(krow + 16 * ft), qh[ft], acc);
+        sc[kt] = acc;
+        mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+      }
+    }
+    mx = quad4_max(mx);
+    const bool q_ok = Km[q] == 0.f;  // (a real slot: pads attend nothing, carca.py:246-256)
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < ATT_LT; ++kt) {
+      if (kt <= qt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sc[kt][r] - mx);
+          sc[kt][r] = e;
+          sum += e;
+        }
+      }
+    }
+    sum = quad4_sum(sum);
+    const float inv = (q_ok && mx > 0.5f * SAE_NEG) ? 1.0f / sum : 0.f;
+    // O^T tiles: rows = head features, cols = queries, contracting over keys; normalised afterwards
+#pragma unroll
+    for (int ft = 0; ft < G::NFH; ++ft) {
+      const float* vrow = Vt + (h * DHP + 16 * ft + ln) * ATT_SK + 4 * mq;
+      f32x4 acc = zero4();
+#pragma unroll
+      for (int kt = 0; kt < ATT_LT; ++kt)
+        if (kt <= qt) acc = mfma16_group(lds4(vrow + 16 * kt), sc[kt], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int fr = 16 * ft + 4 * mq + r;
+        if (fr < dh) {
+          const int j = h * dh + fr;
+          Xs[q * G::SI + j] = acc[r] * inv + (a.residual ? Qn[q * G::SI + j] : 0.f);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  SAE_STAMP(4);
+  // (Measured and dropped: requesting the first ffn_1 / ffn_2 job's weight fragments one phase ahead -- the wait moved into
+  // LayerNorm2, 1.6 -> 3.0 k cycles, and the kernel took as long.)
+  // ---- C2: LayerNorm2 of the own tiles' rows, in place (row pairs) ---------------------------------------------------------
+  {
+    const f32x4 ln2w = gload4(a.w.ln2_w, col_ok ? 4 * c4 : 0), ln2b = gload4(a.w.ln2_b, col_ok ? 4 * c4 : 0);
+    const float inv_d = 1.0f / (float)d;
+    for (int pi = wave; pi < 8 * n_own; pi += NW) {
+      const int r = 16 * own(pi >> 3) + 2 * (pi & 7) + half;
+      f32x4 v = col_ok ? lds4(Xs + r * G::SI + 4 * c4) : zero4();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (4 * c4 + e < d) ? v[e] : 0.f;
+      const float mean = half32_sum((v[0] + v[1]) + (v[2] + v[3])) * inv_d;
+      f32x4 dv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dv[e] = (4 * c4 + e < d) ? v[e] - mean : 0.f;
+      const float var = half32_sum((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * inv_d;
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (4 * c4 + e < d) ? dv[e] * rstd * ln2w[e] + ln2b[e] : 0.f;
+      if (col_ok) *reinterpret_cast<f32x4*>(Xs + r * G::SI + 4 * c4) = v;
+    }
+  }
+  __syncthreads();
+  SAE_STAMP(5);
+  // ---- C3: ffn_1 + LeakyReLU per (query tile, feature tile) -> H1 (over the dead K image) -----------------------------------
+  float* H1 = Ks;
+  for (int job = wave; job < n_own * G::NKG; job += NW) {
+    const int qi = job / G::NKG, ft = job - qi * G::NKG;
+    const int q = 16 * own(qi) + ln;
+    const float* srow = Xs + q * G::SI + 4 * mq;
+    f32x4 wf[G::NKG];
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4s(a.w.w1, 4 * lane, 256 * (ft * G::NKG + kg));
+    f32x4 acc = gload4s(a.w.b1, 4 * mq, 16 * ft);
+    CARCA_PIN_LOADS();
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], lds4(srow + 16 * kg), acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.01f * acc[r];
+    *reinterpret_cast<f32x4*>(H1 + q * G::SI + 16 * ft + 4 * mq) = acc;
+  }
+  __syncthreads();
+  SAE_STAMP(6);
+  // ---- C4: ffn_2 + residual per (query tile, feature tile) -> y at the rows' original slots ----------------------------------
+  for (int job = wave; job < n_own * G::NKG; job += NW) {
+    const int qi = job / G::NKG, ft = job - qi * G::NKG;
+    const int q = 16 * own(qi) + ln;
+    const float* hrow = H1 + q * G::SI + 4 * mq;
+    f32x4 wf[G::NKG];
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) wf[kg] = gload4s(a.w.w2, 4 * lane, 256 * (ft * G::NKG + kg));
+    f32x4 acc = gload4s(a.w.b2, 4 * mq, 16 * ft);
+    CARCA_PIN_LOADS();
+#pragma unroll
+    for (int kg = 0; kg < G::NKG; ++kg) acc = mfma16_group(wf[kg], lds4(hrow + 16 * kg), acc);
+    if (a.residual) acc = acc + lds4(Xs + q * G::SI + 16 * ft + 4 * mq);
+    if (16 * ft + 4 * mq < a.ldy) {
+      float* yu = a.y + ubase * a.ldy + 16 * ft + 4 * mq;
+      if (q < nk) {
+        *reinterpret_cast<f32x4*>(yu + (size_t)(q + s0) * a.ldy) = acc;
+      } else if (q == nk && rep) {  // the kept pad row stands for every leading pad slot
+        for (int j = 0; j < s0; ++j) *reinterpret_cast<f32x4*>(yu + (size_t)j * a.ldy) = acc;
+      }
+    }
+  }
+  SAE_STAMP(7);
+#undef SAE_STAMP
+}
+
+template <int DPI, int DHP, int NH>
+int launch_sa_eval(SaEvalArgs& a, int B, hipStream_t stream) {
+  using G = AttGeom<DPI, DHP, NH>;
+  const size_t lds_bytes = sizeof(float) * (2 * ATT_LMAX * G::SI + ATT_LMAX * G::SO + G::DPO * ATT_SK + ATT_LMAX);
+  auto kern = sa_eval_kernel<DPI, DHP, NH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      carca_set_error("sa_block_fwd: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  // two workgroups per user while that still fits the chip in one round (tuning key 1: 1 = never, 2 = always)
+  const int tune = carca_tuning(CARCA_TUNE_ATTN_VARIANT);
+  a.nparts = (a.L > 16 && tune != 1 && (tune == 2 || 2 * B <= carca_num_cus())) ? 2 : 1;
+  hipEvent_t e0, e1;
+  if (carca_take_launch_events(&e0, &e1))  // (timing events bound to this dispatch: carca_forward's ev[4], ev[5])
+    hipExtLaunchKernelGGL(kern, dim3(B * a.nparts), dim3(1024), lds_bytes, stream, e0, e1, 0, a);
+  else
+    hipLaunchKernelGGL(kern, dim3(B * a.nparts), dim3(1024), lds_bytes, stream, a);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+}  // namespace
+
+// Called by carca_sa_block_fwd (sa_block.hip) for eval-mode launches.  pads_uniform: see the top of this file.
+int carca_sa_eval_launch(const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d, int H,
+                         const CarcaSaWeights* w, int residual, int pads_uniform, hipStream_t stream) {
+  int dpi, dhp, dpo;
+  if (carca_padded_dims(d, H, &dpi, &dhp, &dpo) != CARCA_OK) return CARCA_ERR_UNSUPPORTED;
+  SaEvalArgs a{};
+  a.x = x; a.ids = ids; a.y = y; a.ldx = ldx; a.ldy = ldy; a.L = L; a.d = d; a.residual = residual;
+  a.pads_uniform = pads_uniform;
+  a.w = *w;
+  a.qscale = (float)(1.4426950408889634 / sqrt((double)(d / H)));
+  a.stamps = carca_debug_buffer();
+  CARCA_ATT_DISPATCH(launch_sa_eval, a, B, stream);
+  carca_set_error("sa_block_fwd: no kernel built for d=%d H=%d (padded %d / head %d)", d, H, dpi, dhp);
+  return CARCA_ERR_UNSUPPORTED;
+}

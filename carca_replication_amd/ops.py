@@ -369,10 +369,12 @@ def embed_fwd(segs: Sequence[Tuple[Tensor, Tensor, Tensor, bool]], items_w: Tens
 # self-attention block
 # --------------------------------------------------------------------------------------------------
 def sa_block_fwd(x: Tensor, ids: Tensor, w: "_lib.SaWeights", d: int, H: int, residual: bool, save: bool = False,
-                 drop: Optional[Tuple[float, int, int]] = None):
+                 drop: Optional[Tuple[float, int, int]] = None, pads_uniform: bool = False):
     """x [B, L, ldx] (ldx >= d) -> y [B, L, DPI]; `ids` [B, L] (any integer/bool type, 0 = pad).
 
-    save=True also returns the dict of tensors the backward pass needs (CarcaSaSave)."""
+    save=True also returns the dict of tensors the backward pass needs (CarcaSaSave).
+    pads_uniform=True (eval only): the caller's promise that each user's leading pad rows of x are equal
+    (carca_sa_block_eval): one of them is computed and written to all of them."""
     lib = _lib.load()
     _need_cuda(x, ids)
     x = _f32(x)
@@ -391,6 +393,12 @@ def sa_block_fwd(x: Tensor, ids: Tensor, w: "_lib.SaWeights", d: int, H: int, re
         for k, t in saved.items():
             setattr(sv, k, t.data_ptr())
     dstruct = _drop_struct(*drop) if drop else None
+    if pads_uniform:
+        if save or dstruct is not None:
+            raise CarcaHipError("sa_block_fwd: pads_uniform is an eval-mode promise (no saved tensors, no dropout)")
+        _lib.check(lib.carca_sa_block_eval(x.data_ptr(), ldx, ids32.data_ptr(), y.data_ptr(), dpi, B, L, d, H, C.byref(w),
+                                           int(bool(residual)), 1, _stream()), "sa_block_eval")
+        return y
     _lib.check(lib.carca_sa_block_fwd(x.data_ptr(), ldx, ids32.data_ptr(), y.data_ptr(), dpi, B, L, d, H, C.byref(w),
                                       int(bool(residual)), C.byref(sv) if save else None,
                                       C.byref(dstruct) if dstruct is not None else None, _stream()), "sa_block_fwd")

@@ -242,6 +242,15 @@ int carca_sa_block_fwd(const float* x /*[B*L, ldx]*/, int ldx, const int32_t* id
                        const CarcaSaSave* save /*host struct or NULL*/, const CarcaDropout* drop /*or NULL*/,
                        void* stream);
 
+/* The same block in eval mode (nothing saved, no dropout) with one more promise from the caller:
+ *   pads_uniform != 0: within a user, all LEADING pad rows (ids == 0 before the first real slot) of x are equal.  True for
+ *   the masked embedding (rows of zeros, carca.py:94) and, since a pad row's output depends on its own input only,
+ *   for every block output downstream of it; carca_forward passes 1.  The kernel then computes one of those rows and
+ *   writes it to every leading pad slot, and projects / attends / feeds forward only ceil((real slots + 1) / 16) row
+ *   tiles.  0 = no assumption (what carca_sa_block_fwd passes for save == NULL, drop == NULL). */
+int carca_sa_block_eval(const float* x, int ldx, const int32_t* ids, float* y, int ldy, int B, int L, int d, int H,
+                        const CarcaSaWeights* w /*host struct*/, int residual, int pads_uniform, void* stream);
+
 /* ---- a5 + a6: final LayerNorm + CrossAttentionBlock.forward, grouped --------------------------
  * Replaces CARCA.forward's final norm (carca.py:421) and, for every target group,
  * CrossAttentionBlock.forward (carca.py:338-349): K/V projections of the normed profile are

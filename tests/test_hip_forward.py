@@ -472,3 +472,58 @@ def test_standalone_encodings_add_their_table():
             le(torch.randn(3, 12, 10, device="cuda"))  # longer than max_len
     with pytest.raises(CarcaHipError):  # gradients flow through CARCA.forward, not through the stand-alone module
         le(x)
+
+
+# ---- the eval-mode SelfAttentionBlock kernel (csrc/sa_eval.hip) ----------------------------------------------------------
+@pytest.mark.parametrize("d,H,L", [(90, 3, 50), (64, 2, 20), (128, 4, 64), (90, 1, 33), (64, 4, 7)])
+def test_sa_eval_kernel_equals_oracle_and_training_kernel(d, H, L):
+    """Every row of a block's output -- real slots, pads inside the profile, leading pads -- against the oracle's
+    sa_block and against the training kernel (tuning key 6 = 1), with and without the pads_uniform promise, one and two
+    workgroups per user; profile lengths from 0 (all pad) to L, pads inside the kept range, B beyond one tile of users."""
+    from carca_replication_amd import _lib, ops
+    from carca_replication_amd import modules as M
+
+    torch.manual_seed(d + H + L)
+    B = 11
+    blk = M.SelfAttentionBlock(d, H, 0.0, True).cuda().eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    dpi, _, _ = ops.padded_dims(d, H)
+    g = torch.Generator().manual_seed(1)
+    lens = torch.tensor([0, 1, 2, L, L, L - 1, 17 % (L + 1), 16 % (L + 1), 15 % (L + 1), 33 % (L + 1), 5 % (L + 1)])
+    ids = (torch.arange(L)[None, :] >= (L - lens)[:, None]).int() * 3
+    ids[4, L // 2] = 0  # a pad inside a full profile
+    if L > 4:
+        ids[6, L - 2] = 0
+    x = torch.zeros(B, L, dpi)
+    x[..., :d] = torch.randn(B, L, d, generator=g)
+    # leading pad rows equal within a user (what the masked embedding / an upstream block produce), other rows arbitrary
+    lead = (torch.cumsum(ids != 0, dim=1) == 0)
+    padrow = torch.zeros(B, 1, dpi)
+    padrow[..., :d] = torch.randn(B, 1, d, generator=g)
+    x = torch.where(lead[..., None], padrow.expand(B, L, dpi), x)
+    P = {"encoder.0." + k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    cfg = O.CarcaConfig(d=d, H=H, n_blocks=1)
+    want = O.sa_block(P, cfg, 0, x[..., :d], (ids != 0).float())
+    lib = _lib.load()
+    outs = {}
+    try:
+        for name, tune6, tune1, uniform in (("train-kernel", 1, 0, False), ("eval", 0, 1, False), ("eval-uniform", 0, 1, True),
+                                            ("eval-2wg", 0, 2, False), ("eval-2wg-uniform", 0, 2, True)):
+            lib.carca_set_tuning(6, tune6)
+            lib.carca_set_tuning(1, tune1)
+            with torch.no_grad():
+                y = ops.sa_block_fwd(x.cuda(), ids.cuda(), blk.weights_struct(torch.device("cuda")), d, H, True,
+                                     pads_uniform=uniform)
+            outs[name] = y.cpu()
+            assert float(y[..., d:].abs().max()) == 0.0 if dpi > d else True
+            err = float((y.cpu()[..., :d] - want).abs().max())
+            assert err < ACT_ATOL, (name, err)
+    finally:
+        lib.carca_set_tuning(6, 0)
+        lib.carca_set_tuning(1, 0)
+    assert torch.equal(outs["eval"], outs["eval-2wg"])                   # the split only moves tiles between workgroups
+    assert torch.equal(outs["eval-uniform"], outs["eval-2wg-uniform"])
+    assert float((outs["eval"] - outs["eval-uniform"]).abs().max()) < 1e-6   # (re-based rows: other tile / lane, same sums)

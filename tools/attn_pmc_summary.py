@@ -15,7 +15,7 @@ def one(pat):
 
 
 def short(name):
-    for k in ("cross_fold_kernel", "cross_score_kernel_w16", "sa_block_kernel_w16"):
+    for k in ("cross_fold_kernel", "cross_score_kernel_w16", "sa_block_kernel_w16", "sa_eval_kernel"):
         if k in name:
             return k + name[name.index(k) + len(k):].split("(")[0]
     return None
