@@ -802,7 +802,7 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream, co
   return CARCA_OK;
 }
 
-enum GemmChoice { GEMM_NARROW_BUF, GEMM_NARROW, GEMM_CU, GEMM_CU_STAMPS, GEMM_CU128, GEMM_TILED_BUF, GEMM_TILED };
+enum GemmChoice { GEMM_NARROW_BUF, GEMM_NARROW, GEMM_CU, GEMM_CU_STAMPS, GEMM_CU128, GEMM_TILED_BUF, GEMM_TILED, GEMM_WIDE64, GEMM_WIDE64_PF2 };
 
 // argument checks + kernel selection of one product
 static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice) {
@@ -850,6 +850,7 @@ static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice) {
   const bool narrow = variant != 1 && rb128 * ((desc->ncols_out + 95) / 96) < 384;
   if (narrow) {
     *choice = fits ? GEMM_NARROW_BUF : GEMM_NARROW;
+    if (fits && (variant == 9 || variant == 10)) *choice = variant == 9 ? GEMM_WIDE64 : GEMM_WIDE64_PF2;
     return CARCA_OK;
   }
   // One 384 x 96 block per CU when the grid fills the chip's 256 CUs about as well as the 128 x 96 blocks (3 per CU)
@@ -885,6 +886,8 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
     case GEMM_CU: return launch_gemm_rows_cu<0>(desc, stream);
     case GEMM_CU_STAMPS: return launch_gemm_rows_cu<1>(desc, stream);
     case GEMM_CU128: return launch_gemm_rows_cu<0, 4>(desc, stream);
+    case GEMM_WIDE64: return launch_gemm_rows<64, 96, 32, 4, true>(desc, stream);
+    case GEMM_WIDE64_PF2: return launch_gemm_rows<64, 96, 32, 2, true>(desc, stream);
     case GEMM_TILED_BUF: return launch_gemm_rows<128, 96, 32, 1, true>(desc, stream);
     default: return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
   }
