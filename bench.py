@@ -401,7 +401,7 @@ def main():
                                              "leading pad slots of the left-padded profiles are not projected or scored "
                                              "(exact: their weights are 0).  At B = 128 one launch is one latency chain per "
                                              "workgroup (two per user); B-scaling in profiles/"},
-            "roofline_sa_block": {"kernel": "sa_block_kernel_w16<96,32,3> (one SelfAttentionBlock, first of %d)" % c["n_blocks"],
+            "roofline_sa_block": {"kernel": "sa_eval_kernel<96,32,3> (one SelfAttentionBlock in eval mode, first of %d; leading pad slots re-based away)" % c["n_blocks"],
                                   "bound": "mfma", "achieved": sa_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": sa_tflops / PEAK_F32_MFMA_TFLOPS, "avg_ms": sa_avg, "min_ms": sa_ms[0],
                                   "algorithmic_gflop_per_launch": c["B"] * fl["sa"] / c["n_blocks"] / 1e9},

@@ -87,6 +87,84 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// The same for rows that can be read 16 bytes per lane (padded internal buffers: every stride a multiple of 4): two rows
+// per wave instruction -- lane (half = row of the pair, c4 = four contiguous columns) -- so that the four reductions of a
+// row run over 32 lanes (five steps) on half the instructions, PAIRS row pairs in flight per wave, one block per CU.
+template <int PAIRS>
+__global__ __launch_bounds__(256) void layernorm_bwd_pairs_kernel(const float* __restrict__ dy, int ld_dy,
+                                                                  const float* __restrict__ x, int ld_x,
+                                                                  const float* __restrict__ gamma, int rows, int d,
+                                                                  const float* __restrict__ addend, int ld_add,
+                                                                  float* __restrict__ dx, int ld_dx, int ncols_out,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[2][4][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, c4 = lane & 31;
+  const bool col_ok = 4 * c4 < ((d + 3) & ~3);
+  const f32x4 g4 = col_ok ? gload4(gamma, 4 * c4) : zero4();  // (gamma is a [d] parameter: read below d only)
+  f32x4 gm;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) gm[e] = (4 * c4 + e < d) ? g4[e] : 0.f;
+  const float inv_d = 1.0f / (float)d;
+  f32x4 dg = zero4(), db = zero4();
+  for (int p0 = (blockIdx.x * 4 + wave) * PAIRS; 2 * p0 < rows; p0 += gridDim.x * 4 * PAIRS) {
+    f32x4 xv[PAIRS], yv[PAIRS], av[PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+      const int row = min(2 * (p0 + i) + half, rows - 1);
+      const int c = col_ok ? 4 * c4 : 0;
+      xv[i] = gload4(x, row * ld_x + c);
+      yv[i] = gload4(dy, row * ld_dy + c);
+      av[i] = addend ? gload4(addend, row * ld_add + c) : zero4();
+    }
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+      const int row = 2 * (p0 + i) + half;
+      f32x4 xr = xv[i], yr = yv[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = 4 * c4 + e < d && row < rows;
+        xr[e] = ok ? xr[e] : 0.f;
+        yr[e] = ok ? yr[e] : 0.f;
+      }
+      const float mean = half32_sum((xr[0] + xr[1]) + (xr[2] + xr[3])) * inv_d;
+      f32x4 ev;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ev[e] = (4 * c4 + e < d) ? xr[e] - mean : 0.f;
+      const float rstd = 1.0f / sqrtf(half32_sum((ev[0] * ev[0] + ev[1] * ev[1]) + (ev[2] * ev[2] + ev[3] * ev[3])) * inv_d + 1e-5f);
+      const f32x4 hv = ev * rstd, aa = yr * gm;
+      const float m1 = half32_sum((aa[0] + aa[1]) + (aa[2] + aa[3])) * inv_d;
+      const float m2 = half32_sum((aa[0] * hv[0] + aa[1] * hv[1]) + (aa[2] * hv[2] + aa[3] * hv[3])) * inv_d;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (4 * c4 + e < d) ? rstd * (aa[e] - m1 - hv[e] * m2) + av[i][e] : 0.f;
+      if (row < rows) {
+        dg = dg + yr * hv;
+        db = db + yr;
+        if (4 * c4 < ncols_out) *reinterpret_cast<f32x4*>(dx + (size_t)row * ld_dx + 4 * c4) = o;
+      }
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // the two rows of the pairs, then the four waves
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(dg[e]), __float_as_uint(dg[e]), false, false);
+      dg[e] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      r = __builtin_amdgcn_permlane32_swap(__float_as_uint(db[e]), __float_as_uint(db[e]), false, false);
+      db[e] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if (half == 0) {
+      *reinterpret_cast<f32x4*>(&red[0][wave][4 * c4]) = dg;
+      *reinterpret_cast<f32x4*>(&red[1][wave][4 * c4]) = db;
+    }
+    __syncthreads();
+    if (tid < 128 && tid < d) {
+      atomicAdd(&dgamma[tid], red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid]);
+      atomicAdd(&dbeta[tid], red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid]);
+    }
+  }
+}
+
 // d_items[ids[r]][c] += scale * dz[r][c] for ids[r] != 0 (padding_idx = 0 gets no gradient)
 __global__ void embed_scatter_kernel(const float* __restrict__ dz, int ld_dz, const int32_t* __restrict__ ids,
                                      int rows, int d, float scale, float* __restrict__ d_items) {
@@ -97,6 +175,30 @@ __global__ void embed_scatter_kernel(const float* __restrict__ dz, int ld_dz, co
     const int id = ids[row];
     if (id == 0) continue;
     const float* src = dz + (size_t)row * ld_dz;
+    float* dst = d_items + (size_t)id * d;
+    for (int c = lane; c < d; c += 64) atomicAdd(&dst[c], scale * src[c]);
+  }
+}
+
+// the same over several row segments ([profile | positives | negatives] of the train step) in one launch
+struct ScatterSegs {
+  const float* dz[CARCA_MAX_SEGS];
+  const int32_t* ids[CARCA_MAX_SEGS];
+  int row_end[CARCA_MAX_SEGS];  // running row totals
+  int nseg;
+};
+__global__ void embed_scatter_segs_kernel(ScatterSegs S, int ld_dz, int d, float scale, float* __restrict__ d_items) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int rows = S.row_end[S.nseg - 1];
+  for (int row = wave; row < rows; row += nwaves) {
+    int s = 0;
+    while (row >= S.row_end[s]) ++s;  // (wave-uniform: scalar loads of the kernel arguments)
+    const int r = row - (s ? S.row_end[s - 1] : 0);
+    const int id = S.ids[s][r];
+    if (id == 0) continue;
+    const float* src = S.dz[s] + (size_t)r * ld_dz;
     float* dst = d_items + (size_t)id * d;
     for (int c = lane; c < d; c += 64) atomicAdd(&dst[c], scale * src[c]);
   }
@@ -612,6 +714,19 @@ extern "C" int carca_layernorm_bwd(const float* dy, int ld_dy, const float* x, i
   CARCA_CHECK_SUPPORTED(d <= 128, "layernorm_bwd: d=%d > 128", d);
   CARCA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
   CARCA_CHECK_ARG(ncols_out <= ld_dx && ncols_out <= 128 && ld_dy >= d && ld_x >= d, "layernorm_bwd: bad strides");
+  // padded internal buffers (every stride a multiple of 4 floats, width <= the strides): the row-pair kernel, one block
+  // per CU, four pairs in flight per wave
+  const bool vec = ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && (!addend || ld_add % 4 == 0) &&
+                   ((d + 3) & ~3) <= ld_dy && ((d + 3) & ~3) <= ld_x && (!addend || ((d + 3) & ~3) <= ld_add) &&
+                   ncols_out % 4 == 0 && (size_t)rows * (size_t)max(max(ld_dy, ld_x), max(ld_dx, ld_add)) < (1u << 29) &&
+                   carca_tuning(6) != 1;
+  if (vec) {
+    const int nb = min((rows + 31) / 32, carca_num_cus());
+    hipLaunchKernelGGL(layernorm_bwd_pairs_kernel<4>, dim3(nb), dim3(256), 0, stream, dy, ld_dy, x, ld_x, gamma, rows, d,
+                       addend, ld_add, dx, ld_dx, ncols_out, dgamma, dbeta);
+    CARCA_LAUNCH_CHECK();
+    return CARCA_OK;
+  }
   // few blocks: every block ends with 2d atomics on the SAME dgamma / dbeta addresses, which serialise in L2
   // (6400 rows: 400 blocks 18.7 us, 200 blocks one row per pass 16 us)
   const int blocks = min((rows + 63) / 64, 128);
@@ -627,6 +742,24 @@ extern "C" int carca_embed_scatter(const float* dz, int ld_dz, const int32_t* id
   CARCA_CHECK_ARG(dz && ids && d_items && rows >= 1 && d >= 1 && ld_dz >= d, "embed_scatter: bad arguments");
   const int blocks = min((rows + 3) / 4, 2048);
   hipLaunchKernelGGL(embed_scatter_kernel, dim3(blocks), dim3(256), 0, stream, dz, ld_dz, ids, rows, d, scale, d_items);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+int carca_embed_scatter_segs(const float* const* dz, int ld_dz, const int32_t* const* ids, const int* rows, int nseg,
+                             int d, float scale, float* d_items, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(dz && ids && rows && d_items && nseg >= 1 && nseg <= CARCA_MAX_SEGS && d >= 1 && ld_dz >= d,
+                  "embed_scatter: bad arguments");
+  ScatterSegs S = {};
+  int total = 0;
+  for (int s = 0; s < nseg; ++s) {
+    CARCA_CHECK_ARG(dz[s] && ids[s] && rows[s] >= 1, "embed_scatter: segment %d malformed", s);
+    S.dz[s] = dz[s]; S.ids[s] = ids[s]; S.row_end[s] = (total += rows[s]);
+  }
+  S.nseg = nseg;
+  const int blocks = min((total + 3) / 4, 2048);
+  hipLaunchKernelGGL(embed_scatter_segs_kernel, dim3(blocks), dim3(256), 0, stream, S, ld_dz, d, scale, d_items);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

@@ -299,10 +299,13 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
   gz.lda0 = D->ld_de; gz.K0 = d; gz.bt0 = D->joint_wt; gz.ldb0 = D->ld_joint_wt; gz.N = ldz; gz.ldc = ldz;
   gz.ncols_out = ldz; gz.gate_slope = 0.01f; gz.mask_rows = 1;
   if ((rc = carca_gemm_rows(&gz, stream))) return rc;
-  for (int s = 0; s < D->nseg; ++s)  // nn.Embedding(padding_idx = 0): z = E[ids] * sqrt(d)
-    if ((rc = carca_embed_scatter(dzq[s], ldz, D->seg[s].ids, D->seg[s].rows, d, (float)sqrt((double)d), D->g_items,
-                                  stream)))
+  {  // nn.Embedding(padding_idx = 0): z = E[ids] * sqrt(d); every segment in one launch
+    const int32_t* sids[CARCA_MAX_SEGS];
+    int srows[CARCA_MAX_SEGS];
+    for (int s = 0; s < D->nseg; ++s) { sids[s] = D->seg[s].ids; srows[s] = D->seg[s].rows; }
+    if ((rc = carca_embed_scatter_segs(dzq, ldz, sids, srows, D->nseg, d, (float)sqrt((double)d), D->g_items, stream)))
       return rc;
+  }
   wf.ld_dy = ldz; wf.ld_x = D->n_attrs; wf.ld_x1 = D->n_ctx; wf.N = g; wf.K = D->n_attrs; wf.K1 = D->n_ctx;
   wf.dw = D->g_feats_w; wf.ldw = D->n_attrs + D->n_ctx; wf.db = D->g_feats_b;
   if (D->ev_early && hipEventRecord((hipEvent_t)D->ev_early, (hipStream_t)stream) != hipSuccess) {

@@ -177,6 +177,9 @@ struct CarcaGemmDesc;
 // carca_gemm_rows with the item-row gather riding along where the kernel choice leaves a CU idle; *rode tells whether
 // it did (otherwise the caller launches the gather itself)
 int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* ga, int* rode, void* stream);
+// carca_embed_scatter over several row segments in one launch (backward.hip)
+int carca_embed_scatter_segs(const float* const* dz, int ld_dz, const int32_t* const* ids, const int* rows, int nseg,
+                             int d, float scale, float* d_items, void* stream);
 unsigned long long* carca_debug_buffer();  // device buffer for in-kernel phase stamps (diagnostic runs), or null
 #define CARCA_CHECK_ARG(cond, ...)            \
   do {                                        \

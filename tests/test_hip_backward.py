@@ -228,3 +228,28 @@ def test_c2_full_batch_gradients_are_the_weighted_sum_of_its_halves():
     for k in gf:
         want = (n1 * g1[k] + n2 * g2[k]) / nf
         assert float((gf[k] - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-7, k
+
+
+@pytest.mark.parametrize("rows,d,ld,out_ld", [(6400, 90, 96, 96), (6401, 128, 128, 128), (333, 50, 64, 64),
+                                              (77, 6, 8, 8), (129, 90, 91, 96), (64, 128, 256, 128)])
+def test_layernorm_backward_kernels_against_torch(rows, d, ld, out_ld):
+    """Both LayerNorm-backward kernels (16-byte row pairs for the padded internal strides, one row per wave otherwise)
+    against torch.autograd of nn.LayerNorm (carca.py:421 / 440, eps 1e-5), with the fused addend and pad columns."""
+    from carca_replication_amd import ops
+    torch.manual_seed(rows + d)
+    xs = torch.randn(rows, ld, device="cuda") * 2 + 0.5
+    dys = torch.randn(rows, ld, device="cuda")
+    add = torch.randn(rows, ld, device="cuda")
+    gamma = torch.randn(d, device="cuda")
+    dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    dx = ops.layernorm_bwd(dys, xs, gamma, d, out_ld, addend=add, dgamma=dg, dbeta=db)
+    xr = xs[:, :d].double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = torch.zeros(d, dtype=torch.float64, device="cuda", requires_grad=True)
+    torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5).backward(dys[:, :d].double())
+    assert torch.allclose(dx[:, :d].double(), xr.grad + add[:, :d].double(), rtol=1e-4, atol=1e-5)
+    assert torch.equal(dx[:, d:], torch.zeros_like(dx[:, d:]))
+    assert torch.allclose(dg.double(), gr.grad, rtol=1e-4, atol=1e-4 * float(gr.grad.abs().max()))
+    assert torch.allclose(db.double(), br.grad, rtol=1e-4, atol=1e-4 * float(br.grad.abs().max()))
+    dx2 = ops.layernorm_bwd(dys, xs, gamma, d, out_ld)  # no addend, no parameter gradients
+    assert torch.allclose(dx2[:, :d].double(), xr.grad, rtol=1e-4, atol=1e-5)
