@@ -267,9 +267,9 @@ __device__ __forceinline__ void fold_b_load(FoldBW<DPI>& w, const float* __restr
 }
 template <int DPI, int NCH, bool ISU>
 __device__ __forceinline__ void fold_b_chains(const FoldBW<DPI>& w, const float* xs, int si, float* Ks, int so, float* Ut,
-                                              int ft, int lane, int nh) {
+                                              int ft, int lane, int nh, int c0 = 0) {  // slot tiles c0 .. c0 + NCH - 1
   const int ln = lane & 15, mq = lane >> 4;
-  const float* x0 = xs + ln * si + 4 * mq;
+  const float* x0 = xs + (16 * c0 + ln) * si + 4 * mq;
   f32x4 acc[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) acc[c] = ISU ? f32x4{w.cu1, w.cu1, w.cu1, w.cu1} : w.bk4;
@@ -287,9 +287,9 @@ __device__ __forceinline__ void fold_b_chains(const FoldBW<DPI>& w, const float*
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     if (ISU) {
-      if (ln < nh) *reinterpret_cast<f32x4*>(Ut + ln * ATT_SK + 16 * c + 4 * mq) = acc[c];
+      if (ln < nh) *reinterpret_cast<f32x4*>(Ut + ln * ATT_SK + 16 * (c0 + c) + 4 * mq) = acc[c];
     } else {
-      *reinterpret_cast<f32x4*>(Ks + (16 * c + ln) * so + 16 * ft + 4 * mq) = acc[c];
+      *reinterpret_cast<f32x4*>(Ks + (16 * (c0 + c) + ln) * so + 16 * ft + 4 * mq) = acc[c];
     }
   }
 }
@@ -306,6 +306,8 @@ __device__ __forceinline__ void fold_b_job(const FoldBW<DPI>& w, const float* xs
 }
 
 #define FOLD_TPR_S 8  // target tiles staged in LDS per round (STAGE)
+#define FOLD_WU_FLOATS(DPI) ((((DPI) / 16 + 3) / 4) * 256)
+#define FOLD_UQ 4  // STAGE: u is computed on the VALU as FOLD_UQ partial sums per (head, slot), added where phase C reads them
 
 // STAGE (the 16-wave workgroups, alone on their CU): W_Q (d <= 96) and the round's target tiles are brought into LDS by
 // LDS-DMA requested in the kernel's first instructions -- each byte once per workgroup instead of once per (tile, head)
@@ -315,23 +317,26 @@ template <int DPI, int DHP, int NH, int NW, bool STAGE>
 __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a) {
 #define CF_STAMP(i)                                                                                  \
   do {                                                                                               \
-    if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+    if (a.stamps && threadIdx.x == 0 && !(a.dbg & 96)) a.stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
   CF_STAMP(0);
+  // diagnostic: per-WAVE stamps instead (dbg bit 32: first instruction of every wave, bit 64: arrival at the A barrier)
+  if (a.stamps && (a.dbg & 96) == 32 && (threadIdx.x & 63) == 0) a.stamps[blockIdx.x * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();
   using G = AttGeom<DPI, DHP, NH>;
   constexpr bool STAGE_W = STAGE && DPI <= 96;
   constexpr int TPR = STAGE ? FOLD_TPR_S : CROSS_TPR;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ps = lds;                    // [64][SI]  final-normed profile, re-based at the first real slot
   float* Ks = Ps + ATT_LMAX * G::SI;  // [64][SO]
-  float* Ut = Ks + ATT_LMAX * G::SO;  // [NH][ATT_SK]  u^T
-  float* Km = Ut + NH * ATT_SK;       // [64] additive key mask: 0 real key, FOLD_NEG pad / beyond the profile; then the slot mask (2 words)
+  float* Ut = Ks + ATT_LMAX * G::SO;  // [NH][ATT_SK]  u^T  (STAGE: [FOLD_UQ][NH][ATT_SK] partial sums over quarters of the features)
+  float* Km = Ut + (STAGE ? FOLD_UQ : 1) * NH * ATT_SK;  // [64] additive key mask: 0 real key, FOLD_NEG pad / beyond the profile; then the slot mask (2 words)
   float* Yp = Km + ATT_LMAX + 4;      // [CROSS_TPR][NH][16] per-head partial logits
   float* Ot = Yp + CROSS_TPR * NH * 16;               // STAGE: [TPR][NKG][64 lanes x 4] target tiles, fragment order
   float* Bq = Ot + FOLD_TPR_S * G::NKG * 256;         // STAGE: b_Q [DPO], then decoder.ffn.weight [DPI]
   float* Fw = Bq + 256;
   int* Ids = reinterpret_cast<int*>(Fw + 256);        // STAGE: [TPR * 16] target ids of the round
-  float* Wq = Fw + 256 + FOLD_TPR_S * 16;             // STAGE_W: W_Q, fragment order as packed
+  float* Wu = Fw + 256 + FOLD_TPR_S * 16;             // STAGE: wu as [k group of 4][head (4)][4]: the u wave's broadcast reads
+  float* Wq = Wu + FOLD_WU_FLOATS(DPI);               // STAGE_W: W_Q, fragment order as packed
 
   const int L = a.L, d = a.d, nparts = a.nparts;
   const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
@@ -420,7 +425,17 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   const bool dma_wave = STAGE && wave >= NLN;
   constexpr int PPW = (ATT_LMAX / 2 + NLN - 1) / NLN;  // row pairs per wave
   constexpr int NFB = G::NF + 1;                        // phase B jobs: feature tiles of K, then the u tile
-  static_assert(!STAGE || NFB <= NLN, "every phase B job needs a wave of the prologue");
+  // STAGE: the K jobs are cut in two (feature tile x HALF of the slot tiles: 2 NF jobs of 48 MFMAs, three per SIMD at
+  // d = 90 instead of two of 96 on three SIMDs and one on the fourth) and run on the first NKW waves.  u = p . wu + cu is
+  // VALU work, a slot per lane, beside the MFMAs (as an MFMA job it cost a whole feature tile's MFMAs for NH columns): task
+  // (head, quarter of the features) = 6-8 row reads, as many broadcast reads of wu, 12-16 packed FMAs, dealt to the waves
+  // whose K job ends first; the FOLD_UQ partial sums are added where phase C reads them (a fixed order: deterministic).
+  // Wave NKW brings wu into LDS.  (Not the DMA waves' work: hipcc orders an LDS read behind every outstanding LDS-DMA of the
+  // wave -- measured: they started when their last byte had landed, 5 k cycles into the phase.)
+  constexpr int NKW = STAGE ? NLN - 1 : NW;
+  constexpr int NUW = 8;  // waves that take u tasks (the first two of every SIMD)
+  static_assert(!STAGE || NH <= 4, "the weight image of u holds four heads");
+  static_assert(DPI / 4 % FOLD_UQ == 0, "feature quarters");
   const int half = lane >> 5, c4 = lane & 31;
   const bool col_ok = 4 * c4 < DPI;
   FoldBW<DPI> bw;
@@ -429,15 +444,21 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   bool have_pre = false;
   unsigned long long pmask = 0;
   int* Pm = reinterpret_cast<int*>(Km + ATT_LMAX);
-  if (dma_wave) {
+  auto dma_wq = [&]() {
+    if constexpr (STAGE_W)
+      if (!(a.dbg & 2))
+        for (int c = wave - NLN; c < G::DPO * DPI / 256; c += NDMA) dma16(a.wq, 4 * lane, 256 * c, Wq + 256 * c);
+  };
+  auto dma_rest = [&]() {
     if constexpr (STAGE) {
-      if constexpr (STAGE_W)
-        if (!(a.dbg & 2))
-          for (int c = wave - NLN; c < G::DPO * DPI / 256; c += NDMA) dma16(a.wq, 4 * lane, 256 * c, Wq + 256 * c);
       if (!(a.dbg & 4)) stage_tiles(t_lo, min(TPR, t_hi - t_lo), NLN, NDMA);
       if (wave == NW - 1 && lane < G::DPO / 4) dma16(a.bq, 4 * lane, 0, Bq);
       if (wave == NW - 1 && lane < DPI / 4) dma16(a.ffn_w, 4 * lane, 0, Fw);
     }
+  };
+  if (dma_wave) {
+    if (!(a.dbg & 384)) dma_wq();
+    if (!(a.dbg & 128)) dma_rest();
   } else {
     // ---- A0: every request of the prologue, none under a branch of its own (behind one, hipcc no longer knows how many
     // loads are in flight and turns the counted wait for the FIRST of them into a wait for nearly all) --------------
@@ -449,13 +470,26 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     f32x4 rv[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
+      // (a pair beyond the profile is not requested: every load a wave issues is 1 KB through the CU's 64 B/clk return
+      // path, wanted or not -- the front of the kernel is bound by that path, stamps in tools/k4_probe.py WAVES=1)
       const int r = 2 * (wave + NLN * j) + half;
-      rv[j] = gload4(p_user, (r < L ? r : 0) * a.ldp + (col_ok ? 4 * c4 : 0));
+      rv[j] = zero4();
+      if (2 * (wave + NLN * j) < L) rv[j] = gload4(p_user, (r < L ? r : 0) * a.ldp + (col_ok ? 4 * c4 : 0));
     }
     const f32x4 lnw = gload4(a.ln_w ? a.ln_w : a.bq, col_ok ? 4 * c4 : 0);  // (without a final norm b_Q stands in)
     const f32x4 lnb = gload4(a.ln_w ? a.ln_b : a.bq, col_ok ? 4 * c4 : 0);
     // this wave's phase B job (feature tile `wave`) gets its weight fragments now
-    fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, min(wave, NFB - 1), G::NF, lane, a.dbg & 16);
+    f32x4 wu_pre[(G::NKG + 3) / 4];
+    if constexpr (STAGE) {
+      if (wave < NKW && wave < 2 * G::NF) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, wave % G::NF, G::NF, lane, a.dbg & 16);
+      if (wave == NKW) {  // lane (kg' = lane >> 4, mq = (lane >> 2) & 3, h = lane & 3): wu[h][16 kg + 4 mq ..] out of the fragment order
+#pragma unroll
+        for (int c = 0; c < (G::NKG + 3) / 4; ++c)
+          wu_pre[c] = gload4(a.wu, 256 * min(4 * c + (lane >> 4), G::NKG - 1) + 64 * ((lane >> 2) & 3) + 4 * (lane & 3));
+      }
+    } else {
+      fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, min(wave, NFB - 1), G::NF, lane, a.dbg & 16);
+    }
     int tile_id0 = 0;
     if constexpr (STAGE) {
       tile_id0 = load_tile_id(t_lo, min(TPR, t_hi - t_lo));
@@ -511,6 +545,11 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     for (int t = nk + 2 * wave + half; t < min(ATT_LMAX, 32 * ((LTc + 1) >> 1)); t += 2 * NLN)
       if (col_ok) *reinterpret_cast<f32x4*>(Ps + t * G::SI + 4 * c4) = zero4();
     if (wave == NLN - 1) Km[lane] = (lane < nk && ((pmask >> (lane + s0)) & 1ull)) ? 0.f : FOLD_NEG;
+    if constexpr (STAGE)
+      if (wave == NKW) {
+#pragma unroll
+        for (int c = 0; c < (G::NKG + 3) / 4; ++c) *reinterpret_cast<f32x4*>(Wu + 256 * c + 4 * lane) = wu_pre[c];
+      }
     if (STAGE && tid == 0) {  // the slot mask, for the waves that did not see the ids
       Pm[0] = (int)(unsigned)pmask;
       Pm[1] = (int)(unsigned)(pmask >> 32);
@@ -520,8 +559,13 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   // LDS-only barrier, hand-written: the DMA stays in flight across it.  (__syncthreads(), and even a workgroup fence
   // restricted to LDS, make hipcc wait vmcnt(0) here: an outstanding LDS-DMA counts as a pending LDS write.  Nothing the
   // DMA writes is read before the __syncthreads() that ends phase B.)
+  if (a.stamps && (a.dbg & 96) == 64 && (threadIdx.x & 63) == 0) a.stamps[blockIdx.x * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   CF_STAMP(2);
+  if (dma_wave) {
+    if (a.dbg & 384) dma_wq();
+    if (a.dbg & 128) dma_rest();
+  }
   if (dma_wave)
     pmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(Pm[1]) << 32) |
             (unsigned)__builtin_amdgcn_readfirstlane(Pm[0]);
@@ -529,7 +573,39 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   const int nk = L - s0;
   const int LTc = (nk + 15) >> 4;
   // ---- B: K tiles and the u tile, every slot tile in one job ------------------------------------------------------------
-  {
+  if constexpr (STAGE) {
+    const int npair = (LTc + 1) >> 1;
+    if (wave < NKW) {
+      bool first = true;
+      for (int job = wave; job < 2 * G::NF && npair > 0; job += NKW) {
+        const int ft = job % G::NF, hf = job / G::NF;
+        if (!first) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, ft, G::NF, lane, a.dbg & 16);
+        first = false;
+        if (npair > 1) fold_b_chains<DPI, 2, false>(bw, Ps, G::SI, Ks, G::SO, Ut, ft, lane, NH, 2 * hf);
+        else fold_b_chains<DPI, 1, false>(bw, Ps, G::SI, Ks, G::SO, Ut, ft, lane, NH, hf);
+      }
+      if (wave < NUW && npair > 0) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr int KQ = DPI / 4 / FOLD_UQ;  // 16-byte feature groups per quarter
+        const float* xr = Ps + lane * G::SI;
+        for (int task = wave; task < FOLD_UQ * NH; task += NUW) {
+          const int h = task % NH, q = task / NH;
+          f32x4 xv[KQ], wv[KQ];
+#pragma unroll
+          for (int i = 0; i < KQ; ++i) xv[i] = lds4(xr + 4 * (q * KQ + i));
+#pragma unroll
+          for (int i = 0; i < KQ; ++i) wv[i] = lds4(Wu + 16 * (q * KQ + i) + 4 * h);
+          f32x2 acc = f32x2{q == 0 ? a.cu[h] : 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < KQ; ++i) {
+            acc = f32x2{xv[i][0], xv[i][1]} * f32x2{wv[i][0], wv[i][1]} + acc;
+            acc = f32x2{xv[i][2], xv[i][3]} * f32x2{wv[i][2], wv[i][3]} + acc;
+          }
+          Ut[task * ATT_SK + lane] = lane < 32 * npair ? acc[0] + acc[1] : 0.f;  // (task = q NH + h)
+        }
+      }
+    }
+  } else {
     const int npair = (LTc + 1) >> 1;
     bool first = true;
     for (int job = wave; job < NFB && npair > 0; job += NW) {
@@ -538,6 +614,9 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
       fold_b_job<DPI>(bw, Ps, G::SI, Ks, G::SO, Ut, job, G::NF, npair, lane, NH);
     }
   }
+  CF_STAMP(5);
+  // (dbg bits 32 + 64: every wave's clock when its phase B work is done)
+  if (a.stamps && (a.dbg & 96) == 96 && (threadIdx.x & 63) == 0) a.stamps[blockIdx.x * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();
   __syncthreads();
   CF_STAMP(3);
 
@@ -655,7 +734,11 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
         if (2 * kp < nkt) {
 #pragma unroll
           for (int kt = 2 * kp; kt < 2 * kp + 2; ++kt) {
-            const f32x4 uv = lds4(Ut + h * ATT_SK + 16 * kt + 4 * mq);
+            f32x4 uv = lds4(Ut + h * ATT_SK + 16 * kt + 4 * mq);
+            if constexpr (STAGE) {
+#pragma unroll
+              for (int q = 1; q < FOLD_UQ; ++q) uv = uv + lds4(Ut + (q * NH + h) * ATT_SK + 16 * kt + 4 * mq);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float e = __builtin_amdgcn_exp2f(sc[kt][r] - mx);
@@ -757,8 +840,8 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
 template <int DPI, int DHP, int NH, bool STAGE>
 constexpr size_t fold_lds_bytes() {
   using G = AttGeom<DPI, DHP, NH>;
-  size_t f = ATT_LMAX * G::SI + ATT_LMAX * G::SO + NH * ATT_SK + ATT_LMAX + 4 + CROSS_TPR * NH * 16;
-  if (STAGE) f += FOLD_TPR_S * G::NKG * 256 + 512 + FOLD_TPR_S * 16 + (DPI <= 96 ? G::DPO * DPI : 0);
+  size_t f = ATT_LMAX * G::SI + ATT_LMAX * G::SO + (STAGE ? FOLD_UQ : 1) * NH * ATT_SK + ATT_LMAX + 4 + CROSS_TPR * NH * 16;
+  if (STAGE) f += FOLD_TPR_S * G::NKG * 256 + 512 + FOLD_TPR_S * 16 + FOLD_WU_FLOATS(DPI) + (DPI <= 96 ? G::DPO * DPI : 0);
   return sizeof(float) * f;
 }
 

@@ -92,16 +92,19 @@ __global__ __launch_bounds__(1024) void sa_eval_kernel(const SaEvalArgs a) {
   f32x4 rv[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
+    // (a pair beyond the profile, or weights for a wave without a job, are not requested: every load a wave issues is
+    // 1 KB through the CU's 64 B/clk return path, wanted or not, and the kernel's front is bound by that path)
     const int r = 2 * (wave + NW * j) + half;
-    rv[j] = gload4(x_user, (r < L ? r : 0) * a.ldx + (col_ok ? 4 * c4 : 0));
+    rv[j] = zero4();
+    if (2 * (wave + NW * j) < L) rv[j] = gload4(x_user, (r < L ? r : 0) * a.ldx + (col_ok ? 4 * c4 : 0));
   }
   const f32x4 ln1w = gload4(a.w.ln1_w, col_ok ? 4 * c4 : 0), ln1b = gload4(a.w.ln1_b, col_ok ? 4 * c4 : 0);
   // phase B jobs: j < NF: K feature tile j; j >= NF: V^T feature tile j - NF.  This wave's first one gets its weights now.
   constexpr int NBJ = 2 * G::NF;
   f32x4 bwf[G::NKG], bb4;
   float bb1;
-  {
-    const int j = wave < NBJ ? wave : 0;
+  if (wave < NBJ) {
+    const int j = wave;
     const bool isv = j >= G::NF;
     const int ft = isv ? j - G::NF : j;
     const float* wp = isv ? a.w.wv : a.w.wk;

@@ -366,14 +366,17 @@ def test_two_workgroups_per_user_is_bitwise_the_same():
                 outs[tune] = model(profile=dev(profile), targets=[dev(target)]).cpu()
     finally:
         lib.carca_set_tuning(1, 0)
-    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
+    # one vs two 16-wave workgroups: the same instruction stream per tile, bit for bit.  The 8-wave workgroups compute the
+    # folded value u = p . wu + cu as an MFMA tile, the 16-wave ones as four partial sums on the VALU: last bits only.
+    assert torch.equal(outs[1], outs[2]) and float((outs[1] - outs[3]).abs().max()) < 5e-7
     want = O.carca_forward(P, cfg, profile, [target], training=False)
     assert float((outs[2] - want).abs().max()) < Y_ATOL
 
 
 def test_big_batch_scoring_variant_is_bitwise_the_same():
-    """B > #CUs takes the scoring kernel's 8-wave workgroups (two resident per CU) by itself: same bits as the 16-wave
-    ones (tuning key 1 = 1), and the oracle's numbers."""
+    """B > #CUs takes the scoring kernel's 8-wave workgroups (two resident per CU) by itself: the 16-wave ones' results
+    (tuning key 1 = 1) up to the summation order of the folded value u (MFMA tile there, VALU partial sums here), and the
+    oracle's numbers."""
     from carca_replication_amd import _lib
 
     cfg = O.CarcaConfig(d=90, H=3, n_blocks=1, encoding="learnable")
@@ -390,7 +393,7 @@ def test_big_batch_scoring_variant_is_bitwise_the_same():
                 outs[tune] = model(profile=dev(profile), targets=[dev(target)]).cpu()
     finally:
         lib.carca_set_tuning(1, 0)
-    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - outs[1]).abs().max()) < 5e-7
     want = O.carca_forward(P, cfg, profile, [target], training=False)
     assert float((outs[0] - want).abs().max()) < Y_ATOL
 

@@ -87,7 +87,7 @@ for B in [int(b) for b in os.environ.get("BS", "128,256,512,1024,4096").split(",
             extra = f"   folded, unstaged {t_ns * 1e6:8.1f} us"
         print(f"B={B:5d} {lengths:8s} materialised {t_old * 1e6:8.1f} us {B * CA / t_old / PEAK * 100:5.1f} %   "
               f"folded {t_new * 1e6:8.1f} us {B * CA / t_new / PEAK * 100:5.1f} %" + extra, flush=True)
-NAMES = ["start", "ids in", "A barrier passed", "B done", "end", "B weights in", "LN done", "job: operands", "job: Q proj", "job: scores",
+NAMES = ["start", "ids in", "A barrier passed", "B done", "end", "wave 0: B work done", "LN done", "job: operands", "job: Q proj", "job: scores",
          "job: softmax", "C barrier passed", "at A barrier"]
 if os.environ.get("STAMPS", "1") != "0":
     for dbg in [int(x) for x in os.environ.get("DBG", "0,2,4,16,22").split(",")]:
@@ -106,8 +106,43 @@ if os.environ.get("STAMPS", "1") != "0":
             st = buf.view(nwg, 16).cpu().double()
             st = st[st[:, 0] > 0]
             rel = st - st[:, :1]
-            order = [1, 6, 5, 12, 2, 3, 7, 8, 9, 10, 11, 4]
+            order = [1, 6, 12, 2, 5, 3, 7, 8, 9, 10, 11, 4]
             print(f"dbg={dbg} B={B} {lengths}: {t * 1e6:.1f} us; cycles since kernel start, median over {len(st)} workgroups (max):")
             print("   " + "  ".join(f"[{NAMES[i]}] {rel[:, i][rel[:, i] > 0].median() if (rel[:, i] > 0).any() else 0:.0f}"
                                     f" ({rel[:, i].max():.0f})" for i in order), flush=True)
+    lib.carca_set_tuning(5, 0)
+if os.environ.get("WAVES"):  # per-wave clocks: start of every wave (dbg 32) and its arrival at the A barrier (dbg 64)
+    a = inputs(128, "full")
+    per = {}
+    for dbg in (32,):
+        lib.carca_set_tuning(5, dbg)
+        for _ in range(5):
+            run(*a, False, True)
+        buf = torch.zeros(256 * 16, dtype=torch.int64, device="cuda")
+        lib.carca_set_debug_buffer(buf.data_ptr())
+        run(*a, False, True)
+        torch.cuda.synchronize()
+        lib.carca_set_debug_buffer(None)
+        per[dbg] = buf.view(256, 16).cpu().double()
+    lib.carca_set_tuning(5, 0)
+    st = per[32]
+    print("wave start - earliest wave start of the workgroup, median (max) over workgroups:")
+    rel = st - st.min(dim=1, keepdim=True).values
+    print("   " + "  ".join(f"w{w}: {rel[:, w].median():.0f} ({rel[:, w].max():.0f})" for w in range(16)))
+    print(f"   workgroup start - earliest workgroup start: median {float((st.min(1).values - st.min()).median()):.0f}, max {float((st.min(1).values - st.min()).max()):.0f}")
+    for extra, what in ((0, ""), (8, ", no LayerNorm arithmetic"), (6, ", no W_Q / target-tile DMA issued"), (14, ", neither"), (32, ": END OF PHASE B work instead"), (38, ": END OF PHASE B work, no DMA issued")):
+        lib.carca_set_tuning(5, 64 | extra)
+        for _ in range(5):
+            run(*a, False, True)
+        buf = torch.zeros(256 * 16, dtype=torch.int64, device="cuda")
+        lib.carca_set_debug_buffer(buf.data_ptr())
+        run(*a, False, True)
+        torch.cuda.synchronize()
+        lib.carca_set_debug_buffer(None)
+        ar = buf.view(256, 16).cpu().double()
+        print(f"(separate launch{what}) arrival at the A barrier - earliest arrival of the workgroup:")
+        rel = ar - ar.min(dim=1, keepdim=True).values
+        print("   " + "  ".join(f"w{w}: {rel[:, w].median():.0f} ({rel[:, w].max():.0f})" for w in range(16)))
+        print(f"   last wave of a workgroup: median {float(rel.max(dim=1).values.median()):.0f}; which wave is last: "
+              + str(torch.bincount(rel.argmax(dim=1), minlength=16).tolist()))
     lib.carca_set_tuning(5, 0)
