@@ -405,7 +405,7 @@ def main():
                                   "bound": "mfma", "achieved": sa_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": sa_tflops / PEAK_F32_MFMA_TFLOPS, "avg_ms": sa_avg, "min_ms": sa_ms[0],
                                   "algorithmic_gflop_per_launch": c["B"] * fl["sa"] / c["n_blocks"] / 1e9},
-            "roofline_joint_gemm": {"kernel": "gemm_rows_kernel (AllEmbedding.joint_embed, carca.py:89)", "bound": "mfma",
+            "roofline_joint_gemm": {"kernel": "gemm_rows_n96_kernel, one 80x96 block per CU (AllEmbedding.joint_embed, carca.py:89)", "bound": "mfma",
                                     "achieved": joint_flops / (joint_avg * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                                     "unit": "TFLOP/s", "frac": joint_flops / (joint_avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                     "avg_ms": joint_avg, "min_ms": joint_ms[0],

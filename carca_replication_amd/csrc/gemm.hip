@@ -33,6 +33,7 @@ struct GemmDev {
   int rb_start[CARCA_MAX_SEGS + 1];
   int nrb, ncb;
   unsigned long long* dbg;  // phase-stamp buffer of a diagnostic run (DBG instantiation only)
+  int diag;                 // timing experiments of gemm_rows_n96_kernel (tuning key 5; wrong results): 1 no loads, 2 no MFMAs, 4 plain epilogue, 8 no stores
   int has_pas;              // one-block-per-CU kernel: block nrb * ncb (one past the tiles) runs the item-row gather
   CarcaGatherArgs pas;
 };
@@ -558,6 +559,213 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// gemm_rows_n96_kernel: the same product for a NARROW output (64 < N <= 96: the joint embedding e = [z ; q] W_j^T,
+// carca.py:89) over one k-source with a short K (540 at C2).  The 128 x 32 blocks above leave one dependent chain per
+// K step on eight waves a CU and two unequal rounds of blocks; here ONE 768-thread block per CU takes 80 rows x all 96
+// columns (19328 rows = 242 blocks on 256 CUs, one round): 5 x 6 16x16 tiles, wave (ct = wave % 6, kh = wave / 6) owns
+// column tile ct over the five row tiles for one half of every 64-wide K stage -- 2 x 20 MFMAs (16x16x4) in five
+// independent chains behind twelve 16-byte fragment reads, three waves per SIMD -- and the two K halves meet in LDS at
+// the end.  Stages are double-buffered in LDS (one barrier per stage) behind a two-stage register ring of buffer loads;
+// what the epilogue reads per row (ids, positional rows, bias) is requested before the K loop.
+// Per CU the product needs 80 x 540 of A (173 KB) and all of W_j (207 KB) for 4050 MFMAs = 32.4 k cycles per SIMD =
+// 13.5 us; the launch itself (prologue, first round trip, epilogue without its stores) measures 7.8 us in the pipeline.
+namespace n96 {
+constexpr int BM = 80, BN = 96, BK = 64, LS = BK + 4, NT = 768, C4 = BK / 4;
+constexpr int A_SLOTS = BM * C4, B_SLOTS = BN * C4;        // 1280 + 1536 sixteen-byte slots per stage
+constexpr int NSL = (A_SLOTS + B_SLOTS + NT - 1) / NT;    // 4 per thread (the last one for the first 512 threads)
+constexpr int A_BUF = BM * LS, B_BUF = BN * LS;
+static_assert(A_SLOTS % 64 == 0 && (A_SLOTS + B_SLOTS) % 64 == 0, "a wave's slots are all A, all B or all void");
+}  // namespace n96
+
+__global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) {
+  using namespace n96;
+  extern __shared__ __attribute__((aligned(16))) float Sm[];  // 2 x (A stage + B stage)
+  float* As = Sm;
+  float* Bs = Sm + 2 * A_BUF;
+  static_assert(2 * (A_BUF + B_BUF) >= BM * (BN + 4), "the K-half partial sums reuse the stage buffers");
+  const CarcaGemmDesc& D = args.d;
+  const int rb = blockIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+    if (i < D.nseg && rb >= args.rb_start[i]) s = i;
+  const CarcaGemmSeg sg = D.seg[s];
+  const int row0 = (rb - args.rb_start[s]) * BM;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform to the compiler too: scalar branches, scalar resource choice)
+  const int ln = lane & 15, mq = lane >> 4;
+  const int ct = wave % 6, kh = wave / 6;
+  const int nst = (D.K0 + BK - 1) / BK;
+  const int diag = args.diag;
+
+  // staging slots tid + 768 i: A slots first, then B slots; a slot past the end repeats the thread's previous one (same
+  // load, same store: harmless) so that the pipelined body has no branch -- behind a branch with loads inside, hipcc
+  // turns every counted wait into vmcnt(0)
+  unsigned off[NSL];   // byte offset of the slot's row start
+  int c4s[NSL], ldsx[NSL], bstr[NSL];
+  bool slot_a[NSL];
+#pragma unroll
+  for (int i = 0; i < NSL; ++i) {
+    int slot = tid + i * NT;
+    if (slot >= A_SLOTS + B_SLOTS) slot -= NT;
+    const bool is_a = slot < A_SLOTS;
+    slot_a[i] = (i * NT + (wave << 6) >= A_SLOTS + B_SLOTS ? (i - 1) * NT + (wave << 6) : i * NT + (wave << 6)) < A_SLOTS;  // (uniform)
+    const int bs = slot - A_SLOTS;
+    const int r = is_a ? slot / C4 : bs / C4;
+    c4s[i] = (is_a ? slot : bs) % C4;
+    const int gr = min(row0 + r, sg.rows - 1);
+    const int ub = gr / sg.T, ut = gr - ub * sg.T;
+    const size_t ao = sg.a0_bstride ? (size_t)ub * sg.a0_bstride + (size_t)ut * D.lda0 : (size_t)gr * D.lda0;
+    off[i] = is_a ? (unsigned)(ao * sizeof(float)) : (unsigned)((size_t)min(r, D.N - 1) * D.ldb0 * sizeof(float));
+    ldsx[i] = (is_a ? 0 : 2 * A_BUF) + r * LS + c4s[i] * 4;  // float index inside Sm for buffer 0
+    bstr[i] = is_a ? A_BUF : B_BUF;
+  }
+  const __amdgpu_buffer_rsrc_t r_a = carca_rsrc(sg.a0), r_b = carca_rsrc(D.bt0);
+  f32x4 rg[3][NSL];  // three stages of loads in flight (the fabric streams while the MFMAs run)
+  auto load_stage = [&](int st, int ring) {
+    // (the last stage of a K that is no multiple of 64: 16-byte groups past K are clamped to the last valid one and
+    // zeroed when stored; K0 % 4 == 0, so a group is all inside or all outside)
+    const int kb = st * BK;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const unsigned kc = 4u * (unsigned)min(kb + c4s[i] * 4, D.K0 - 4);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(slot_a[i] ? r_a : r_b, off[i] + kc, 0, 0);
+      rg[ring][i] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    }
+  };
+  auto store_stage = [&](int st, int ring, int buf) {
+    const int kb = st * BK;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const f32x4 v = kb + c4s[i] * 4 < D.K0 ? rg[ring][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&Sm[ldsx[i] + buf * bstr[i]]) = v;
+    }
+  };
+
+  // ---- the epilogue's per-row operands (ids, positional rows, bias) are requested behind the K loop, all at once, as
+  // unconditional buffer loads (a load under a branch, or a select on a loaded value, is waited for right there, one row
+  // after the other); where a pointer is absent the weights stand in and the value is dropped.
+  // acc[rt][r] = C[row0 + 16 rt + 4 mq + r][16 ct + ln]
+  const int n = 16 * ct + ln;
+  const bool n_ok = n < D.N;
+  const bool fancy = !(diag & 4);
+  const bool use_pos = sg.add_pos && D.pos;
+
+  f32x4 acc[5];
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragments: lane (ln, mq) reads 16 bytes = k 4 mq .. + 3 of a 16-wide chunk of its row; this wave's chunks of a stage
+  // are 2 kh and 2 kh + 1
+  const float* a_frag = &As[ln * LS + 32 * kh + 4 * mq];
+  const float* b_frag = &Bs[(16 * ct + ln) * LS + 32 * kh + 4 * mq];
+  auto compute = [&](int buf) {
+    // (reading all twelve fragments of the stage ahead of its 40 MFMAs measured 1 us SLOWER than chunk by chunk)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(b_frag + buf * B_BUF + 16 * ch);
+      f32x4 a[5];
+#pragma unroll
+      for (int rt = 0; rt < 5; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(a_frag + buf * A_BUF + rt * 16 * LS + 16 * ch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int rt = 0; rt < 5; ++rt) acc[rt] = mfma16(a[rt][e], b[e], acc[rt]);
+    }
+  };
+
+  load_stage(0, 0);
+  if (nst > 1) load_stage(1, 1);
+  if (nst > 2) load_stage(2, 2);
+  store_stage(0, 0, 0);
+  __syncthreads();
+  // stage st: LDS buffer st % 2, ring slot st % 3; unrolled by six so that both are compile-time constants
+#define N96_STEP(o, R1, B1, R3, B0)                                        \
+  if (st + (o) < nst) {                                                    \
+    if (st + (o) + 1 < nst) store_stage(st + (o) + 1, R1, B1);             \
+    if (st + (o) + 3 < nst && !(diag & 1)) load_stage(st + (o) + 3, R3);   \
+    if (!(diag & 2)) compute(B0);                                          \
+    __syncthreads();                                                       \
+  }
+  for (int st = (diag & 16) ? nst : 0; st < nst; st += 6) {
+    N96_STEP(0, 1, 1, 0, 0)
+    N96_STEP(1, 2, 0, 1, 1)
+    N96_STEP(2, 0, 1, 2, 0)
+    N96_STEP(3, 1, 0, 0, 1)
+    N96_STEP(4, 2, 1, 1, 0)
+    N96_STEP(5, 0, 0, 2, 1)
+  }
+#undef N96_STEP
+  // ---- the two K halves meet: kh = 1 leaves its sums in LDS (the stage buffers are dead), kh = 0 adds and finishes ------
+  float* Part = Sm;  // [BM][BN + 4]
+  constexpr int PS = BN + 4;
+  int idv[5][4];
+  float posv[5][4];
+  float bias;
+  {
+    const float* posp = use_pos ? D.pos : D.bt0;
+    const int32_t* idp = sg.ids ? sg.ids : reinterpret_cast<const int32_t*>(D.bt0);
+    const int nn = min(n, D.N - 1);
+    bias = gload1(D.bias ? D.bias : D.bt0, nn);
+    const int t0 = use_pos ? row0 % sg.T : 0;
+#pragma unroll
+    for (int rt = 0; rt < 5; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = 16 * rt + 4 * mq + r;
+        const int row = min(row0 + lrow, sg.rows - 1);
+        int tt = t0 + lrow;  // (row % T without twenty divisions: t0 + 79 < 4 T for T >= 27; smaller T takes the slow form)
+        if (use_pos) {
+          if (sg.T >= 27) {
+            tt = tt >= sg.T ? tt - sg.T : tt;
+            tt = tt >= sg.T ? tt - sg.T : tt;
+            tt = tt >= sg.T ? tt - sg.T : tt;
+          } else {
+            tt %= sg.T;
+          }
+        }
+        idv[rt][r] = gload1i(idp, sg.ids ? row : 0);
+        posv[rt][r] = gload1(posp, use_pos ? tt * D.N + nn : 0);
+      }
+  }
+  if (kh == 1) {
+#pragma unroll
+    for (int rt = 0; rt < 5; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Part[(16 * rt + 4 * mq + r) * PS + 16 * ct + ln] = acc[rt][r];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+  if (n >= D.ncols_out) return;
+  const float cv = (n_ok && D.colvec) ? D.colvec[n] : 0.f;
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lrow = 16 * rt + 4 * mq + r, row = row0 + lrow;
+      if (row >= sg.rows) continue;
+      float v = 0.f;
+      if (n_ok) {
+        const float a = acc[rt][r] + Part[lrow * PS + n];
+        v = (D.alpha != 0.f ? D.alpha * a : a) + (D.bias ? bias : 0.f);
+        if (!fancy) {
+          if (!(diag & 8) || v == 123.456f) sg.c[(size_t)row * D.ldc + n] = v;
+          continue;
+        }
+        if (use_pos) v += posv[rt][r];
+        if (sg.add) v += sg.add[(size_t)row * D.ld_add + n];
+        if (sg.rowscale) v += sg.rowscale[row] * cv;
+        if (sg.gate) {
+          const float gv = sg.gate[(size_t)row * D.ld_gate + n];
+          const float gs = D.gate_scale != 0.f ? D.gate_scale : 1.0f;
+          v *= gv > 0.f ? gs : ((gv < 0.f || !D.gate_zero_drops) ? D.gate_slope * gs : 0.f);
+        }
+        if (D.mask_rows) v = idv[rt][r] != 0 ? v : 0.f;
+      }
+      sg.c[(size_t)row * D.ldc + n] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 struct WgradDev {
   CarcaWgradDesc d;
   int chunk_start[CARCA_MAX_SEGS + 1];  // 32-row chunks per segment, prefix sums
@@ -802,7 +1010,39 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream, co
   return CARCA_OK;
 }
 
-enum GemmChoice { GEMM_NARROW_BUF, GEMM_NARROW, GEMM_CU, GEMM_CU_STAMPS, GEMM_CU128, GEMM_TILED_BUF, GEMM_TILED, GEMM_WIDE64, GEMM_WIDE64_PF2 };
+static int launch_gemm_rows_n96(const CarcaGemmDesc* desc, hipStream_t stream) {
+  GemmDev g{};
+  g.d = *desc;
+  int rb = 0;
+  for (int s = 0; s < desc->nseg; ++s) {
+    if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
+    g.rb_start[s] = rb;
+    rb += (desc->seg[s].rows + n96::BM - 1) / n96::BM;
+  }
+  g.rb_start[desc->nseg] = rb;
+  g.nrb = rb;
+  g.ncb = 1;
+  g.diag = carca_tuning(5);
+  constexpr size_t lds_bytes = sizeof(float) * 2 * (n96::A_BUF + n96::B_BUF);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_n96_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      carca_set_error("gemm_rows: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  hipEvent_t e0, e1;
+  if (carca_take_launch_events(&e0, &e1))
+    hipExtLaunchKernelGGL(gemm_rows_n96_kernel, dim3(rb), dim3(768), lds_bytes, stream, e0, e1, 0, g);
+  else
+    hipLaunchKernelGGL(gemm_rows_n96_kernel, dim3(rb), dim3(768), lds_bytes, stream, g);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+enum GemmChoice { GEMM_NARROW_BUF, GEMM_NARROW, GEMM_CU, GEMM_CU_STAMPS, GEMM_CU128, GEMM_TILED_BUF, GEMM_TILED, GEMM_WIDE64, GEMM_WIDE64_PF2, GEMM_N96 };
 
 // argument checks + kernel selection of one product
 static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice) {
@@ -851,6 +1091,20 @@ static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice) {
   if (narrow) {
     *choice = fits ? GEMM_NARROW_BUF : GEMM_NARROW;
     if (fits && (variant == 9 || variant == 10)) *choice = variant == 9 ? GEMM_WIDE64 : GEMM_WIDE64_PF2;
+    // one 80 x 96 block per CU: narrow output over ONE k-source with a K worth pipelining, rows that fill the chip in about
+    // one round, every operand row 16-byte aligned (variant 11 forces it where it applies, 12 forbids it)
+    if (fits && variant != 12 && desc->K1 == 0 && desc->N > 64 && desc->ncols_out <= 96 && desc->K0 % 4 == 0 &&
+        desc->lda0 % 4 == 0 && desc->ldb0 % 4 == 0 && ((uintptr_t)desc->bt0 & 15) == 0) {
+      bool ok = true;
+      int rb80 = 0;
+      for (int s = 0; s < desc->nseg; ++s) {
+        const CarcaGemmSeg& sg = desc->seg[s];
+        ok = ok && !sg.a0_gather && ((uintptr_t)sg.a0 & 15) == 0 && sg.a0_bstride % 4 == 0;
+        rb80 += (sg.rows + n96::BM - 1) / n96::BM;
+      }
+      const int cus = carca_num_cus();
+      if (ok && (variant == 11 || (variant == 0 && desc->K0 >= 256 && rb80 > cus / 2 && rb80 <= cus))) *choice = GEMM_N96;
+    }
     return CARCA_OK;
   }
   // One 384 x 96 block per CU when the grid fills the chip's 256 CUs about as well as the 128 x 96 blocks (3 per CU)
@@ -888,6 +1142,7 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
     case GEMM_CU128: return launch_gemm_rows_cu<0, 4>(desc, stream);
     case GEMM_WIDE64: return launch_gemm_rows<64, 96, 32, 4, true>(desc, stream);
     case GEMM_WIDE64_PF2: return launch_gemm_rows<64, 96, 32, 2, true>(desc, stream);
+    case GEMM_N96: return launch_gemm_rows_n96(desc, stream);
     case GEMM_TILED_BUF: return launch_gemm_rows<128, 96, 32, 1, true>(desc, stream);
     default: return launch_gemm_rows<128, 96, 32, 1>(desc, stream);
   }

@@ -530,3 +530,30 @@ def test_sa_eval_kernel_equals_oracle_and_training_kernel(d, H, L):
     assert torch.equal(outs["eval"], outs["eval-2wg"])                   # the split only moves tiles between workgroups
     assert torch.equal(outs["eval-uniform"], outs["eval-2wg-uniform"])
     assert float((outs["eval"] - outs["eval-uniform"]).abs().max()) < 1e-6   # (re-based rows: other tile / lane, same sums)
+
+
+@pytest.mark.parametrize("B,L,N,enc", [(40, 50, 101, "learnable"), (33, 50, 37, "identity"), (7, 23, 5, "positional")])
+def test_one_block_per_cu_joint_gemm_equals_the_tiled_one(B, L, N, enc):
+    """The 80 x 96 row GEMM (gemm_rows_n96_kernel: narrow output over one k-source -- AllEmbedding.joint_embed,
+    carca.py:89, with its positional rows, bias and padding mask in the epilogue) forced on (tuning key 0 = 11) against
+    the 128 x 32 blocks (12), at row counts that are no multiple of its tile and a K (d + g = 540) that is no multiple of
+    its stage; then the oracle."""
+    from carca_replication_amd import _lib
+
+    cfg = O.CarcaConfig(d=90, H=3, n_blocks=1, encoding=enc)
+    n_items, n_attrs, n_ctx, g = 300, 40, 6, 450
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    profile, target, _ = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=B)
+    model = model_from_params(P, cfg).eval()
+    lib = _lib.load()
+    outs = {}
+    try:
+        for variant in (11, 12):
+            lib.carca_set_tuning(0, variant)
+            with torch.no_grad():
+                outs[variant] = model(profile=dev(profile), targets=[dev(target)]).cpu()
+    finally:
+        lib.carca_set_tuning(0, 0)
+    assert float((outs[11] - outs[12]).abs().max()) < 2e-6
+    want = O.carca_forward(P, cfg, profile, [target], training=False)
+    assert float((outs[11] - want).abs().max()) < Y_ATOL
