@@ -293,21 +293,9 @@ __device__ __forceinline__ void fold_b_chains(const FoldBW<DPI>& w, const float*
     }
   }
 }
-template <int DPI>
-__device__ __forceinline__ void fold_b_job(const FoldBW<DPI>& w, const float* xs, int si, float* Ks, int so, float* Ut,
-                                           int ft, int nf, int npair, int lane, int nh) {
-  if (ft == nf) {  // (uniform)
-    if (npair > 1) fold_b_chains<DPI, 4, true>(w, xs, si, Ks, so, Ut, ft, lane, nh);
-    else fold_b_chains<DPI, 2, true>(w, xs, si, Ks, so, Ut, ft, lane, nh);
-  } else {
-    if (npair > 1) fold_b_chains<DPI, 4, false>(w, xs, si, Ks, so, Ut, ft, lane, nh);
-    else fold_b_chains<DPI, 2, false>(w, xs, si, Ks, so, Ut, ft, lane, nh);
-  }
-}
-
 #define FOLD_TPR_S 8  // target tiles staged in LDS per round (STAGE)
 #define FOLD_WU_FLOATS(DPI) ((((DPI) / 16 + 3) / 4) * 256)
-#define FOLD_UQ 4  // STAGE: u is computed on the VALU as FOLD_UQ partial sums per (head, slot), added where phase C reads them
+#define FOLD_UQ 4  // u is computed on the VALU as FOLD_UQ partial sums per (head, slot), added where phase C reads them
 
 // STAGE (the 16-wave workgroups, alone on their CU): W_Q (d <= 96) and the round's target tiles are brought into LDS by
 // LDS-DMA requested in the kernel's first instructions -- each byte once per workgroup instead of once per (tile, head)
@@ -328,15 +316,15 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ps = lds;                    // [64][SI]  final-normed profile, re-based at the first real slot
   float* Ks = Ps + ATT_LMAX * G::SI;  // [64][SO]
-  float* Ut = Ks + ATT_LMAX * G::SO;  // [NH][ATT_SK]  u^T  (STAGE: [FOLD_UQ][NH][ATT_SK] partial sums over quarters of the features)
-  float* Km = Ut + (STAGE ? FOLD_UQ : 1) * NH * ATT_SK;  // [64] additive key mask: 0 real key, FOLD_NEG pad / beyond the profile; then the slot mask (2 words)
+  float* Ut = Ks + ATT_LMAX * G::SO;  // [FOLD_UQ][NH][ATT_SK]  u^T as partial sums over quarters of the features
+  float* Km = Ut + FOLD_UQ * NH * ATT_SK;  // [64] additive key mask: 0 real key, FOLD_NEG pad / beyond the profile; then the slot mask (2 words)
   float* Yp = Km + ATT_LMAX + 4;      // [CROSS_TPR][NH][16] per-head partial logits
-  float* Ot = Yp + CROSS_TPR * NH * 16;               // STAGE: [TPR][NKG][64 lanes x 4] target tiles, fragment order
+  float* Wu = Yp + CROSS_TPR * NH * 16;               // wu as [k group of 4][head (4)][4]: the u tasks' broadcast reads
+  float* Ot = Wu + FOLD_WU_FLOATS(DPI);               // STAGE: [TPR][NKG][64 lanes x 4] target tiles, fragment order
   float* Bq = Ot + FOLD_TPR_S * G::NKG * 256;         // STAGE: b_Q [DPO], then decoder.ffn.weight [DPI]
   float* Fw = Bq + 256;
   int* Ids = reinterpret_cast<int*>(Fw + 256);        // STAGE: [TPR * 16] target ids of the round
-  float* Wu = Fw + 256 + FOLD_TPR_S * 16;             // STAGE: wu as [k group of 4][head (4)][4]: the u wave's broadcast reads
-  float* Wq = Wu + FOLD_WU_FLOATS(DPI);               // STAGE_W: W_Q, fragment order as packed
+  float* Wq = Fw + 256 + FOLD_TPR_S * 16;             // STAGE_W: W_Q, fragment order as packed
 
   const int L = a.L, d = a.d, nparts = a.nparts;
   const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
@@ -424,17 +412,20 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   constexpr int NDMA = STAGE ? 3 : 0, NLN = NW - NDMA;
   const bool dma_wave = STAGE && wave >= NLN;
   constexpr int PPW = (ATT_LMAX / 2 + NLN - 1) / NLN;  // row pairs per wave
-  constexpr int NFB = G::NF + 1;                        // phase B jobs: feature tiles of K, then the u tile
-  // STAGE: the K jobs are cut in two (feature tile x HALF of the slot tiles: 2 NF jobs of 48 MFMAs, three per SIMD at
-  // d = 90 instead of two of 96 on three SIMDs and one on the fourth) and run on the first NKW waves.  u = p . wu + cu is
-  // VALU work, a slot per lane, beside the MFMAs (as an MFMA job it cost a whole feature tile's MFMAs for NH columns): task
-  // (head, quarter of the features) = 6-8 row reads, as many broadcast reads of wu, 12-16 packed FMAs, dealt to the waves
-  // whose K job ends first; the FOLD_UQ partial sums are added where phase C reads them (a fixed order: deterministic).
-  // Wave NKW brings wu into LDS.  (Not the DMA waves' work: hipcc orders an LDS read behind every outstanding LDS-DMA of the
-  // wave -- measured: they started when their last byte had landed, 5 k cycles into the phase.)
+  // Phase B: the K jobs are cut in two (feature tile x HALF of the slot tiles: 2 NF jobs of 48 MFMAs -- three per SIMD at
+  // d = 90, on 12 of the staged variant's waves or as 2 + 1 on the 8-wave variant's SIMDs -- instead of NF + 1 jobs of 96,
+  // two on three SIMDs and one on the fourth) and run on the first NKW waves.  u = p . wu + cu is VALU work, a slot per
+  // lane, beside the MFMAs (as an MFMA job it cost a whole feature tile's MFMAs for NH columns): task (head, quarter of the
+  // features) = 6-8 row reads, as many broadcast reads of wu, 12-16 packed FMAs, dealt to the waves whose K jobs end first
+  // (U0 ..); the FOLD_UQ partial sums are added where phase C reads them (a fixed order: deterministic).  Wave WUW brings
+  // wu into LDS.  (Not the DMA waves' work: hipcc orders an LDS read behind every outstanding LDS-DMA of the wave --
+  // measured: they started when their last byte had landed, 5 k cycles into the phase.)
   constexpr int NKW = STAGE ? NLN - 1 : NW;
-  constexpr int NUW = 8;  // waves that take u tasks (the first two of every SIMD)
-  static_assert(!STAGE || NH <= 4, "the weight image of u holds four heads");
+  constexpr int NKJ = 2 * G::NF;                                   // half jobs
+  constexpr int U0 = NKJ % NKW;                                    // first wave with the lighter K load
+  constexpr int NUW = (NKW - U0) < 8 ? (NKW - U0) : 8;             // waves that take u tasks
+  constexpr int WUW = STAGE ? NKW : NW - 1;                        // the wave that stages wu
+  static_assert(NH <= 4, "the weight image of u holds four heads");
   static_assert(DPI / 4 % FOLD_UQ == 0, "feature quarters");
   const int half = lane >> 5, c4 = lane & 31;
   const bool col_ok = 4 * c4 < DPI;
@@ -480,20 +471,16 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     const f32x4 lnb = gload4(a.ln_w ? a.ln_b : a.bq, col_ok ? 4 * c4 : 0);
     // this wave's phase B job (feature tile `wave`) gets its weight fragments now
     f32x4 wu_pre[(G::NKG + 3) / 4];
-    if constexpr (STAGE) {
-      if (wave < NKW && wave < 2 * G::NF) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, wave % G::NF, G::NF, lane, a.dbg & 16);
-      if (wave == NKW) {  // lane (kg' = lane >> 4, mq = (lane >> 2) & 3, h = lane & 3): wu[h][16 kg + 4 mq ..] out of the fragment order
+    if (wave < NKW && wave < NKJ) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, wave % G::NF, G::NF, lane, a.dbg & 16);
+    if (wave == WUW) {  // lane (kg' = lane >> 4, mq = (lane >> 2) & 3, h = lane & 3): wu[h][16 kg + 4 mq ..] out of the fragment order
 #pragma unroll
-        for (int c = 0; c < (G::NKG + 3) / 4; ++c)
-          wu_pre[c] = gload4(a.wu, 256 * min(4 * c + (lane >> 4), G::NKG - 1) + 64 * ((lane >> 2) & 3) + 4 * (lane & 3));
-      }
-    } else {
-      fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, min(wave, NFB - 1), G::NF, lane, a.dbg & 16);
+      for (int c = 0; c < (G::NKG + 3) / 4; ++c)
+        wu_pre[c] = gload4(a.wu, 256 * min(4 * c + (lane >> 4), G::NKG - 1) + 64 * ((lane >> 2) & 3) + 4 * (lane & 3));
     }
     int tile_id0 = 0;
     if constexpr (STAGE) {
       tile_id0 = load_tile_id(t_lo, min(TPR, t_hi - t_lo));
-    } else if constexpr (DPI <= 96) {
+    } else if constexpr (DPI <= 64) {
       // (d > 96: eight fragments per target row and per weight tile; the prefetch would not fit 128 registers)
       // requested by every wave, job or not: a wave without a job fetches job 0's
       const bool pre_ok = wave < min(TPR, t_hi - t_lo) * NH;
@@ -545,11 +532,10 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     for (int t = nk + 2 * wave + half; t < min(ATT_LMAX, 32 * ((LTc + 1) >> 1)); t += 2 * NLN)
       if (col_ok) *reinterpret_cast<f32x4*>(Ps + t * G::SI + 4 * c4) = zero4();
     if (wave == NLN - 1) Km[lane] = (lane < nk && ((pmask >> (lane + s0)) & 1ull)) ? 0.f : FOLD_NEG;
-    if constexpr (STAGE)
-      if (wave == NKW) {
+    if (wave == WUW) {
 #pragma unroll
-        for (int c = 0; c < (G::NKG + 3) / 4; ++c) *reinterpret_cast<f32x4*>(Wu + 256 * c + 4 * lane) = wu_pre[c];
-      }
+      for (int c = 0; c < (G::NKG + 3) / 4; ++c) *reinterpret_cast<f32x4*>(Wu + 256 * c + 4 * lane) = wu_pre[c];
+    }
     if (STAGE && tid == 0) {  // the slot mask, for the waves that did not see the ids
       Pm[0] = (int)(unsigned)pmask;
       Pm[1] = (int)(unsigned)(pmask >> 32);
@@ -573,22 +559,22 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   const int nk = L - s0;
   const int LTc = (nk + 15) >> 4;
   // ---- B: K tiles and the u tile, every slot tile in one job ------------------------------------------------------------
-  if constexpr (STAGE) {
+  {
     const int npair = (LTc + 1) >> 1;
     if (wave < NKW) {
       bool first = true;
-      for (int job = wave; job < 2 * G::NF && npair > 0; job += NKW) {
+      for (int job = wave; job < NKJ && npair > 0; job += NKW) {
         const int ft = job % G::NF, hf = job / G::NF;
         if (!first) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, ft, G::NF, lane, a.dbg & 16);
         first = false;
         if (npair > 1) fold_b_chains<DPI, 2, false>(bw, Ps, G::SI, Ks, G::SO, Ut, ft, lane, NH, 2 * hf);
         else fold_b_chains<DPI, 1, false>(bw, Ps, G::SI, Ks, G::SO, Ut, ft, lane, NH, hf);
       }
-      if (wave < NUW && npair > 0) {
+      if (wave >= U0 && wave < U0 + NUW && npair > 0) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         constexpr int KQ = DPI / 4 / FOLD_UQ;  // 16-byte feature groups per quarter
         const float* xr = Ps + lane * G::SI;
-        for (int task = wave; task < FOLD_UQ * NH; task += NUW) {
+        for (int task = wave - U0; task < FOLD_UQ * NH; task += NUW) {
           const int h = task % NH, q = task / NH;
           f32x4 xv[KQ], wv[KQ];
 #pragma unroll
@@ -604,14 +590,6 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
           Ut[task * ATT_SK + lane] = lane < 32 * npair ? acc[0] + acc[1] : 0.f;  // (task = q NH + h)
         }
       }
-    }
-  } else {
-    const int npair = (LTc + 1) >> 1;
-    bool first = true;
-    for (int job = wave; job < NFB && npair > 0; job += NW) {
-      if (!first) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, job, G::NF, lane, a.dbg & 16);
-      first = false;
-      fold_b_job<DPI>(bw, Ps, G::SI, Ks, G::SO, Ut, job, G::NF, npair, lane, NH);
     }
   }
   CF_STAMP(5);
@@ -735,10 +713,8 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
 #pragma unroll
           for (int kt = 2 * kp; kt < 2 * kp + 2; ++kt) {
             f32x4 uv = lds4(Ut + h * ATT_SK + 16 * kt + 4 * mq);
-            if constexpr (STAGE) {
 #pragma unroll
-              for (int q = 1; q < FOLD_UQ; ++q) uv = uv + lds4(Ut + (q * NH + h) * ATT_SK + 16 * kt + 4 * mq);
-            }
+            for (int q = 1; q < FOLD_UQ; ++q) uv = uv + lds4(Ut + (q * NH + h) * ATT_SK + 16 * kt + 4 * mq);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float e = __builtin_amdgcn_exp2f(sc[kt][r] - mx);
@@ -840,8 +816,8 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
 template <int DPI, int DHP, int NH, bool STAGE>
 constexpr size_t fold_lds_bytes() {
   using G = AttGeom<DPI, DHP, NH>;
-  size_t f = ATT_LMAX * G::SI + ATT_LMAX * G::SO + (STAGE ? FOLD_UQ : 1) * NH * ATT_SK + ATT_LMAX + 4 + CROSS_TPR * NH * 16;
-  if (STAGE) f += FOLD_TPR_S * G::NKG * 256 + 512 + FOLD_TPR_S * 16 + FOLD_WU_FLOATS(DPI) + (DPI <= 96 ? G::DPO * DPI : 0);
+  size_t f = ATT_LMAX * G::SI + ATT_LMAX * G::SO + FOLD_UQ * NH * ATT_SK + ATT_LMAX + 4 + CROSS_TPR * NH * 16 + FOLD_WU_FLOATS(DPI);
+  if (STAGE) f += FOLD_TPR_S * G::NKG * 256 + 512 + FOLD_TPR_S * 16 + (DPI <= 96 ? G::DPO * DPI : 0);
   return sizeof(float) * f;
 }
 
