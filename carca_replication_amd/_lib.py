@@ -282,9 +282,9 @@ SIGNATURES = {
     "carca_mark_rows": (_i, [_fp, C.c_int64, _fp, C.c_int64, _fp]),
     "carca_zero_rows": (_i, [_fp, C.c_int64, _i, C.POINTER(_fp), C.POINTER(C.c_int64), _i, _fp]),
     "carca_concat_ids": (_i, [C.POINTER(_fp), C.POINTER(C.c_int64), _i, _fp, _fp]),
-    "carca_build_eval_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,
+    "carca_build_eval_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,
                                     _fp]),
-    "carca_build_train_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,
+    "carca_build_train_batch": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_uint64, _fp, _fp, _fp, _fp, _fp,
                                      _fp]),
 }
 

@@ -75,7 +75,7 @@ struct BuildArgs {
   const int64_t* offs;     // [n_users + 1]
   const float* hctx;       // [total, n_ctx] context row of every interaction
   const int32_t* users;    // [B] user indices of this batch (into offs)
-  int B, L, N, n_ctx, n_items, held_out, floor_;
+  int B, L, N, n_ctx, n_items, held_out, floor_, n_users;
   unsigned long long seed;
   int32_t* p_x;   // [B, L]
   float* p_c;     // [B, L, n_ctx]
@@ -98,9 +98,11 @@ __global__ __launch_bounds__(256) void build_eval_kernel(const BuildArgs a) {
   const int b = blockIdx.x * 4 + wave;
   if (b >= a.B) return;
   int* acc = acc_s[wave];
-  const int u = a.users[b];
+  const int u_raw = a.users[b];
+  const bool u_ok = u_raw >= 0 && u_raw < a.n_users;  // an index outside the log reads as a user without history: an all-pad row
+  const int u = u_ok ? u_raw : 0;
   const long o0 = a.offs[u];
-  const int n = (int)(a.offs[u + 1] - o0);
+  const int n = u_ok ? (int)(a.offs[u + 1] - o0) : 0;
   const int32_t* h = a.hist + o0;
   const int T = 1 + a.N, L = a.L, nc = a.n_ctx;
   int start = 0, stop = 0;
@@ -138,9 +140,11 @@ __global__ __launch_bounds__(256) void build_train_kernel(const BuildArgs a) {
   const int b = blockIdx.x * 4 + wave;
   if (b >= a.B) return;
   int* acc = acc_s[wave];
-  const int u = a.users[b];
+  const int u_raw = a.users[b];
+  const bool u_ok = u_raw >= 0 && u_raw < a.n_users;  // an index outside the log reads as a user without history: an all-pad row
+  const int u = u_ok ? u_raw : 0;
   const long o0 = a.offs[u];
-  const int n = (int)(a.offs[u + 1] - o0);
+  const int n = u_ok ? (int)(a.offs[u + 1] - o0) : 0;
   const int32_t* h = a.hist + o0;
   const int L = a.L, nc = a.n_ctx;
   int start = 0, stop = 0;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void build_train_kernel(const BuildArgs a) {
 int check(const BuildArgs& a, const char* who, int n_out) {
   CARCA_CHECK_ARG(a.hist && a.offs && a.users && a.p_x && a.o_x && a.y_true && (a.n_ctx == 0 || (a.hctx && a.p_c && a.o_c)),
                   "%s: null pointer", who);
-  CARCA_CHECK_ARG(a.B >= 1 && a.L >= 1 && a.n_ctx >= 0 && a.n_items >= 2 && a.held_out >= 0 && a.floor_ >= 1,
+  CARCA_CHECK_ARG(a.B >= 1 && a.L >= 1 && a.n_ctx >= 0 && a.n_items >= 2 && a.held_out >= 0 && a.floor_ >= 1 && a.n_users >= 1,
                   "%s: bad dimensions", who);
   CARCA_CHECK_SUPPORTED(n_out >= 0 && n_out <= NEG_MAX, "%s: %d negatives per user > %d", who, n_out, NEG_MAX);
   return CARCA_OK;
@@ -179,10 +183,10 @@ int check(const BuildArgs& a, const char* who, int n_out) {
 }  // namespace
 
 extern "C" int carca_build_eval_batch(const int32_t* hist, const int64_t* offs, const float* hctx, const int32_t* users,
-                                      int B, int L, int N, int n_ctx, int n_items, int held_out, int floor_,
+                                      int n_users, int B, int L, int N, int n_ctx, int n_items, int held_out, int floor_,
                                       uint64_t seed, int32_t* p_x, float* p_c, int32_t* o_x, float* o_c, int32_t* y_true,
                                       void* stream_) {
-  const BuildArgs a{hist, offs, hctx, users, B, L, N, n_ctx, n_items, held_out, floor_, seed, p_x, p_c, o_x, o_c, y_true};
+  const BuildArgs a{hist, offs, hctx, users, B, L, N, n_ctx, n_items, held_out, floor_, n_users, seed, p_x, p_c, o_x, o_c, y_true};
   if (int rc = check(a, "build_eval_batch", N)) return rc;
   hipLaunchKernelGGL(build_eval_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream_, a);
   CARCA_LAUNCH_CHECK();
@@ -190,10 +194,10 @@ extern "C" int carca_build_eval_batch(const int32_t* hist, const int64_t* offs, 
 }
 
 extern "C" int carca_build_train_batch(const int32_t* hist, const int64_t* offs, const float* hctx, const int32_t* users,
-                                       int B, int L, int n_ctx, int n_items, int held_out, int floor_, uint64_t seed,
-                                       int32_t* p_x, float* p_c, int32_t* o_x, float* o_c, int32_t* y_true,
+                                       int n_users, int B, int L, int n_ctx, int n_items, int held_out, int floor_,
+                                       uint64_t seed, int32_t* p_x, float* p_c, int32_t* o_x, float* o_c, int32_t* y_true,
                                        void* stream_) {
-  const BuildArgs a{hist, offs, hctx, users, B, L, 0, n_ctx, n_items, held_out, floor_, seed, p_x, p_c, o_x, o_c, y_true};
+  const BuildArgs a{hist, offs, hctx, users, B, L, 0, n_ctx, n_items, held_out, floor_, n_users, seed, p_x, p_c, o_x, o_c, y_true};
   if (int rc = check(a, "build_train_batch", L)) return rc;
   hipLaunchKernelGGL(build_train_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream_, a);
   CARCA_LAUNCH_CHECK();

@@ -81,7 +81,7 @@ class DeviceInteractions:
         o_c = torch.empty(B, 1 + N, nc, dtype=torch.float32, device=dev)
         y = torch.empty(B, 1 + N, dtype=torch.int32, device=dev)
         _lib.check(lib.carca_build_eval_batch(self.hist.data_ptr(), self.offs.data_ptr(), self.hctx.data_ptr(),
-                                              users.data_ptr(), B, L, N, nc, self.n_items, held_out, floor,
+                                              users.data_ptr(), len(self.lens), B, L, N, nc, self.n_items, held_out, floor,
                                               int(seed) & (2 ** 64 - 1), p_x.data_ptr(), p_c.data_ptr(), o_x.data_ptr(),
                                               o_c.data_ptr(), y.data_ptr(), ops._stream()), "build_eval_batch")
         return p_x, p_c, o_x, o_c, y
@@ -98,7 +98,7 @@ class DeviceInteractions:
         o_c = torch.empty(B, 2 * L, nc, dtype=torch.float32, device=dev)
         y = torch.empty(B, 2 * L, dtype=torch.int32, device=dev)
         _lib.check(lib.carca_build_train_batch(self.hist.data_ptr(), self.offs.data_ptr(), self.hctx.data_ptr(),
-                                               users.data_ptr(), B, L, nc, self.n_items, held_out, floor,
+                                               users.data_ptr(), len(self.lens), B, L, nc, self.n_items, held_out, floor,
                                                int(seed) & (2 ** 64 - 1), p_x.data_ptr(), p_c.data_ptr(),
                                                o_x.data_ptr(), o_c.data_ptr(), y.data_ptr(), ops._stream()),
                    "build_train_batch")

@@ -520,12 +520,13 @@ int carca_concat_ids(const int32_t* const* ids /*host [nlists]*/, const int64_t*
  *   candidate, y_true [B,1+N] = one-hot at column 0.  N <= 2048.
  * carca_build_train_batch = get_train_sequences (data.py:90-137): o_x [B,2L] = successors | negatives aligned with the
  *   history slots, o_c [B,2L,n_ctx] = the successor's context for both, y_true [B,2L] = (p_x > 0) | 0.
- * Attribute rows are NOT materialised: AllEmbedding.register_attr_table gathers them inside the feature GEMM. */
-int carca_build_eval_batch(const int32_t* hist, const int64_t* offs, const float* hctx, const int32_t* users, int B, int L,
-                           int N, int n_ctx, int n_items, int held_out, int floor_, uint64_t seed, int32_t* p_x,
+ * Attribute rows are NOT materialised: AllEmbedding.register_attr_table gathers them inside the feature GEMM.
+ * offs has n_users + 1 entries; a user index outside [0, n_users) yields an all-pad row (no history, no candidates). */
+int carca_build_eval_batch(const int32_t* hist, const int64_t* offs, const float* hctx, const int32_t* users, int n_users,
+                           int B, int L, int N, int n_ctx, int n_items, int held_out, int floor_, uint64_t seed, int32_t* p_x,
                            float* p_c, int32_t* o_x, float* o_c, int32_t* y_true, void* stream);
-int carca_build_train_batch(const int32_t* hist, const int64_t* offs, const float* hctx, const int32_t* users, int B,
-                            int L, int n_ctx, int n_items, int held_out, int floor_, uint64_t seed, int32_t* p_x,
+int carca_build_train_batch(const int32_t* hist, const int64_t* offs, const float* hctx, const int32_t* users, int n_users,
+                            int B, int L, int n_ctx, int n_items, int held_out, int floor_, uint64_t seed, int32_t* p_x,
                             float* p_c, int32_t* o_x, float* o_c, int32_t* y_true, void* stream);
 
 /* ---- a7: CARCA.forward (carca.py:411-431), inference path, as ONE host call -----------------------------

@@ -135,3 +135,24 @@ def test_too_few_items_for_the_negatives_is_an_error():
     log = DeviceInteractions(profiles, ctx, 12)
     with pytest.raises(CarcaHipError):
         log.eval_batch(log.valid_users("test"), 4, 5, "test")
+
+
+def test_user_indices_outside_the_log_give_all_pad_rows():
+    """carca_build_*_batch takes the number of users of the log: an index outside [0, n_users) is a user without history
+    (all-pad profile, no candidates) instead of an out-of-bounds read of the CSR offsets."""
+    from carca_replication_amd.device_data import DeviceInteractions
+
+    profiles, ctx, attrs = _log(n_users=6, n_items=60, seed=4)
+    L, N = 5, 7
+    log = DeviceInteractions(profiles, ctx, attrs.shape[0])
+    good = log.valid_users("test")[:2]
+    users = torch.cat([good[:1], torch.tensor([-3, 6, 10 ** 6], dtype=torch.int32, device=good.device), good[1:2]])
+    p_x, p_c, o_x, o_c, y = log.eval_batch(users, L, N, "test", seed=1)
+    ref = log.eval_batch(good, L, N, "test", seed=1)
+    for got, want in zip((p_x, p_c, o_x, o_c, y), ref):
+        assert torch.equal(got[[0, 4]], want)          # the real users' rows are what they are without the strangers
+        assert int(got[1:4].abs().sum()) == 0          # the strangers: zeros everywhere
+    t = log.train_batch(users, L, seed=1)
+    tref = log.train_batch(good, L, seed=1)
+    for got, want in zip(t, tref):
+        assert torch.equal(got[[0, 4]], want) and int(got[1:4].abs().sum()) == 0

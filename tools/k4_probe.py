@@ -92,7 +92,10 @@ NAMES = ["start", "ids in", "A barrier passed", "B done", "end", "wave 0: B work
 if os.environ.get("STAMPS", "1") != "0":
     for dbg in [int(x) for x in os.environ.get("DBG", "0,2,4,16,22").split(",")]:
         lib.carca_set_tuning(5, dbg)
-        for B, lengths in ((128, "full"), (1024, "full")) if dbg else ((128, "full"), (128, "uniform"), (1024, "full")):
+        cases = ((128, "full"), (1024, "full")) if dbg else ((128, "full"), (128, "uniform"), (1024, "full"))
+        if os.environ.get("STAMP_BS"):
+            cases = tuple((int(b), "full") for b in os.environ["STAMP_BS"].split(","))
+        for B, lengths in cases:
             a = inputs(B, lengths)
             for _ in range(5):
                 run(*a, False, True)
