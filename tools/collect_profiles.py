@@ -1,5 +1,5 @@
 """Copy one round's rocprofv3 summaries from gpurun_out/ (scratch) into profiles/ (tracked):
-  python tools/collect_profiles.py r02_d [--attn r02_d_attn] [--train]
+  python tools/collect_profiles.py r02_e [--attn r02_d_attn] [--train]
 Keeps what profiles/README.md lists: kernel stats, per-grid split, the three PMC passes filtered to the feature-GEMM
 kernel, the traffic JSON, both bench lines; with --attn the K2/K4 PMC summary and their kernel stats; with --train the
 train-step kernel stats of tools/train_trace.sh."""
