@@ -35,7 +35,13 @@ struct WgradCuDev {
   int chunk_start[CARCA_MAX_SEGS + 1];
   unsigned y_bytes[CARCA_MAX_SEGS], x_bytes[CARCA_MAX_SEGS], x1_bytes[CARCA_MAX_SEGS];  // buffer extents
   const unsigned* tab;  // [3][V]: byte offsets of dY / X / X1 rows inside their segment, V = 32 * chunks
-  int V, nnb, nkb, per;
+  int V, nnb, nkb;
+  // stream-K ranges in units of 1/256 item: items of the k block that also carries the second k-source (the LAST k block:
+  // k blocks are the outermost index) weigh slow_w / 256 -- its chunks run ~5 % longer (one more load per lane), and with
+  // equal item counts the workgroups that sit entirely inside it finished 5.4 % behind the rest (measured, C2: block times
+  // 1.134 .. 1.417 M cycles; 1.295 .. 1.364 M with a weight of 270 / 256, those workgroups then 2 % early: 264)
+  long per_w, n_fast;
+  int slow_w;
   int src1_kb;  // k block that also carries the second k-source's columns, or -1
   unsigned long long* dbg;    // phase stamps of a diagnostic run (tuning variant 3)
 };
@@ -91,7 +97,12 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
   const int lr = lane & 31, lh = lane >> 5;
   const int nchunks = args.chunk_start[D.nseg];
   const long total = (long)args.nnb * args.nkb * nchunks;
-  const long w_begin = (long)blockIdx.x * args.per, w_end = min(total, w_begin + args.per);
+  auto item_at = [&](long wt) -> long {  // weight units -> item index (monotonic: consecutive blocks tile [0, total))
+    const long fast_w = args.n_fast * 256;
+    return wt <= fast_w ? wt / 256 : args.n_fast + (wt - fast_w) / args.slow_w;
+  };
+  const long w_begin = min(total, item_at((long)blockIdx.x * args.per_w));
+  const long w_end = blockIdx.x + 1 == gridDim.x ? total : min(total, item_at((long)(blockIdx.x + 1) * args.per_w));
 
   // staging slots of this thread: dY (row tid / 24, float4 tid % 24), X rows tid / 96 + 8 i, float4 tid % 96
   const int y_r = tid / 24, y_c4 = tid - y_r * 24;
@@ -378,8 +389,12 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   // (24 chunk-tiles per CU: the d x F product of the re-associated embedding backward, 26 per CU at C2, runs 2x faster
   // here than on the tile kernel; the joint-embedding dW, 5 per CU, does not)
   if (!forced && (total < (long)g_num_cus * 24 || chunks < 8)) return 1;
-  g.per = (int)((total + g_num_cus - 1) / g_num_cus);
-  const int grid = (int)((total + g.per - 1) / g.per);
+  const long n_slow = (desc->K1 > 0 && g.src1_kb >= 0 && g.src1_kb == g.nkb - 1) ? (long)g.nnb * chunks : 0;
+  g.n_fast = total - n_slow;
+  g.slow_w = carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 13 ? 256 : 264;  // (variant 13: equal item counts -- A/B switch)
+  const long total_w = g.n_fast * 256 + n_slow * g.slow_w;
+  g.per_w = (total_w + g_num_cus - 1) / g_num_cus;
+  const int grid = (int)((total_w + g.per_w - 1) / g.per_w);
   g.V = chunks * WG_BR;
   if (!g_tab_init) {
     for (int i = 0; i < TAB_RING; ++i) (void)hipEventCreateWithFlags(&g_tab_ev[i], hipEventDisableTiming);

@@ -37,3 +37,9 @@ print("whole kernel: mean %.0f cycles; loop %.0f (%.0f per chunk, ideal 9216); v
 print("per-wave-slot barrier wait/chunk:", [round(float(r[:, w, 3].mean() / steps)) for w in range(nw)])
 print("per-wave-slot vmcnt wait/chunk:", [round(float(r[:, w, 2].mean() / steps)) for w in range(nw)])
 print("blocks: kernel cycles min %.0f max %.0f" % (r[:, 0, 0].min(), r[:, 0, 0].max()))
+kc = r[:, 0, 0]
+order = torch.argsort(kc)
+print("kernel cycles by block id (sorted): fastest", [(int(i), int(kc[i])) for i in order[:8]], " slowest", [(int(i), int(kc[i])) for i in order[-8:]])
+print("mean by block id mod 8 (XCD):", [int(kc[x::8].mean()) for x in range(8)])
+print("mean by block id // 32:", [int(kc[32 * x: 32 * x + 32].mean()) for x in range(8)])
+print("loop cycles by block: min %.0f mean %.0f max %.0f" % (r[:, 0, 1].min(), r[:, 0, 1].mean(), r[:, 0, 1].max()))
