@@ -425,6 +425,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   constexpr int U0 = NKJ % NKW;                                    // first wave with the lighter K load
   constexpr int NUW = (NKW - U0) < 8 ? (NKW - U0) : 8;             // waves that take u tasks
   constexpr int WUW = STAGE ? NKW : NW - 1;                        // the wave that stages wu
+  constexpr int PREF_B = STAGE ? G::NF : NKJ;                      // waves whose first half job's weights are prefetched
   static_assert(NH <= 4, "the weight image of u holds four heads");
   static_assert(DPI / 4 % FOLD_UQ == 0, "feature quarters");
   const int half = lane >> 5, c4 = lane & 31;
@@ -471,7 +472,9 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     const f32x4 lnb = gload4(a.ln_w ? a.ln_b : a.bq, col_ok ? 4 * c4 : 0);
     // this wave's phase B job (feature tile `wave`) gets its weight fragments now
     f32x4 wu_pre[(G::NKG + 3) / 4];
-    if (wave < NKW && wave < NKJ) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, wave % G::NF, G::NF, lane, a.dbg & 16);
+    // (only the first round of half jobs prefetches in the front: the second half's waves fetch behind the A barrier, under
+    // the first half's MFMAs -- every load issued here lengthens the front by its 1 KB on the return path)
+    if (wave < NKW && wave < PREF_B) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, wave % G::NF, G::NF, lane, a.dbg & 16);
     if (wave == WUW) {  // lane (kg' = lane >> 4, mq = (lane >> 2) & 3, h = lane & 3): wu[h][16 kg + 4 mq ..] out of the fragment order
 #pragma unroll
       for (int c = 0; c < (G::NKG + 3) / 4; ++c)
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   {
     const int npair = (LTc + 1) >> 1;
     if (wave < NKW) {
-      bool first = true;
+      bool first = wave < PREF_B;
       for (int job = wave; job < NKJ && npair > 0; job += NKW) {
         const int ft = job % G::NF, hf = job / G::NF;
         if (!first) fold_b_load<DPI>(bw, a.wk, a.bk, a.wu, a.cu, ft, G::NF, lane, a.dbg & 16);
