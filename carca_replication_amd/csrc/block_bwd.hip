@@ -90,6 +90,27 @@ extern "C" int carca_sa_block_bwd(const CarcaSaBwdDesc* D, CarcaWgradDesc* wgrad
   float* dkh = ws;                          ws += (size_t)rows * dpo;
   float* dvh = ws;
   int rc;
+  // Without dropout the two row chains run as ONE launch each (row_chain.hip) around the attention core: 3 launches per
+  // block instead of 6 (tuning key 6 = 1 or 2: the launch-per-step path below).
+  if (!drop && dpi == dpo && dpi <= 96 && carca_tuning(6) == 0) {  // (dpi = 128: 16 waves leave 128 registers, the chain kernel would spill)
+    if ((rc = carca_sa_ffn_chain_bwd(D->dy, D->h1, D->r, D->w2_t, D->w1_t, D->ln2_w, rows, d, dpi, D->residual, dh1pre, dr,
+                                     D->g_ln2_w, D->g_ln2_b, stream)))
+      return rc;
+    if ((rc = carca_sa_attn_bwd(D->qh, D->kh, D->vh, dr, dpi, D->ids, dqh, dkh, dvh, D->B, D->L, d, D->H, nullptr, 1.0f,
+                                stream)))
+      return rc;
+    if ((rc = carca_sa_input_chain_bwd(dqh, dkh, dvh, dr, D->x_in, D->wq_t, D->wk_t, D->wv_t, D->ln1_w, rows, d, dpi,
+                                       D->residual, D->dx, D->g_ln1_w, D->g_ln1_b, stream)))
+      return rc;
+    CarcaWgradDesc* w = wgrads + *n_wgrads;
+    w[0] = wgrad_product(D->dy, dpi, D->h1, dpi, rows, d, d, D->g_w2, d, D->g_b2);     // d ffn_2
+    w[1] = wgrad_product(dh1pre, dpi, D->s2, dpi, rows, d, d, D->g_w1, d, D->g_b1);   // d ffn_1
+    w[2] = wgrad_product(dqh, dpo, D->qn, dpi, rows, dpo, d, D->g_wq, d, D->g_bq);    // d W_Q (head-padded staging)
+    w[3] = wgrad_product(dkh, dpo, D->x_in, dpi, rows, dpo, d, D->g_wk, d, D->g_bk);  // d W_K
+    w[4] = wgrad_product(dvh, dpo, D->x_in, dpi, rows, dpo, d, D->g_wv, d, D->g_bv);  // d W_V
+    *n_wgrads += 5;
+    return CARCA_OK;
+  }
   // f = dropout2(ffn_2(dropout1(lrelu(ffn_1(s))))) (+ s): the f branch sees dy * mask2 / (1 - p)   (carca.py:305-316)
   const float* dyf_c = D->dy;
   if (drop) {

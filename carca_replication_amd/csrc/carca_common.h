@@ -180,6 +180,13 @@ int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* 
 // carca_embed_scatter over several row segments in one launch (backward.hip)
 int carca_embed_scatter_segs(const float* const* dz, int ld_dz, const int32_t* const* ids, const int* rows, int nseg,
                              int d, float scale, float* d_items, void* stream);
+// fused row chains of the SelfAttentionBlock backward (row_chain.hip)
+int carca_sa_ffn_chain_bwd(const float* dy, const float* h1, const float* r, const float* w2_t, const float* w1_t,
+                           const float* ln2_w, int rows, int d, int dpi, int residual, float* dh1pre, float* dr,
+                           float* g_ln2_w, float* g_ln2_b, void* stream);
+int carca_sa_input_chain_bwd(const float* dqh, const float* dkh, const float* dvh, const float* dr, const float* x_in,
+                             const float* wq_t, const float* wk_t, const float* wv_t, const float* ln1_w, int rows, int d,
+                             int dpi, int residual, float* dx, float* g_ln1_w, float* g_ln1_b, void* stream);
 unsigned long long* carca_debug_buffer();  // device buffer for in-kernel phase stamps (diagnostic runs), or null
 #define CARCA_CHECK_ARG(cond, ...)            \
   do {                                        \
