@@ -82,13 +82,16 @@ __global__ __launch_bounds__(DPI / 16 * 2 * 64) void row_chain_bwd_kernel(const 
       *reinterpret_cast<f32x4*>(&As[t][r * LS + 4 * c4]) = row0 + r < a.rows ? st[t][j] : zero4();
     }
   // C (2 row tiles x this wave's column tile) = A[slot] Bt^T
-  // (the weight fragments -- Bt row = this lane's output column -- are requested where the product starts: all of them at
-  // the kernel's start, beside the tiles and the per-element operands, measured 10 % slower; 32-row workgroups, i.e.
-  // twice the weight traffic, 20 % slower: every wave re-reads its column tile's 6 KB per matrix out of the L2)
-  auto gemm = [&](int slot, const float* bt, f32x4 (&acc)[2]) {
-    f32x4 wf[NKG];
+  // (the weight fragments -- Bt row = this lane's output column -- are requested ONE product ahead: all of them at the
+  // kernel's start, beside the tiles and the per-element operands, measured 10 % slower; 32-row workgroups, i.e. twice
+  // the weight traffic, 20 % slower: every wave re-reads its column tile's 6 KB per matrix out of the L2)
+  auto load_w = [&](const float* bt, f32x4 (&wf)[NKG]) {
 #pragma unroll
     for (int kg = 0; kg < NKG; ++kg) wf[kg] = gload4(bt, nn * ld + 16 * kg + 4 * mq);
+  };
+  f32x4 wfA[NKG], wfB[NKG];
+  load_w(a.w0, wfA);
+  auto gemm = [&](int slot, const f32x4 (&wf)[NKG], f32x4 (&acc)[2]) {
     const float* a0p = &As[slot][(16 * (2 * rh) + ln) * LS + 4 * mq];
 #pragma unroll
     for (int kg = 0; kg < NKG; ++kg) {
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(DPI / 16 * 2 * 64) void row_chain_bwd_kernel(const 
   f32x4 t2[2] = {zero4(), zero4()}, u[2] = {zero4(), zero4()};
   if constexpr (MODE == 0) {
     f32x4 t1[2] = {zero4(), zero4()};
-    gemm(0, a.w0, t1);
+    gemm(0, wfA, t1);
+    load_w(a.w1, wfB);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -114,16 +118,27 @@ __global__ __launch_bounds__(DPI / 16 * 2 * 64) void row_chain_bwd_kernel(const 
         // LeakyReLU'(h1): slope 0.01 at and below 0 (no dropout on this path)
         const float v = n_ok ? t1[i][r] * (gv[i][r] > 0.f ? 1.0f : 0.01f) : 0.f;
         As[1][lrow * LS + n] = v;
-        if (row0 + lrow < a.rows) a.out1[(size_t)(row0 + lrow) * ld + n] = v;
+        t1[i][r] = v;
       }
     RC_STAMP(2);
     __syncthreads();
     RC_STAMP(3);
-    gemm(1, a.w1, t2);
+    gemm(1, wfB, t2);
+    // dh1pre goes to memory only now: vmcnt retires in order, so a store issued before the product's last wait on its
+    // weight fragments made that wait a wait for the stores (measured: the product took 14 k cycles instead of 6 k)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = 16 * (2 * rh + i) + 4 * mq + r;
+        if (row0 + lrow < a.rows) a.out1[(size_t)(row0 + lrow) * ld + n] = t1[i][r];
+      }
   } else {
-    gemm(0, a.w0, t2);
-    gemm(1, a.w1, u);
-    gemm(2, a.w2, u);
+    load_w(a.w1, wfB);
+    gemm(0, wfA, t2);
+    load_w(a.w2, wfA);
+    gemm(1, wfB, u);
+    gemm(2, wfA, u);
   }
   RC_STAMP(4);
   // ---- LayerNorm backward of t2 (+ add) against x, plus u -------------------------------------------------------------
