@@ -306,6 +306,13 @@ class _CarcaFn(torch.autograd.Function):
             dpi_b = ops.padded_dims(d, blk.attn.H)[0]
             bpks.append(plan.add_attn(blk.attn, [ops.PackItem(blk.ffn_1.weight[:, :, 0], dpi_b, dpi_b, transposed=True),
                                                  ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi_b, dpi_b, transposed=True)]))
+        # the embedding's own transposed copy (joint_embed^T for d [z ; q]) rides in the same pack launch
+        emb_wt_idx = None
+        if hasattr(emb, "backward_pack_items") and not isinstance(st["emb_saved"], str):
+            items = emb.backward_pack_items(dpi)
+            if items:
+                emb_wt_idx = len(plan.fw)
+                plan.fw += items
         # (every id a scatter-add of this pass can touch: known for the embeddings with an item table)
         id_lists = [sg[0] for sg in st["segs"]] if hasattr(emb, "items_embed") and len(st["segs"]) <= 4 else None
         late = emb.late_grad_params(st["emb_saved"]) if hasattr(emb, "late_grad_params") else ()
@@ -354,7 +361,10 @@ class _CarcaFn(torch.autograd.Function):
         des = [dx] + des_t                      # d e per segment, [rows, dpi]; profile rows still unmasked
         wg.launch()
         plan.unpack(gbp)  # head-padded staging areas -> the real WQ / WK / WV / ffn gradients
-        emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi)
+        if emb_wt_idx is not None:
+            emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi, wj_t=plan.wT.view(emb_wt_idx))
+        else:
+            emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi)
         after_pass()
         ctx.st = None
         return (None, None, None) + tuple(grads)

@@ -322,7 +322,12 @@ class AllEmbedding(Embedding):
         the others so that a sharded step can reduce everything else under that launch)."""
         return () if isinstance(saved, str) else (self.feats_embed.weight, self.feats_embed.bias)
 
-    def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int) -> None:
+    def backward_pack_items(self, dpi: int):
+        """The transposed weight copy embed_backward needs (Bt[n = input feature of joint_embed][k = output feature]): the
+        backward pass packs it in ITS pack launch and hands the view back as embed_backward(..., wj_t=)."""
+        return [ops.PackItem(self.joint_embed.weight, self.d + self.feats_embed.weight.shape[0], dpi, transposed=True)]
+
+    def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int, wj_t=None) -> None:
         """Backward of embed_segments (carca.py:85-95): des[i] = d e of segment i, [rows, dpi], NOT yet masked;
         accumulates into the gradient buffers gbp[id(param)].  One host call (carca_embed_bwd): position-encoding
         gradient, d joint_embed, d [z ; q], item-row scatter-add, d feats_embed."""
@@ -333,14 +338,16 @@ class AllEmbedding(Embedding):
         table = self.attr_table()
         n_attrs = table.shape[1] if table is not None else segs[0][1].shape[-1]
         n_ctx = segs[0][2].shape[-1]
-        wj_t = self.__dict__.get("_wj_t")  # Bt[n = input feature of joint_embed][k = output feature]: repacked every step
-        if wj_t is None or wj_t.buf.device != des[0].device or wj_t.items[0].dst_cols != dpi:
-            wj_t = ops.PackedWeights([ops.PackItem(self.joint_embed.weight, d + g_feats, dpi, transposed=True)], des[0].device)
-            self.__dict__["_wj_t"] = wj_t
-        wj_t.items[0].src = self.joint_embed.weight
-        wj_t.pack()
+        if wj_t is None:  # (a caller without a pack plan: own copy, own launch)
+            pw = self.__dict__.get("_wj_t")  # Bt[n = input feature of joint_embed][k = output feature]: repacked every step
+            if pw is None or pw.buf.device != des[0].device or pw.items[0].dst_cols != dpi:
+                pw = ops.PackedWeights(self.backward_pack_items(dpi), des[0].device)
+                self.__dict__["_wj_t"] = pw
+            pw.items[0].src = self.joint_embed.weight
+            pw.pack()
+            wj_t = pw.view(0)
         enc_w = self.enc.encoding.weight if hasattr(self.enc, "encoding") else None
-        ops.embed_bwd(des, segs, zq, wj_t.view(0),
+        ops.embed_bwd(des, segs, zq, wj_t,
                       dict(g_items=gbp[id(self.items_embed.weight)], g_feats_w=gbp[id(self.feats_embed.weight)],
                            g_feats_b=gbp[id(self.feats_embed.bias)], g_joint_w=gbp[id(self.joint_embed.weight)],
                            g_joint_b=gbp[id(self.joint_embed.bias)]),
