@@ -84,7 +84,9 @@ __global__ __launch_bounds__(DPI / 16 * 2 * 64) void row_chain_bwd_kernel(const 
   // C (2 row tiles x this wave's column tile) = A[slot] Bt^T
   // (the weight fragments -- Bt row = this lane's output column -- are requested ONE product ahead: all of them at the
   // kernel's start, beside the tiles and the per-element operands, measured 10 % slower; 32-row workgroups, i.e. twice
-  // the weight traffic, 20 % slower: every wave re-reads its column tile's 6 KB per matrix out of the L2)
+  // the weight traffic, 20 % slower: every wave re-reads its column tile's 6 KB per matrix out of the L2 -- but 32-row
+  // workgroups with the matrices staged ONCE per workgroup in LDS, i.e. the same traffic on twice the CUs, were slower too:
+  // 28.5 against 24.5 us, so it is not the weight traffic)
   auto load_w = [&](const float* bt, f32x4 (&wf)[NKG]) {
 #pragma unroll
     for (int kg = 0; kg < NKG; ++kg) wf[kg] = gload4(bt, nn * ld + 16 * kg + 4 * mq);
