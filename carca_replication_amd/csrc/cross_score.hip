@@ -318,8 +318,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
   float* Ks = Ps + ATT_LMAX * G::SI;  // [64][SO]
   float* Ut = Ks + ATT_LMAX * G::SO;  // [FOLD_UQ][NH][ATT_SK]  u^T as partial sums over quarters of the features
   float* Km = Ut + FOLD_UQ * NH * ATT_SK;  // [64] additive key mask: 0 real key, FOLD_NEG pad / beyond the profile; then the slot mask (2 words)
-  int* Cnt = reinterpret_cast<int*>(Km + ATT_LMAX + 4);  // [2][8] heads done per target tile, a set per round parity
-  float* Yp = Km + ATT_LMAX + 4 + 16;  // [CROSS_TPR][NH][16] per-head partial logits
+  float* Yp = Km + ATT_LMAX + 4;      // [CROSS_TPR][NH][16] per-head partial logits
   float* Wu = Yp + CROSS_TPR * NH * 16;               // wu as [k group of 4][head (4)][4]: the u tasks' broadcast reads
   float* Ot = Wu + FOLD_WU_FLOATS(DPI);               // STAGE: [TPR][NKG][64 lanes x 4] target tiles, fragment order
   float* Bq = Ot + FOLD_TPR_S * G::NKG * 256;         // STAGE: b_Q [DPO], then decoder.ffn.weight [DPI]
@@ -536,7 +535,6 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
     for (int t = nk + 2 * wave + half; t < min(ATT_LMAX, 32 * ((LTc + 1) >> 1)); t += 2 * NLN)
       if (col_ok) *reinterpret_cast<f32x4*>(Ps + t * G::SI + 4 * c4) = zero4();
     if (wave == NLN - 1) Km[lane] = (lane < nk && ((pmask >> (lane + s0)) & 1ull)) ? 0.f : FOLD_NEG;
-    if (wave == 0 && lane < 16) Cnt[lane] = 0;
     if (wave == WUW) {
 #pragma unroll
       for (int c = 0; c < (G::NKG + 3) / 4; ++c) *reinterpret_cast<f32x4*>(Wu + 256 * c + 4 * lane) = wu_pre[c];
@@ -605,11 +603,8 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
 
   // ---- C: rounds of TPR target tiles; job = (tile, head) ----------------------------------------------------------------
   const float ffn_b = a.ffn_b[0];
-  int round = 0;
-  for (int t0 = t_lo; t0 < t_hi; t0 += TPR, ++round) {
+  for (int t0 = t_lo; t0 < t_hi; t0 += TPR) {
     const int nt = min(TPR, t_hi - t0);
-    int* const cnt = Cnt + 8 * (round & 1);
-    if (round > 0 && tid < 8) Cnt[8 * ((round + 1) & 1) + tid] = 0;  // (the set of round - 1: its last user passed the barrier below)
     if (STAGE && t0 != t_lo) {  // (the first round's tiles were requested in the prologue)
       stage_tiles(t0, nt);
       const int id = load_tile_id(t0, nt);
@@ -737,19 +732,6 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
       // a target with no allowed key (pad target, first slot when training, all-pad profile) attends nothing: exact 0
       const float attn = (q_ok && mx > 0.5f * FOLD_NEG) ? dot / sum : 0.f;
       if (mq == 0) Yp[(c.tl * NH + h) * 16 + ln] = attn + ypart;
-      // The head that finishes a target tile LAST adds the heads up (fixed order) and writes the probabilities: no
-      // workgroup barrier and no separate pass behind the jobs.
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      int done = 0;
-      if (lane == 0) done = atomicAdd(&cnt[c.tl], 1);
-      done = __builtin_amdgcn_readfirstlane(done);
-      if (done == NH - 1 && mq == 0 && c.in_range) {
-        float logit = ffn_b;
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) logit += Yp[(c.tl * NH + hh) * 16 + ln];
-        const int ldy = a.g[c.gi].ldy ? a.g[c.gi].ldy : a.g[c.gi].N;
-        a.g[c.gi].y[(size_t)u * ldy + c.n] = 1.0f / (1.0f + expf(-logit));
-      }
       CF_STAMP(10);
     };
     constexpr bool PIPE = !STAGE && G::NFH * G::NKG <= 16;
@@ -815,7 +797,19 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
         run_job(c, qfrag, nullptr, nullptr, STAGE ? Ids[c.tl * 16 + ln] : c.ids[c.lrow], []() {});
       }
     }
+    __syncthreads();
     CF_STAMP(11);
+    if (tid < nt * 16) {
+      const int tl = tid >> 4, l16 = tid & 15;
+      const Grp g = group_of(t0 + tl);
+      const int n = 16 * (t0 + tl - g.ts) + l16;
+      if (n < g.N) {
+        float logit = ffn_b;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) logit += Yp[(tl * NH + h) * 16 + l16];
+        g.y[(size_t)u * g.ldy + n] = 1.0f / (1.0f + expf(-logit));
+      }
+    }
     if (t0 + TPR < t_hi) __syncthreads();
   }
   CF_STAMP(4);
@@ -825,7 +819,7 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_fold_kernel(const FoldArgs a
 template <int DPI, int DHP, int NH, bool STAGE>
 constexpr size_t fold_lds_bytes() {
   using G = AttGeom<DPI, DHP, NH>;
-  size_t f = ATT_LMAX * G::SI + ATT_LMAX * G::SO + FOLD_UQ * NH * ATT_SK + ATT_LMAX + 4 + 16 + CROSS_TPR * NH * 16 + FOLD_WU_FLOATS(DPI);
+  size_t f = ATT_LMAX * G::SI + ATT_LMAX * G::SO + FOLD_UQ * NH * ATT_SK + ATT_LMAX + 4 + CROSS_TPR * NH * 16 + FOLD_WU_FLOATS(DPI);
   if (STAGE) f += FOLD_TPR_S * G::NKG * 256 + 512 + FOLD_TPR_S * 16 + (DPI <= 96 ? G::DPO * DPI : 0);
   return sizeof(float) * f;
 }
