@@ -165,6 +165,58 @@ def measure_train(c, model, rank, world, device, steps, fold=False, graphed=Fals
             "last_loss": float(loss)}
 
 
+def measure_scoring_scaling(c, model, device, batches=(1024, 4096), reps=30):
+    """The scoring kernel (final norm + CrossAttentionBlock, eval mode) ALONE at batch sizes where several users share a
+    CU -- above #CUs users the library runs it as persistent workgroups that pipeline their users (csrc/cross_stream.hip).
+    Untimed side pass: `reps` back-to-back launches between two events (launch gaps included), synthetic encoder outputs /
+    embedded targets of the C2 shape, profile lengths as BASELINE.md draws them (U{3..L}, left-padded) and, beside it,
+    every profile full.  Fraction = SURVEY 8d's algorithmic CA flops per user x users / time / fp32 MFMA peak."""
+    import torch
+
+    from carca_replication_amd import ops
+
+    L, N, d, H = c["L"], c["N"], c["d"], c["H"]
+    dpi, _, _ = ops.padded_dims(d, H)
+    cw = model.decoder.weights_struct(device, model.norm)
+    ca = flops_per_user(c)["ca"]
+    out = {}
+    for B in batches:
+        gen = torch.Generator(device=device).manual_seed(B)
+        x = torch.zeros(B, L, dpi, device=device)
+        x[..., :d] = torch.randn(B, L, d, device=device, generator=gen)
+        o = torch.zeros(B, N, dpi, device=device)
+        o[..., :d] = torch.randn(B, N, d, device=device, generator=gen)
+        o_ids = torch.randint(1, 5, (B, N), device=device, dtype=torch.int32, generator=gen)
+        res = {}
+        for name in ("baseline_lengths", "full_profiles"):
+            ln = (torch.randint(3, L + 1, (B,), device=device, generator=gen) if name == "baseline_lengths"
+                  else torch.full((B,), L, device=device))
+            p_ids = ((torch.arange(L, device=device)[None, :] >= (L - ln)[:, None]).int() * 7).contiguous()
+            run = lambda: ops.cross_score_fwd(x, p_ids, [(o, o_ids)], cw, d, H, True, False)  # noqa: E731
+            for _ in range(8):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = e0.elapsed_time(e1) / reps
+        tf = B * ca / (res["baseline_lengths"] * 1e-3) / 1e12
+        tf_full = B * ca / (res["full_profiles"] * 1e-3) / 1e12
+        out[B] = {"kernel": "cross_stream_kernel<96,32,3> (final norm + CrossAttentionBlock, eval mode; persistent 16-wave "
+                            "workgroups, W_Q / W_K resident in LDS, one barrier per user)",
+                  "users": B, "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                  "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_ms": res["baseline_lengths"],
+                  "frac_full_profiles": tf_full / PEAK_F32_MFMA_TFLOPS, "avg_ms_full_profiles": res["full_profiles"],
+                  "algorithmic_gflop_per_launch": B * ca / 1e9, "launches_timed": reps,
+                  "timing": "side pass, untimed by the headline: back-to-back launches of the kernel alone between two "
+                            "events (launch gaps included); `frac` at BASELINE.md's profile lengths U{3..50}, "
+                            "`frac_full_profiles` with every profile at L = 50"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +227,7 @@ def main():
     ap.add_argument("--no-fold", action="store_true", help="skip the folded-embedding (composed weights) measurement")
     ap.add_argument("--no-table", action="store_true", help="skip the attribute-table (ids-only batch) measurement")
     ap.add_argument("--train-steps", type=int, default=24, help="extra, untimed-by-the-headline train-step measurement")
+    ap.add_argument("--no-scoring-scaling", action="store_true", help="skip the scoring kernel's B = 1024 / 4096 side pass")
     args = ap.parse_args()
 
     # The box exposes every host core but the cgroup grants only a share of them: torch's default intra-op pool
@@ -331,6 +384,8 @@ def main():
                      "what": "CARCA.fold_embedding(True): e = z W_jz^T + [a;c] (W_jq W_f)^T + const, one F->d GEMM instead of "
                              "F->g->d; executed flops per user 5x lower in the embedding, algorithmic flops unchanged"}
 
+    scoring_scaling = measure_scoring_scaling(c, model, device) if (rank == 0 and not args.no_scoring_scaling) else {}
+
     train_info = train_graph_info = train_fold_info = train_fold_graph_info = None
     if args.train_steps > 0:
         train_info = measure_train(c, model, rank, world, device, args.train_steps)
@@ -428,6 +483,8 @@ def main():
                                     "timing": "pass behind the timed region, as roofline_cross_score",
                                     "algorithmic_gflop_per_launch": joint_flops / 1e9},
         }
+        for bsz, info in scoring_scaling.items():
+            out["roofline_cross_score_b%d" % bsz] = info
         if train_info is not None:
             out["train"] = train_info
         if train_graph_info is not None:

@@ -12,6 +12,7 @@
 //            sigmoid(w.o + b) (carca.py:339).  Pad targets (id 0) attend nothing.
 #include <hip/hip_ext.h>
 #include "attn_common.h"
+#include "cross_fold.h"
 #include "../../include/carca_hip.h"
 
 namespace {
@@ -217,27 +218,6 @@ __global__ __launch_bounds__(NW * 64, 4) void cross_score_kernel_w16(const float
 //   * masks are ADDED: the score accumulators start from 0 / -1e30 per key (an LDS vector), so the exp2 of a masked
 //     score is an exact 0 without a select per score; rows with no allowed key are zeroed by one select.
 //   * the first job's target rows are requested before phase A, its W_Q fragments before the barrier ahead of phase C.
-struct FoldArgs {
-  const float* p_raw;
-  const int32_t* p_ids;
-  float* p_normed;
-  CarcaTargetGroup g[CARCA_MAX_GROUPS];
-  int tile_start[CARCA_MAX_GROUPS + 1];
-  int ngroups, ldp, ldo, L, d, residual, nparts;
-  const float *ln_w, *ln_b, *wq, *bq, *wk, *bk, *wu, *cu, *ffn_w, *ffn_b;
-  float qscale;  // log2(e) / sqrt(dh): scores leave the Q projection in the exp2 domain
-  int dbg;       // timing experiments (tuning key 5; wrong results): bit 1 no W_Q traffic, 2 no tile traffic, 3 no LayerNorm,
-                 // 4 no W_K traffic
-  unsigned long long* stamps;
-};
-#define FOLD_NEG (-1.0e30f)
-
-// LDS-DMA: 64 lanes x 16 B from per-lane global offsets into 1 KB of LDS at lds_dst + 16 * lane (no registers)
-__device__ __forceinline__ void dma16(const float* base, int lane_elem_off, int uniform_elem_off, float* lds_dst) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(carca_rsrc(base), (__attribute__((address_space(3))) void*)lds_dst, 16,
-                                           lane_elem_off * 4, uniform_elem_off * 4, 0, 0);
-}
-
 // Phase B job = one feature tile x ALL slot tiles of the re-based profile (2 or 4 of them: tiles are projected in
 // pairs): the tile's weight fragments are fetched ONCE per workgroup (by the caller, so that the first job's can be
 // requested before phase A) and feed that many independent accumulator chains.
@@ -959,6 +939,15 @@ extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t*
     fa.qscale = (float)(1.4426950408889634 / sqrt((double)(d / H)));
     fa.stamps = carca_debug_buffer();
     fa.dbg = carca_tuning(5);
+    fa.B = B;
+    fa.opt = carca_tuning(3);
+    // more users than CUs: persistent workgroups that pipeline their users (cross_stream.hip; tuning key 7: 2 = never,
+    // 3 = at every batch size); it has no p_normed output and no instantiation above d = 96 -- the kernel below then runs
+    const int t7 = carca_tuning(7);
+    if (!p_normed && t7 != 2 && carca_tuning(CARCA_TUNE_ATTN_VARIANT) == 0 && (t7 == 3 || B > carca_num_cus())) {
+      const int rc = carca_cross_stream_launch(fa, dpi, dhp, H, B, stream);
+      if (rc != CARCA_ERR_UNSUPPORTED) return rc;
+    }
     CARCA_ATT_DISPATCH(launch_fold, fa, B, stream);
     carca_set_error("cross_score_fwd: no kernel built for d=%d H=%d (padded %d / head %d)", d, H, dpi, dhp);
     return CARCA_ERR_UNSUPPORTED;

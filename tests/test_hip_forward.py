@@ -374,9 +374,9 @@ def test_two_workgroups_per_user_is_bitwise_the_same():
 
 
 def test_big_batch_scoring_variant_is_bitwise_the_same():
-    """B > #CUs takes the scoring kernel's 8-wave workgroups (two resident per CU) by itself: the 16-wave ones' results
-    (tuning key 1 = 1) up to the summation order of the folded value u (MFMA tile there, VALU partial sums here), and the
-    oracle's numbers."""
+    """B > #CUs takes the persistent, user-pipelined scoring kernel (csrc/cross_stream.hip) by itself: the 16-wave
+    per-user workgroups' results (tuning key 1 = 1) up to the summation order of the final LayerNorm's row sums and of the
+    folded value u, the 8-wave per-user workgroups' (key 7 = 2) likewise, and the oracle's numbers."""
     from carca_replication_amd import _lib
 
     cfg = O.CarcaConfig(d=90, H=3, n_blocks=1, encoding="learnable")
@@ -391,9 +391,14 @@ def test_big_batch_scoring_variant_is_bitwise_the_same():
             lib.carca_set_tuning(1, tune)
             with torch.no_grad():
                 outs[tune] = model(profile=dev(profile), targets=[dev(target)]).cpu()
+        lib.carca_set_tuning(1, 0)
+        lib.carca_set_tuning(7, 2)
+        with torch.no_grad():
+            outs[2] = model(profile=dev(profile), targets=[dev(target)]).cpu()
     finally:
         lib.carca_set_tuning(1, 0)
-    assert float((outs[0] - outs[1]).abs().max()) < 5e-7
+        lib.carca_set_tuning(7, 0)
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-6 and float((outs[0] - outs[2]).abs().max()) < 1e-6
     want = O.carca_forward(P, cfg, profile, [target], training=False)
     assert float((outs[0] - want).abs().max()) < Y_ATOL
 
@@ -557,3 +562,68 @@ def test_one_block_per_cu_joint_gemm_equals_the_tiled_one(B, L, N, enc):
     assert float((outs[11] - outs[12]).abs().max()) < 2e-6
     want = O.carca_forward(P, cfg, profile, [target], training=False)
     assert float((outs[11] - want).abs().max()) < Y_ATOL
+
+
+# ---- the persistent, user-pipelined scoring kernel (csrc/cross_stream.hip) --------------------------------------------------
+@pytest.mark.parametrize("d,H,L,Ns,B,lengths", [
+    (90, 3, 50, [101], 300, "uniform"), (90, 3, 50, [101], 261, "holes"), (90, 3, 50, [101], 5, "holes"),
+    (90, 3, 50, [1], 270, "holes"), (90, 3, 50, [17], 270, "uniform"), (90, 3, 50, [300], 260, "holes"),
+    (90, 3, 50, [5, 130, 33], 270, "holes"), (90, 2, 50, [50, 50], 300, "holes"), (90, 1, 33, [101], 280, "holes"),
+    (64, 2, 50, [101], 300, "holes"), (64, 4, 7, [40], 300, "holes"), (64, 1, 64, [20], 300, "full"),
+    (96, 3, 64, [129], 300, "holes")])
+def test_stream_scoring_kernel_equals_oracle_and_per_user_kernels(d, H, L, Ns, B, lengths):
+    """cross_stream_kernel (what B > #CUs launches in eval mode; forced here with tuning key 7 = 3 at any B) against the
+    oracle's final norm + cross_block and against the two per-user kernels (folded: key 7 = 2, V-materialising: key 6 = 1):
+    several rounds of target tiles (N = 300), several groups, one-target groups, pads inside profiles, all-pad users,
+    batches that leave some workgroups one user more than others, every head layout with an instantiation."""
+    from carca_replication_amd import _lib, ops
+    from tests.model_util import build_model
+
+    torch.manual_seed(d * 7 + H + L)
+    model = build_model(dict(d=d, H=H, n_blocks=1), 50, 16, 2, 8, L).eval().cuda()
+    with torch.no_grad():
+        for p_ in model.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    dpi, _, _ = ops.padded_dims(d, H)
+    cw = model.decoder.weights_struct(torch.device("cuda"), model.norm)
+    g = torch.Generator().manual_seed(B)
+    x = torch.zeros(B, L, dpi)
+    x[..., :d] = torch.randn(B, L, d, generator=g)
+    ln = torch.full((B,), L) if lengths == "full" else torch.randint(min(3, L), L + 1, (B,), generator=g)
+    p_ids = (torch.arange(L)[None, :] >= (L - ln)[:, None]).int() * 7
+    if lengths == "holes":
+        p_ids = p_ids * (torch.rand(B, L, generator=g) > 0.2).int()
+        p_ids[0] = 0
+        p_ids[B // 2] = 0
+    groups = []
+    for N in Ns:
+        o = torch.zeros(B, N, dpi)
+        o[..., :d] = torch.randn(B, N, d, generator=g)
+        o_ids = torch.randint(1, 5, (B, N), generator=g).int()
+        o_ids[:, -1] = 0
+        groups.append((o, o_ids))
+    lib = _lib.load()
+    outs = {}
+    try:
+        for name, t7, t6 in (("stream", 3, 0), ("fold", 2, 0), ("mat", 2, 1)):
+            lib.carca_set_tuning(7, t7)
+            lib.carca_set_tuning(6, t6)
+            with torch.no_grad():
+                ys, _ = ops.cross_score_fwd(x.cuda(), p_ids.cuda(), [(o.cuda(), i.cuda()) for o, i in groups], cw, d, H, True,
+                                            False)
+            outs[name] = [y.cpu() for y in ys]
+    finally:
+        lib.carca_set_tuning(7, 0)
+        lib.carca_set_tuning(6, 0)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = O.CarcaConfig(d=d, H=H, n_blocks=1)
+    nu = min(B, 24)  # the oracle on the first users (they include an all-pad profile), the kernels on all of them
+    p_mask = (p_ids[:nu] != 0).float()
+    pn = O.layer_norm(x[:nu, :, :d], P["norm.weight"], P["norm.bias"])
+    for gi, (o, o_ids) in enumerate(groups):
+        want = O.cross_block(P, cfg, o[:nu, :, :d], (o_ids[:nu] != 0).float(), pn, p_mask, training=False).reshape(nu, -1)
+        assert float((outs["stream"][gi][:nu] - want).abs().max()) < Y_ATOL
+        assert bool(torch.isfinite(outs["stream"][gi]).all())
+        assert float((outs["stream"][gi] - outs["fold"][gi]).abs().max()) < 2e-6
+        assert float((outs["stream"][gi] - outs["mat"][gi]).abs().max()) < 2e-6
