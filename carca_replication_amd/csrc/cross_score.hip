@@ -941,10 +941,13 @@ extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t*
     fa.dbg = carca_tuning(5);
     fa.B = B;
     fa.opt = carca_tuning(3);
-    // more users than CUs: persistent workgroups that pipeline their users (cross_stream.hip; tuning key 7: 2 = never,
-    // 3 = at every batch size); it has no p_normed output and no instantiation above d = 96 -- the kernel below then runs
+    // Persistent workgroups that pipeline their units of work (cross_stream.hip): every batch size where they are not
+    // slower -- tuning key 7: 2 = never, 3 = at every batch size, 0 = above #CUs users.  It has no p_normed output and
+    // no instantiation above d = 96: the per-user kernel below then runs.
     const int t7 = carca_tuning(7);
-    if (!p_normed && t7 != 2 && carca_tuning(CARCA_TUNE_ATTN_VARIANT) == 0 && (t7 == 3 || B > carca_num_cus())) {
+    const int tune1 = carca_tuning(CARCA_TUNE_ATTN_VARIANT);
+    if (!p_normed && t7 != 2 && (tune1 == 0 || tune1 == 2) && (t7 == 3 || B > carca_num_cus())) {
+      fa.nparts = (gd.tile_start[ngroups] > 1 && (tune1 == 2 || 2 * B <= carca_num_cus())) ? 2 : 1;
       const int rc = carca_cross_stream_launch(fa, dpi, dhp, H, B, stream);
       if (rc != CARCA_ERR_UNSUPPORTED) return rc;
     }

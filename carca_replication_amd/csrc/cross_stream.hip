@@ -86,10 +86,17 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, mq = lane >> 4;
   const int L = a.L, d = a.d;
+  // A workgroup's UNITS: unit w = (user w / nparts, part w % nparts of that user's target tiles), w = blockIdx.x,
+  // blockIdx.x + gridDim.x, ...  nparts = 1 when users outnumber the CUs; 2 while 2 B <= #CUs (the latency regime: both
+  // workgroups of a user build the same K / u images and score half of the tiles each, nothing passes between them).
   const int v0 = blockIdx.x, vs = gridDim.x;
-  const int nu = (a.B - v0 + vs - 1) / vs;  // users of this workgroup (>= 1: the grid never exceeds B)
+  const int nparts = a.nparts;
   const int all_tiles = a.tile_start[a.ngroups];
-  const int R = (all_tiles + XS_TPR - 1) / XS_TPR;  // rounds per user
+  const int per_part = (all_tiles + nparts - 1) / nparts;
+  const int nu = (a.B * nparts - v0 + vs - 1) / vs;  // units of this workgroup (>= 1: the grid never exceeds their number)
+  const int R = (per_part + XS_TPR - 1) / XS_TPR;    // rounds per unit
+  auto user_of = [&](int k) { return (v0 + k * vs) / nparts; };
+  auto tlo_of = [&](int k) { return ((v0 + k * vs) % nparts) * per_part; };
   const bool ln_on = a.ln_w != nullptr;
 #define XS_STAMP(i)                                                                                          \
   do {                                                                                                       \
@@ -129,7 +136,10 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
     c.o = a.g[gi].o + (size_t)v * N * a.ldo;
     c.ids = a.g[gi].ids + (size_t)v * N;
   };
-  auto njobs_of = [&](int rd) { return min(XS_TPR, all_tiles - rd * XS_TPR) * NH; };
+  auto njobs_of = [&](int k, int rd) {
+    const int t_lo = tlo_of(k);
+    return max(0, min(XS_TPR, min(all_tiles, t_lo + per_part) - t_lo - rd * XS_TPR)) * NH;
+  };
   // LDS-only barrier: global loads (the prefetched operands of the next job / user) stay in flight across it
 #define XS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   // diagnostic (debug buffer set, tools/k4_stream_check.py STAMPS=1): per-wave clocks of step a.dbg of this workgroup --
@@ -153,11 +163,11 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
     f32x4 xr[G::NKG];              // the tile's rows as requested (raw encoder output)
     unsigned long long pmask;
     auto request_ids = [&](int k) {
-      const int v = v0 + min(k, nu - 1) * vs;
+      const int v = user_of(min(k, nu - 1));
       return gload1i(a.p_ids + (size_t)v * L, lane < L ? lane : L - 1);
     };
     auto request_rows = [&](int k, unsigned long long pm) {
-      const int v = v0 + min(k, nu - 1) * vs;
+      const int v = user_of(min(k, nu - 1));
       const int s0 = pm ? (int)__builtin_ctzll(pm) : L;
       const int r = s0 + 16 * st + ln;
       const float* pu = a.p_raw + (size_t)v * L * a.ldp;
@@ -264,9 +274,9 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
     auto finish = [&](int k, int rd, int sp) {
       if (wave < XS_NW - 2) return;
       const int tl = 4 * (wave - (XS_NW - 2)) + mq;
-      const int nt = min(XS_TPR, all_tiles - rd * XS_TPR);
+      const int nt = njobs_of(k, rd) / NH;
       if (tl < nt) {
-        const int tile = rd * XS_TPR + tl;
+        const int tile = tlo_of(k) + rd * XS_TPR + tl;
         int gi = 0;
 #pragma unroll
         for (int i = 1; i < CARCA_MAX_GROUPS; ++i)
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
           float logit = ffn_b;
 #pragma unroll
           for (int h = 0; h < NH; ++h) logit += Yp2[((sp * XS_TPR + tl) * NH + h) * 16 + ln];
-          const int v = v0 + k * vs;
+          const int v = user_of(k);
           a.g[gi].y[(size_t)v * ldy + n] = 1.0f / (1.0f + expf(-logit));
         }
       }
@@ -318,14 +328,14 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
     } cur;
     auto load_ops = [&](int k, int rd, int job) {
       Job c;
-      decode_tile(rd * XS_TPR + job / NH, v0 + k * vs, c);
+      decode_tile(tlo_of(k) + rd * XS_TPR + job / NH, user_of(k), c);
 #pragma unroll
       for (int kg = 0; kg < G::NKG; ++kg) cur.q[kg] = gload4s(c.o, c.lrow * a.ldo + 4 * mq, 16 * kg);
       cur.id = gload1i(c.ids, c.lrow);
     };
     // the job this wave runs after (k, rd, job); false when there is none
     auto find_next = [&](int k, int rd, int cand, int& k2, int& rd2, int& job2) {
-      if (cand < njobs_of(rd)) {
+      if (cand < njobs_of(k, rd)) {
         k2 = k;
         rd2 = rd;
         job2 = cand;
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
           ++k;
         }
         if (k >= nu) return false;
-        if (cw < njobs_of(rd)) {
+        if (cw < njobs_of(k, rd)) {
           k2 = k;
           rd2 = rd;
           job2 = cw;
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
       const float* Km = Km2 + buf * ATT_LMAX;
       const float* Ut = Ut2 + buf * NH * ATT_SK;
       float* Yp = Yp2 + sp * XS_TPR * NH * 16;
-      const int nj = njobs_of(rd);
+      const int nj = njobs_of(k, rd);
       XS_WSTAMP(s, 0);
       for (int job = cw; job < nj;) {
         // Which job comes next: job + 12 (static dealing).  a.opt bit 0 (tuning key 3, A/B): a wave's first job of a step
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
         const float* const w0 = Wq + (h * G::NFH * G::NKG) * 256 + 4 * lane;
         const float* const bq0 = Bq + h * DHP + 4 * mq;
         Job c;
-        decode_tile(rd * XS_TPR + tl, v0 + k * vs, c);
+        decode_tile(tlo_of(k) + rd * XS_TPR + tl, user_of(k), c);
         const bool q_ok = c.in_range && cur.id != 0;
         // Q^T tiles of the head: NFH interleaved accumulator chains that start from the bias, W_Q fragments from LDS.  The
         // softmax scale is applied inside the exponent below (one fma per score either way), not to the tile.
@@ -520,7 +530,7 @@ int launch_stream(const FoldArgs& fa, int B, hipStream_t stream) {
       }
       attr_set = true;
     }
-    const int grid = min(B, carca_num_cus());
+    const int grid = min(B * fa.nparts, carca_num_cus());
     hipEvent_t e0, e1;
     if (carca_take_launch_events(&e0, &e1))
       hipExtLaunchKernelGGL(kern, dim3(grid), dim3(XS_NW * 64), lds_bytes, stream, e0, e1, 0, fa);

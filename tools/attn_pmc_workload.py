@@ -17,6 +17,9 @@ model = build_model(dict(d=d, H=H, n_blocks=2), 500, g, 6, 64, L).eval().cuda()
 dpi, _, _ = ops.padded_dims(d, H)
 cw = model.decoder.weights_struct(torch.device("cuda"), model.norm)
 sw = model.encoder[0].weights_struct(torch.device("cuda"))
+if os.environ.get("TUNE7"):  # 2: the per-user scoring kernel at every batch size, 3: the persistent one (A/B)
+    from carca_replication_amd import _lib
+    _lib.load().carca_set_tuning(7, int(os.environ["TUNE7"]))
 for B in [int(b) for b in os.environ.get("BS", "128,1024,4096").split(",")]:
     gen = torch.Generator(device="cuda").manual_seed(B)
     x = torch.zeros(B, L, dpi, device="cuda")

@@ -134,10 +134,11 @@ if os.environ.get("STAMPS"):  # per-wave clocks of one step (tuning key 5 = step
     d, H, L, N = 90, 3, 50, 101
     model, dpi, cw = models[(d, H, L)]
     step = int(os.environ.get("STEP", "2"))
-    for B, lengths in ((4096, "full"), (4096, "uniform")):
+    for B, lengths in [(int(b), l) for b in os.environ.get("STAMP_BS", "4096").split(",") for l in ("full", "uniform")]:
         a = inputs(B, L, [N], d, dpi, lengths)
         for _ in range(5):
             run(*a, cw, d, H, "stream")
+        nwg = min(256, B * (2 if 2 * B <= 256 else 1))
         buf = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
         lib.carca_set_debug_buffer(buf.data_ptr())
         lib.carca_set_tuning(5, step)
@@ -145,7 +146,7 @@ if os.environ.get("STAMPS"):  # per-wave clocks of one step (tuning key 5 = step
         torch.cuda.synchronize()
         lib.carca_set_tuning(5, 0)
         lib.carca_set_debug_buffer(None)
-        st = buf.view(256, 64).cpu().double()
+        st = buf.view(256, 64)[:nwg].cpu().double()
         opened, arrive, mid = st[:, 0:16], st[:, 16:32], st[:, 32:48]
         t0 = opened.min(dim=1, keepdim=True).values
         med = lambda t: [int(x) for x in t.median(dim=0).values.tolist()]  # noqa: E731
@@ -155,4 +156,5 @@ if os.environ.get("STAMPS"):  # per-wave clocks of one step (tuning key 5 = step
         print("   at the barrier", med(arrive - t0))
         print("   step length (last arrival - first open): median %.0f  max %.0f" % (
             float((arrive.max(dim=1).values - t0[:, 0]).median()), float((arrive.max(dim=1).values - t0[:, 0]).max())))
-        print("   kernel span: median %.0f cycles" % float((st[:, 52] - st[:, 48]).median()))
+        print("   kernel span: median %.0f cycles; step opened %.0f cycles after the kernel's first instruction" % (
+            float((st[:, 52] - st[:, 48]).median()), float((t0[:, 0] - st[:, 48]).median())))
