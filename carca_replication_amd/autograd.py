@@ -83,7 +83,10 @@ def _grad_buffers(model, params, extra: int, id_lists, late=()):
         flat = torch.zeros(total, dtype=dt, device=dev)  # one fill launch for every gradient and staging area
     views = [flat[offs[i]: offs[i] + p.numel()].view(p.shape) for i, p in enumerate(params)]
     model.__dict__["_flat_grad"] = dict(flat=flat, early=(0, n_early), late=(n_early, n_late),
-                                        big=[(params[i], views[i]) for i in big], n_params=len(params))
+                                        big=[params[i] for i in big], n_params=len(params))
+    # (`big` names the parameters only: a second reference to a big table's view would make AccumulateGrad CLONE it --
+    # it takes a gradient over as p.grad only while nobody else holds it -- i.e. a fresh 512 MB allocation + copy per
+    # step at BASELINE config 4, and a p.grad that no longer lives in the flat buffer; tests/test_c4_scale.py)
 
     def after():
         if cached:

@@ -41,7 +41,19 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, const Ad
   const CarcaAdamTensor T = tab.t[ti];
   const int64_t base = (int64_t)((int)blockIdx.x - tab.chunk_start[ti]) * ADAM_CHUNK;
   const int64_t left = T.n - base;
-  if (T.row_mask && (T.row_len & 3) == 0) {  // embedding table with a row mask: untouched rows are skipped (see the header)
+  const bool aligned = (((uintptr_t)T.p | (uintptr_t)T.g | (uintptr_t)T.m | (uintptr_t)T.v) & 15) == 0;
+  if (T.row_mask && !((T.row_len & 3) == 0 && aligned)) {  // rows or pointers off the 16-byte grid: one float per thread
+    for (int64_t i = base + threadIdx.x; i < base + ADAM_CHUNK && i < T.n; i += 256) {
+      if (!T.row_mask[i / T.row_len]) continue;
+      float p = T.p[i], m = T.m[i], v = T.v[i];
+      adam_one(p, T.g[i], m, v, s);
+      T.p[i] = p;
+      T.m[i] = m;
+      T.v[i] = v;
+    }
+    return;
+  }
+  if (T.row_mask) {  // embedding table with a row mask: untouched rows are skipped (see the header)
     for (int64_t i = base + threadIdx.x * 4; i < base + ADAM_CHUNK && i < T.n; i += 1024) {
       if (!T.row_mask[i / T.row_len]) continue;
       f32x4 p = *reinterpret_cast<const f32x4*>(T.p + i), m = *reinterpret_cast<const f32x4*>(T.m + i);
@@ -61,7 +73,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab, const Ad
     }
     return;
   }
-  const bool vec = left >= ADAM_CHUNK && (((uintptr_t)T.p | (uintptr_t)T.g | (uintptr_t)T.m | (uintptr_t)T.v) & 15) == 0;
+  const bool vec = left >= ADAM_CHUNK && aligned;
   if (vec) {  // one float4 per thread
     const int64_t i = base + threadIdx.x * 4;
     f32x4 p = *reinterpret_cast<const f32x4*>(T.p + i), m = *reinterpret_cast<const f32x4*>(T.m + i);

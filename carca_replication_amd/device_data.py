@@ -56,6 +56,27 @@ class DeviceInteractions:
         self.hctx = torch.from_numpy(hctx).to(device)
         self.device = self.hist.device
 
+    @classmethod
+    def from_arrays(cls, lens: np.ndarray, hist: np.ndarray, hctx: np.ndarray, n_items: int, device: str = "cuda",
+                    user_ids: Sequence[int] = None) -> "DeviceInteractions":
+        """The same log from its CSR arrays (bulk / synthetic construction without the per-interaction dict walk):
+        lens [U] interactions per user, hist [sum lens] item ids in interaction order, hctx [sum lens, n_ctx]."""
+        self = cls.__new__(cls)
+        lens = np.asarray(lens, dtype=np.int64)
+        offs = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        hist, hctx = np.asarray(hist, dtype=np.int32), np.asarray(hctx, dtype=np.float32)
+        if hist.shape != (int(offs[-1]),) or hctx.ndim != 2 or hctx.shape[0] != hist.shape[0]:
+            raise ValueError("from_arrays: hist must hold sum(lens) ids and hctx one context row per id")
+        self.user_ids = list(range(len(lens))) if user_ids is None else list(user_ids)
+        self.lens, self.n_items, self.n_ctx = lens, int(n_items), int(hctx.shape[1])
+        self.max_len = int(lens.max()) if len(lens) else 0
+        self.hist = torch.from_numpy(hist).to(device)
+        self.offs = torch.from_numpy(offs).to(device)
+        self.hctx = torch.from_numpy(np.ascontiguousarray(hctx)).to(device)
+        self.device = self.hist.device
+        return self
+
     def valid_users(self, mode: str, test: bool = True) -> Tensor:
         """Indices (into this log) of the users that have a window in the split (CARCADataset.valid_user_ids)."""
         _, floor = split_constants(mode, test)
@@ -103,3 +124,62 @@ class DeviceInteractions:
                                                o_x.data_ptr(), o_c.data_ptr(), y.data_ptr(), ops._stream()),
                    "build_train_batch")
         return p_x, p_c, o_x, o_c, y
+
+
+class DeviceLoader:
+    """The reference's `DataLoader(CARCADataset(...))` (scripts/training.py:118-163, data.py:211-248) with the dataset
+    resident in HBM: iterating yields the batches `train()` / `evaluate()` take -- the reference's 7-tuple
+    (p_x, p_a, p_c, o_x, o_a, o_c, y_true) with p_a = o_a = None, ids + context only -- built on the device by
+    `DeviceInteractions`.  Pair it with `model.embeds.register_attr_table(load_attrs(...))`: the model gathers the
+    attribute rows by id inside its feature GEMM and no dense [B, T, n_attrs] tensor exists anywhere (2.5 MB per user at
+    BASELINE config 2).
+
+        log = DeviceInteractions(profiles, ctx, n_items=attrs.shape[0])
+        train_loader = DeviceLoader(log, "train", batch_size=128, profile_seq_len=50, shuffle=True)
+        val_loader = DeviceLoader(log, "val", batch_size=128, profile_seq_len=50, target_seq_len=100)
+
+    One kernel launch builds `chunk_batches` batches at once (ids + context of a user are ~4 KB: the launch is sized
+    for the chip, not for one batch) and the iterator hands out views of that chunk.  shuffle draws a fresh permutation
+    of the split's users per epoch from `seed` (torch's device generator); negatives are re-drawn per epoch and chunk
+    from the same seed (counter-based hash, reproducible).  `len()` = batches per epoch, short last batch included
+    (drop_last=False as in the reference)."""
+
+    def __init__(self, log: DeviceInteractions, mode: str, batch_size: int, profile_seq_len: int,
+                 target_seq_len: int = 100, test: bool = True, shuffle: bool = False, seed: int = 0,
+                 users: Tensor = None, chunk_batches: int = 32, drop_last: bool = False):
+        split_constants(mode, test)  # (validates mode)
+        self.log, self.mode, self.test = log, mode, test
+        self.batch_size, self.L, self.N = int(batch_size), int(profile_seq_len), int(target_seq_len)
+        self.shuffle, self.seed, self.drop_last = bool(shuffle), int(seed), bool(drop_last)
+        self.users = log.valid_users(mode, test) if users is None else users.to(log.device, torch.int32)
+        self.chunk_batches = max(1, int(chunk_batches))
+        self.epoch = 0
+        self._gen = torch.Generator(device=log.device)
+
+    def __len__(self) -> int:
+        n = self.users.numel()
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    @property
+    def n_users(self) -> int:
+        n = self.users.numel()
+        return n // self.batch_size * self.batch_size if self.drop_last else n
+
+    def __iter__(self):
+        users = self.users
+        if self.shuffle:
+            self._gen.manual_seed(self.seed * 1_000_003 + self.epoch)
+            users = users[torch.randperm(users.numel(), device=users.device, generator=self._gen)]
+        epoch, self.epoch = self.epoch, self.epoch + 1
+        B, n = self.batch_size, self.n_users
+        step = B * self.chunk_batches
+        for ci, lo in enumerate(range(0, n, step)):
+            chunk = users[lo: min(lo + step, n)]
+            seed = (self.seed * 0x9E3779B97F4A7C15 + epoch * 0xD1B54A32D192ED03 + ci) & (2 ** 64 - 1)
+            if self.mode == "train":
+                p_x, p_c, o_x, o_c, y = self.log.train_batch(chunk, self.L, self.test, seed)
+            else:
+                p_x, p_c, o_x, o_c, y = self.log.eval_batch(chunk, self.L, self.N, self.mode, self.test, seed)
+            for b in range(0, chunk.numel(), B):
+                s = slice(b, b + B)
+                yield p_x[s], None, p_c[s], o_x[s], None, o_c[s], y[s]

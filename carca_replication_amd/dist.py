@@ -111,55 +111,67 @@ def allreduce_range(flat: torch.Tensor, lo: int, hi: int, bucket_mb: float = 64.
             for off in range(lo, hi, step)]
 
 
-def allgather_row_gradients(grad: torch.Tensor, ids: torch.Tensor) -> None:
+def allgather_row_gradients(grad: torch.Tensor, ids: torch.Tensor, pad_to: Optional[int] = None) -> Optional[torch.Tensor]:
     """Sum over ranks of a gradient that is non-zero only in the rows `ids` touches (an embedding table):
     every rank contributes (ids, grad[ids]) with duplicates zeroed, all-gathers them and adds the lot into its own
     table.  Same result as a dense all-reduce(sum); traffic ~ world x len(ids) x (d + 1) floats instead of the table.
     Ranks may hold different numbers of ids (B % world != 0, a short last batch): the lists are padded with id 0 --
-    the pad row, whose gradient is zero by construction (nn.Embedding(padding_idx=0), carca.py:73) -- to the longest."""
+    the pad row, whose gradient is zero by construction (nn.Embedding(padding_idx=0), carca.py:73).
+    pad_to: the list length every rank pads to, known on the host without asking the other ranks (engine.train_step
+      derives it from the GLOBAL batch size: ceil(B / world) users x ids per user): no host sync on the step.  None =
+      the ranks agree on the longest list with an all-reduce(max) whose result the host must read (one sync per step).
+    Returns every rank's ids, concatenated (the rows the exchanged gradients land in: what a touched-row optimizer has
+    to mark, engine._mark_touched_rows), or None outside a process group."""
     if not _active():
-        return
+        return None
     world = dist.get_world_size()
     flat_ids = ids.reshape(-1).to(torch.int64)
-    n_max = torch.tensor([flat_ids.numel()], dtype=torch.int64, device=flat_ids.device)
-    dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
-    pad = int(n_max.item()) - flat_ids.numel()
+    if pad_to is None:
+        n_max = torch.tensor([flat_ids.numel()], dtype=torch.int64, device=flat_ids.device)
+        dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+        pad_to = int(n_max.item())
+    if flat_ids.numel() > pad_to:
+        raise ValueError(f"allgather_row_gradients: {flat_ids.numel()} ids on this rank, but the ranks agreed on {pad_to}")
+    pad = int(pad_to) - flat_ids.numel()
     if pad > 0:
         flat_ids = torch.cat([flat_ids, flat_ids.new_zeros(pad)])
     srt, _ = torch.sort(flat_ids)
     first = torch.ones_like(srt, dtype=torch.bool)
     first[1:] = srt[1:] != srt[:-1]
     rows = grad.index_select(0, srt) * first.unsqueeze(1).to(grad.dtype)  # each touched row once, duplicates as zeros
-    all_ids = [torch.empty_like(srt) for _ in range(world)]
-    all_rows = [torch.empty_like(rows) for _ in range(world)]
-    h1 = dist.all_gather(all_ids, srt, async_op=True)
-    h2 = dist.all_gather(all_rows, rows, async_op=True)
+    all_ids = torch.empty(world * srt.numel(), dtype=srt.dtype, device=srt.device)
+    all_rows = torch.empty(world * rows.shape[0], rows.shape[1], dtype=rows.dtype, device=rows.device)
+    h1 = dist.all_gather_into_tensor(all_ids, srt, async_op=True)
+    h2 = dist.all_gather_into_tensor(all_rows, rows, async_op=True)
     h1.wait()
     h2.wait()
     grad.index_fill_(0, srt, 0.0)  # own contribution comes back with everybody else's
-    grad.index_add_(0, torch.cat(all_ids), torch.cat(all_rows))
+    grad.index_add_(0, all_ids, all_rows)
+    return all_ids
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, average: bool = False,
                         sparse_rows: Optional[dict] = None, flat_info: Optional[dict] = None,
-                        early_work: Optional[list] = None) -> None:
+                        early_work: Optional[list] = None, sparse_pad_to: Optional[int] = None) -> dict:
     """Sum (or average) .grad over ranks.
     flat_info (flat_layout): the gradients are views of the backward's own flat buffer -- its [early | late] ranges are
       reduced IN PLACE (no gather / scatter copies), asynchronously, in chunks of bucket_mb; early_work: handles of an
       early-range reduction the caller already started (engine.train_step starts it under the backward's last kernel).
     Otherwise: flat fp32 buckets of copies.
     sparse_rows: {parameter: ids} for embedding tables whose gradient is exchanged row-wise instead
-    (allgather_row_gradients); with flat_info these are its `big` tables."""
+    (allgather_row_gradients, padded to sparse_pad_to ids per rank); with flat_info these are its `big` tables.
+    Returns {id(parameter): every rank's ids} for the row-exchanged tables."""
     global last_reduce
+    gathered: dict = {}
     if not _active():
-        return
+        return gathered
     world = dist.get_world_size()
     params = [p for p in params if p.grad is not None]
     sparse_rows = sparse_rows or {}
     sparse = [p for p in params if any(p is q for q in sparse_rows)]
     cap = int(bucket_mb * 2 ** 20)
     work, flat_handles, flat_range = [], [], None
-    if flat_info is not None and all(any(p is q for q in sparse_rows) for p, _ in flat_info["big"]):
+    if flat_info is not None and all(any(p is q for q in sparse_rows) for p in flat_info["big"]):
         flat = flat_info["flat"]
         handles = list(early_work) if early_work is not None else allreduce_range(flat, *flat_info["early"], bucket_mb)
         handles += allreduce_range(flat, *flat_info["late"], bucket_mb)
@@ -174,7 +186,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_mb: float =
         last_reduce = dict(path="bucket-copies", launches=len(work), sparse_tables=len(sparse), early_overlapped=False)
     for p in sparse:
         ids = next(v for q, v in sparse_rows.items() if q is p)
-        allgather_row_gradients(p.grad, ids)
+        gathered[id(p)] = allgather_row_gradients(p.grad, ids, pad_to=sparse_pad_to)
         if average:
             p.grad.div_(world)
     for h in flat_handles:
@@ -190,6 +202,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_mb: float =
             n = g.numel()
             g.copy_(flat[off: off + n].view_as(g))
             off += n
+    return gathered
 
 
 def allreduce_sums(sums: torch.Tensor) -> torch.Tensor:

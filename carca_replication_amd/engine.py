@@ -26,14 +26,40 @@ def _sparse_tables(model, p_x, o_x):
     return {emb.weight: torch.cat([p_x.reshape(-1), o_x.reshape(-1)])}
 
 
-def train_step(model, optim, batch, sharded: bool = False) -> torch.Tensor:
+def as_batch7(batch):
+    """(p_x, p_a, p_c, o_x, o_a, o_c, y_true) from what a loader yields: the reference's 7-tuple (train.py:84), or the
+    ids-only 5-tuple (p_x, p_c, o_x, o_c, y_true) of CARCADataset(with_attrs=False) -- attribute slots None, filled by the
+    model from its registered attribute table."""
+    batch = tuple(batch)
+    if len(batch) == 5:
+        p_x, p_c, o_x, o_c, y_true = batch
+        return p_x, None, p_c, o_x, None, o_c, y_true
+    if len(batch) != 7:
+        raise ValueError(f"a batch is 7 tensors (train.py:84) or 5 without the attribute tensors, got {len(batch)}")
+    return batch
+
+
+def _row_exchange_len(p_x, o_x, global_batch: Optional[int]) -> Optional[int]:
+    """ids per rank the row exchange of a big item table pads to, from the host's own knowledge: the largest shard of
+    dist.shard_range (ceil(global_batch / world) users) x ids per user.  None = unknown (the ranks ask each other)."""
+    if global_batch is None:
+        return None
+    world = max(cdist.world_size(), 1)
+    return -(-int(global_batch) // world) * (p_x.shape[1] + o_x.shape[1])
+
+
+def train_step(model, optim, batch, sharded: bool = False, global_batch: Optional[int] = None) -> torch.Tensor:
     """batch = (p_x, p_a, p_c, o_x, o_a, o_c, y_true) as the reference's DataLoader yields (train.py:84).
 
     With sharded=True the batch holds THIS rank's users; the loss is normalised by the global mask
     count and gradients are summed over ranks, which reproduces the single-process step exactly.
+    global_batch: users of the whole step over all ranks (shards as dist.shard_range cuts them); lets a model with a
+    big item table size its row exchange without a host sync (dist.allgather_row_gradients).
     Returns the (device) loss: the global batch loss's local share when sharded.
     """
+    batch = as_batch7(batch)
     p_x, o_x = batch[0], batch[3]
+    gathered = None
     if not (sharded and cdist._active()):
         loss = _forward_backward(model, optim, batch, None)
     else:
@@ -58,8 +84,9 @@ def train_step(model, optim, batch, sharded: bool = False) -> torch.Tensor:
             _lib.check(_lib.load().carca_stream_wait_event(side.cuda_stream, ev.handle), "stream_wait_event")
             with torch.cuda.stream(side):
                 early = cdist.allreduce_range(info["flat"], *info["early"])
-        cdist.allreduce_gradients(params, sparse_rows=_sparse_tables(model, p_x, o_x), flat_info=info, early_work=early)
-    _mark_touched_rows(model, optim, p_x, o_x, sharded)
+        gathered = cdist.allreduce_gradients(params, sparse_rows=_sparse_tables(model, p_x, o_x), flat_info=info,
+                                             early_work=early, sparse_pad_to=_row_exchange_len(p_x, o_x, global_batch))
+    _mark_touched_rows(model, optim, p_x, o_x, gathered)
     optim.step()
     return loss
 
@@ -80,20 +107,17 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-def _mark_touched_rows(model, optim, p_x, o_x, sharded: bool) -> None:
+def _mark_touched_rows(model, optim, p_x, o_x, gathered: Optional[dict] = None) -> None:
     """Big item tables: tell the optimizer which rows this step's gradient can touch (optim.Adam.mark_rows: rows never
-    touched are skipped, bit-exactly).  With users sharded over ranks the rows are the union over ranks -- every rank's
-    ids, gathered -- because the exchanged row gradients land in every replica."""
+    touched are skipped, bit-exactly).  With users sharded over ranks the rows are the union over ranks, because the
+    exchanged row gradients land in every replica: `gathered` = {id(table): every rank's ids}, which the row exchange
+    itself hands back (dist.allreduce_gradients) -- no second collective."""
     tables = _sparse_tables(model, p_x, o_x)
     if not tables or not hasattr(optim, "mark_rows"):
         return
     for w, ids in tables.items():
-        if sharded and cdist.world_size() > 1:
-            import torch.distributed as dist
-
-            gathered = [torch.empty_like(ids) for _ in range(cdist.world_size())]
-            dist.all_gather(gathered, ids.contiguous())
-            ids = torch.cat(gathered)
+        if gathered and gathered.get(id(w)) is not None:
+            ids = gathered[id(w)]
         optim.mark_rows(w, ids)
 
 
@@ -101,8 +125,8 @@ def _forward_backward(model, optim, batch, denom: Optional[torch.Tensor]) -> tor
     """denom: the loss normaliser (device float[1]: the all-reduced mask count of a sharded step), None = this batch's own."""
     p_x, p_a, p_c, o_x, o_a, o_c, y_true = batch
     half = o_x.shape[1] // 2
-    pos = tuple(t[:, :half] for t in (o_x, o_a, o_c))  # train.py:86-88
-    neg = tuple(t[:, half:] for t in (o_x, o_a, o_c))
+    pos = tuple(t if t is None else t[:, :half] for t in (o_x, o_a, o_c))  # train.py:86-88
+    neg = tuple(t if t is None else t[:, half:] for t in (o_x, o_a, o_c))
     if o_x.shape[1] == 2 * half:  # the kernels want dense [B, L] ids per group: ONE copy for both halves instead of two
         ids2 = o_x.view(o_x.shape[0], 2, half).transpose(0, 1).contiguous()
         pos, neg = (ids2[0],) + pos[1:], (ids2[1],) + neg[1:]
@@ -137,9 +161,11 @@ class GraphedTrainStep:
     that every dropout kernel adds to its seed (ops.set_dropout_seed_offset), so replay t draws the masks an eager step
     with seed + t would."""
 
-    def __init__(self, model, optim, example_batch, warmup: int = 3, sharded: bool = False):
-        self.model, self.optim, self.sharded = model, optim, sharded
-        self.inputs = tuple(t.clone() for t in example_batch)
+    def __init__(self, model, optim, example_batch, warmup: int = 3, sharded: bool = False,
+                 global_batch: Optional[int] = None):
+        self.model, self.optim, self.sharded, self.global_batch = model, optim, sharded, global_batch
+        example_batch = as_batch7(example_batch)
+        self.inputs = tuple(t if t is None else t.clone() for t in example_batch)
         self.denom = torch.ones(1, dtype=torch.float32, device=self.inputs[0].device) if sharded else None
         if sharded:
             self.denom.copy_(cdist.global_mask_count(self.inputs[3]))
@@ -168,8 +194,8 @@ class GraphedTrainStep:
         self._grad_cache = model.__dict__.get("_grad_cache")
 
     def __call__(self, batch) -> torch.Tensor:
-        for dst, src in zip(self.inputs, batch):
-            if dst.data_ptr() != src.data_ptr():
+        for dst, src in zip(self.inputs, as_batch7(batch)):
+            if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         if self.sharded:
             self.denom.copy_(cdist.global_mask_count(self.inputs[3]))
@@ -177,11 +203,14 @@ class GraphedTrainStep:
         for p, g in zip(self.params, self.grads):
             if p.grad is not g:
                 p.grad = g
+        gathered = None
         if self.sharded:
-            cdist.allreduce_gradients(self.params, sparse_rows=_sparse_tables(self.model, self.inputs[0], self.inputs[3]),
-                                      flat_info=cdist.flat_layout(self.model, self.params))
+            gathered = cdist.allreduce_gradients(
+                self.params, sparse_rows=_sparse_tables(self.model, self.inputs[0], self.inputs[3]),
+                flat_info=cdist.flat_layout(self.model, self.params),
+                sparse_pad_to=_row_exchange_len(self.inputs[0], self.inputs[3], self.global_batch))
         note_training_forward()  # the optimizer below rewrites the weights: packed inference copies are stale
-        _mark_touched_rows(self.model, self.optim, self.inputs[0], self.inputs[3], self.sharded)
+        _mark_touched_rows(self.model, self.optim, self.inputs[0], self.inputs[3], gathered)
         self.optim.step()
         return self.loss
 
@@ -190,13 +219,16 @@ class GraphedTrainStep:
 def eval_batch(model, batch, k: int = 10, sums: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Scores one (p_x, p_a, p_c, o_x, o_a, o_c, y_true) eval batch (train.py:42-51); accumulates
     [HR@k sum, NDCG@k sum, ties, loss sum, users] into `sums` (device float[5]) with no host sync."""
-    p_x, p_a, p_c, o_x, o_a, o_c, y_true = batch
+    p_x, p_a, p_c, o_x, o_a, o_c, y_true = as_batch7(batch)
     y = model(profile=(p_x, p_a, p_c), targets=[(o_x, o_a, o_c)])
     y2 = y.reshape(p_x.shape[0], -1)
     if sums is None:
         sums = torch.zeros(5, dtype=torch.float32, device=y.device)
     ops.rank_metrics(y2, k, sums=sums[:3])
-    loss = _loss_fn(y2, y_true, get_mask(o_x))
+    if o_x.dtype == torch.int32 and y2.is_contiguous():  # the loss kernel masks by ids != 0 itself (no float mask)
+        loss, _ = ops.bce_fwd(y2, y_true, o_x, 1e-8)
+    else:
+        loss = _loss_fn(y2, y_true, get_mask(o_x))
     sums[3] += loss
     sums[4] += p_x.shape[0]
     return y, sums

@@ -82,8 +82,8 @@ def get_mask(input: Tensor) -> Tensor:
 
 
 def to(*tensors: Tensor, device: str) -> Tuple[Tensor, ...]:
-    """utils.py:10-11"""
-    return tuple(t.to(device) for t in tensors)
+    """utils.py:10-11 (None entries -- the attribute slots of an ids-only batch -- pass through)"""
+    return tuple(t if t is None else t.to(device) for t in tensors)
 
 
 # ------------------------------------------------------------------------------------------------

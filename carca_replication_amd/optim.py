@@ -41,9 +41,11 @@ class Adam(torch.optim.Optimizer):
         g = m = v = 0, for which dense Adam's update is exactly 0 -- so parameters and state keep the bits of the dense
         sweep without moving 7 floats per element of the whole table (1 M x 128: 2.5 GB per step).
         Must be called before EVERY step from the first one on; a step without it marks the whole table touched (dense
-        from then on: still correct).  Refused (returns False) when weight decay would move untouched rows."""
-        group = next(g for g in self.param_groups if any(q is param for q in g["params"]))
-        if group["weight_decay"] != 0 or param.dim() != 2 or param.shape[1] % 4 != 0:
+        from then on: still correct).  Refused (returns False) when weight decay would move untouched rows, or for a parameter of no group."""
+        group = next((g for g in self.param_groups if any(q is param for q in g["params"])), None)
+        if group is None:  # not this optimizer's parameter (frozen, or stepped by another optimizer): nothing to announce
+            return False
+        if group["weight_decay"] != 0 or param.dim() != 2:
             return False
         st = self.state[param]
         if "row_touched" not in st:

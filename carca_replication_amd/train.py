@@ -42,13 +42,19 @@ def save_checkpoint(path: str, model: Model, optim: Optimizer = None, scheduler=
     os.replace(tmp, path)  # (an interrupted save never leaves a truncated best checkpoint behind)
 
 
-def load_checkpoint(path: str, model: Model, optim: Optimizer = None, scheduler=None, device=None) -> dict:
+def load_checkpoint(path: str, model: Model, optim: Optimizer = None, scheduler=None, device=None,
+                    allow_pickle: bool = False) -> dict:
     """Loads `path` into model (and optimizer / scheduler when given and stored); returns the checkpoint's meta dict.
-    A file written by the reference (torch.save(model), train.py:124) is accepted too: its parameters are copied."""
-    try:
+    The file is read with torch.load(weights_only=True): nothing in it is executed, and a truncated or foreign file
+    raises.  allow_pickle=True (opt-in, for files the caller trusts) also accepts what the reference writes --
+    torch.save(model), a pickled module (train.py:124) -- and copies its parameters; unpickling runs code from the file."""
+    if allow_pickle:
+        try:
+            ck = torch.load(path, map_location=device, weights_only=True)
+        except Exception:
+            ck = torch.load(path, map_location=device, weights_only=False)
+    else:
         ck = torch.load(path, map_location=device, weights_only=True)
-    except Exception:  # a pickled nn.Module: the reference's format (trusted input: the user's own run directory)
-        ck = torch.load(path, map_location=device, weights_only=False)
     if isinstance(ck, torch.nn.Module):
         model.load_state_dict(ck.state_dict())
         return {}
@@ -79,13 +85,15 @@ def compute_NDCG(y_pred: torch.Tensor, y_true: torch.Tensor, k: int) -> float:
 
 
 def evaluate(model: Model, loader: DataLoader, device: str, k: int) -> Tuple[float, float, float]:
-    """(HR@k, NDCG@k, mean batch loss) over the loader (train.py:35-53); one host sync at the end."""
+    """(HR@k, NDCG@k, mean batch loss) over the loader (train.py:35-53); one host sync at the end.
+    The loader yields the reference's 7-tuples, ids-only 5-tuples (CARCADataset(with_attrs=False)) or is a
+    device_data.DeviceLoader (batches built in HBM; the model needs its attribute table: register_attr_table)."""
     model = model.eval().to(device)
     sums = torch.zeros(5, dtype=torch.float32, device=device)
     n_batches = 0
     with torch.no_grad():
         for batch in loader:
-            engine.eval_batch(model, to(*batch, device=device), k=k, sums=sums)
+            engine.eval_batch(model, to(*engine.as_batch7(batch), device=device), k=k, sums=sums)
             n_batches += 1
     hr, ndcg, _ties, loss_sum, users = (float(v) for v in sums.cpu())
     return hr / users, ndcg / users, loss_sum / max(n_batches, 1)
@@ -103,9 +111,11 @@ def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_l
     os.makedirs(datadir, exist_ok=True)
     model = model.train().to(device)
     best, stale, first_epoch = 0.0, 0, 1
+    best_path = None  # the checkpoint holding the best weights so far: a resumed run starts with the one it resumes from
     if resume is not None:
         meta = load_checkpoint(resume, model, optim, scheduler, device=device)
         best, first_epoch = float(meta.get("NDCG", 0.0)), int(meta.get("epoch", 0)) + 1
+        stale, best_path = int(meta.get("stale", 0)), resume
     t0 = datetime.now()
     log = open(f"./{datadir}/{t0.year}-{t0.month}-{t0.day}T{t0.hour}-{t0.minute}-{t0.second}.csv", "a")
     now = lambda: datetime.now().strftime("%H:%M:%S")  # noqa: E731
@@ -114,9 +124,9 @@ def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_l
     for epoch in range(first_epoch, epochs + 1):
         loss_sum = torch.zeros((), dtype=torch.float32, device=device)
         for i, batch in enumerate(train_loader, start=1):
-            dev_batch = to(*batch, device=device)
+            dev_batch = to(*engine.as_batch7(batch), device=device)
             if graphed:
-                sig = tuple((tuple(t.shape), t.dtype) for t in dev_batch)
+                sig = tuple(None if t is None else (tuple(t.shape), t.dtype) for t in dev_batch)
                 if captured is None:
                     captured = (sig, engine.GraphedTrainStep(model, optim, dev_batch))
             if graphed and captured[0] == sig:
@@ -139,8 +149,9 @@ def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_l
                 if f.endswith(".pth"):
                     os.remove(os.path.join(datadir, f))
             best, stale = NDCG, 0
-            save_checkpoint(os.path.join(datadir, f"{epoch:03d}_{HR:.4f}_{NDCG:.4f}.pth"), model, optim, scheduler,
-                            epoch=epoch, HR=float(HR), NDCG=float(NDCG), val_loss=float(loss))
+            best_path = os.path.join(datadir, f"{epoch:03d}_{HR:.4f}_{NDCG:.4f}.pth")
+            save_checkpoint(best_path, model, optim, scheduler,
+                            epoch=epoch, HR=float(HR), NDCG=float(NDCG), val_loss=float(loss), stale=0)
         else:
             stale += 1
         if verbose in (1, 2):
@@ -151,9 +162,10 @@ def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_l
             break
         log.flush()
 
-    saved = [f for f in os.listdir(datadir) if f.endswith(".pth")]
-    if saved:  # the best epoch's weights (train.py:141-142); the optimizer keeps the last epoch's state
-        load_checkpoint(os.path.join(datadir, saved[0]), model, device=device)
+    if best_path is not None and os.path.exists(best_path):
+        # the best epoch's weights (train.py:141-142) -- of THIS run, or the checkpoint it resumed from when no epoch
+        # beat it; the optimizer keeps the last epoch's state
+        load_checkpoint(best_path, model, device=device)
         model = model.to(device)
     if test_loader is not None:
         HR, NDCG, loss = evaluate(model, test_loader, device, top_k)

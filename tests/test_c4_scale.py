@@ -39,6 +39,12 @@ def test_c4_touched_row_step_equals_the_dense_step(monkeypatch):
     touched = torch.zeros(n_items, dtype=torch.bool, device="cuda")
     for bt in batches:
         loss_a = engine.train_step(model_a, opt_a, bt)
+        # the 512 MB gradient of the item table IS its range of the cached flat buffer: autograd took the view over as
+        # .grad (a second holder of that view would have made AccumulateGrad clone it -- 512 MB allocated + copied per step)
+        flat = model_a.__dict__["_grad_cache"]["flat"]
+        g_tab = model_a.embeds.items_embed.weight.grad
+        assert g_tab.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+        assert flat.data_ptr() <= g_tab.data_ptr() < flat.data_ptr() + flat.numel() * 4
         touched[bt[0].reshape(-1).long()] = True
         touched[bt[3].reshape(-1).long()] = True
         # the dense step: no gradient cache (fresh zero fill of the whole table), torch's Adam over every row

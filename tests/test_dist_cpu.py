@@ -120,8 +120,25 @@ def _worker(rank, world, port, ret):
     table.grad, other.grad = dense.clone(), torch.full((3,), float(rank + 1))
     want = dense.clone()
     dist.all_reduce(want)
-    cdist.allreduce_gradients([table, other], sparse_rows={table: ids})
+    got = cdist.allreduce_gradients([table, other], sparse_rows={table: ids})
     ok_sparse = bool(torch.allclose(table.grad, want, atol=1e-6)) and bool(torch.equal(other.grad, torch.full((3,), 3.0)))
+    # ... the exchange hands back every rank's ids (what the touched-row optimizer marks: no second all-gather) ...
+    every = [torch.randint(0, 50, (4 + r, 9), generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    for t in every:
+        t[0, :3] = 0
+    seen = set(torch.cat([t.reshape(-1) for t in every]).tolist())
+    ok_sparse = ok_sparse and set(got[id(table)].tolist()) == seen
+    # ... and with the list length known on the host (engine: ceil(global batch / world) users x ids per user) the
+    # exchange runs without the all-reduce(max) whose result the host would have to wait for
+    table.grad, other.grad = dense.clone(), torch.full((3,), float(rank + 1))
+    got = cdist.allreduce_gradients([table, other], sparse_rows={table: ids}, sparse_pad_to=(4 + world - 1) * 9)
+    ok_sparse = ok_sparse and bool(torch.allclose(table.grad, want, atol=1e-6)) and \
+        got[id(table)].numel() == world * (4 + world - 1) * 9 and set(got[id(table)].tolist()) == seen
+    try:
+        cdist.allgather_row_gradients(table.grad, ids, pad_to=3)
+        ok_sparse = False
+    except ValueError:
+        pass
     ret[rank] = (worst, sums.tolist(), ok_flat, ok_sparse)
     dist.barrier()
     dist.destroy_process_group()

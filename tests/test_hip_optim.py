@@ -220,3 +220,48 @@ def test_sharded_step_reduces_the_flat_buffer_in_place_and_equals_the_plain_step
     finally:
         cdist.FORCE_COLLECTIVES = False
         dist.destroy_process_group()
+
+
+def test_touched_row_adam_is_bit_exact():
+    """DESIGN section 5's claim, deterministically: IDENTICAL gradient tensors into optim.Adam + mark_rows (rows never
+    touched are skipped) and into the same optimizer run densely over every row give bit-identical parameters, exp_avg
+    and exp_avg_sq after three steps -- a row that was never touched has g = m = v = 0 and Adam's update of it is exactly
+    0.  Against torch.optim.Adam over the dense gradient: untouched rows bitwise the initial ones with an all-zero state
+    in both, touched rows within the rounding bound of test_adam_matches_torch (torch contracts multiply-adds differently)."""
+    from carca_replication_amd.optim import Adam
+
+    n_rows, dim, steps = 100_000, 128, 3
+    gen = torch.Generator().manual_seed(11)
+    w0 = torch.randn(n_rows, dim, generator=gen).cuda()
+    small0 = torch.randn(33, 7, generator=gen).cuda()
+    tabs = [torch.nn.Parameter(w0.clone()) for _ in range(3)]
+    smalls = [torch.nn.Parameter(small0.clone()) for _ in range(3)]
+    masked = Adam([tabs[0], smalls[0]], lr=1e-3, betas=(0.9, 0.98))
+    dense = Adam([tabs[1], smalls[1]], lr=1e-3, betas=(0.9, 0.98))
+    ref = torch.optim.Adam([tabs[2], smalls[2]], lr=1e-3, betas=(0.9, 0.98))
+    touched = torch.zeros(n_rows, dtype=torch.bool, device="cuda")
+    for step in range(steps):
+        ids = torch.randint(1, n_rows, (128, 150), generator=gen).to(torch.int32).cuda()
+        if step == 1:
+            ids = ids[:, :40]  # (step 2 leaves most of step 1's rows without a gradient: their momentum still moves them)
+        grad = torch.zeros(n_rows, dim, device="cuda")
+        grad.index_add_(0, ids.reshape(-1).long(), torch.randn(ids.numel(), dim, generator=gen).cuda())
+        gs = torch.randn(33, 7, generator=gen).cuda()
+        touched[ids.reshape(-1).long()] = True
+        for t, s_ in zip(tabs, smalls):
+            t.grad, s_.grad = grad.clone(), gs.clone()
+        assert masked.mark_rows(tabs[0], ids)
+        masked.step()
+        dense.step()
+        ref.step()
+    sm, sd, sr = masked.state[tabs[0]], dense.state[tabs[1]], ref.state[tabs[2]]
+    assert "row_touched" in sm and "row_touched" not in sd
+    assert torch.equal(sm["row_touched"].bool(), touched) and 0 < int(touched.sum()) < n_rows // 2
+    assert torch.equal(tabs[0], tabs[1]) and torch.equal(smalls[0], smalls[1])
+    assert torch.equal(sm["exp_avg"], sd["exp_avg"]) and torch.equal(sm["exp_avg_sq"], sd["exp_avg_sq"])
+    for w, st in ((tabs[0], sm), (tabs[1], sd), (tabs[2], sr)):
+        assert torch.equal(w[~touched], w0[~touched])
+        assert int(st["exp_avg"][~touched].count_nonzero()) == 0 and int(st["exp_avg_sq"][~touched].count_nonzero()) == 0
+    assert float((tabs[0] - tabs[2]).abs().max()) <= 2e-6 * steps
+    # a parameter of no group is refused instead of raising out of the step (frozen table / another optimizer's)
+    assert masked.mark_rows(torch.nn.Parameter(torch.zeros(8, 4, device="cuda")), ids) is False

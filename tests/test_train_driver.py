@@ -198,13 +198,25 @@ def test_checkpoints_are_state_dicts_and_a_run_resumes(tmp_path, monkeypatch):
     rows = [ln.strip().split(";") for f in os.listdir("run_b") if f.endswith(".csv") for ln in open(os.path.join("run_b", f))]
     assert [r[1] for r in rows if r[2] == "train"] == [str(ck["meta"]["epoch"] + 1)]  # exactly one more epoch was run
 
-    # a reference-style checkpoint (pickled module, train.py:124) still loads
+    # a reference-style checkpoint (pickled module, train.py:124) loads only when the caller opts in to unpickling it
     torch.save(model, "ref_style.pth")
     m4, _ = fresh()
     with torch.no_grad():
         for prm in m4.parameters():
             prm.add_(1.0)
-    load_checkpoint("ref_style.pth", m4, device="cuda")
+    with pytest.raises(Exception):
+        load_checkpoint("ref_style.pth", m4, device="cuda")
+    load_checkpoint("ref_style.pth", m4, device="cuda", allow_pickle=True)
+    # a run that resumes and never beats the stored NDCG still ends on the BEST weights: the checkpoint it resumed from
+    m5, o5 = fresh()
+    ck_best = dict(torch.load(os.path.join("run_a", ck_name), weights_only=True))
+    ck_best["meta"] = dict(ck_best["meta"], NDCG=2.0)  # unbeatable
+    torch.save(ck_best, "unbeatable.pth")
+    out = train(model=m5, train_loader=mk("train"), val_loader=mk("val"), test_loader=None, device="cuda", optim=o5,
+                epochs=ck["meta"]["epoch"] + 1, early_stop=20, datadir="run_c", verbose=0, resume="unbeatable.pth")
+    assert not [f for f in os.listdir("run_c") if f.endswith(".pth")]
+    for (k, a), (_, b) in zip(out.state_dict().items(), ck_best["model"].items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
     for (k, a), (_, b) in zip(m4.state_dict().items(), model.state_dict().items()):
         assert torch.equal(a, b), k
     save_checkpoint("plain.pth", m4)
