@@ -232,6 +232,8 @@ _i, _f = C.c_int, C.c_float
 SIGNATURES = {
     "carca_abi_version": (_i, []),
     "carca_set_tuning": (_i, [_i, _i]),
+    "carca_det_begin": (_i, [_fp, C.c_longlong, _fp, _fp]),
+    "carca_det_flush": (_i, [_fp, _fp, C.c_longlong, C.c_longlong, _fp]),
     "carca_set_debug_buffer": (_i, [_fp]),
     "carca_last_error": (C.c_char_p, []),
     "carca_padded_dims": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

@@ -82,7 +82,7 @@ def _grad_buffers(model, params, extra: int, id_lists, late=()):
     else:
         flat = torch.zeros(total, dtype=dt, device=dev)  # one fill launch for every gradient and staging area
     views = [flat[offs[i]: offs[i] + p.numel()].view(p.shape) for i, p in enumerate(params)]
-    model.__dict__["_flat_grad"] = dict(flat=flat, early=(0, n_early), late=(n_early, n_late),
+    model.__dict__["_flat_grad"] = dict(flat=flat, early=(0, n_early), late=(n_early, n_late), front=front,
                                         big=[params[i] for i in big], n_params=len(params))
     # (`big` names the parameters only: a second reference to a big table's view would make AccumulateGrad CLONE it --
     # it takes a gradient over as p.grad only while nobody else holds it -- i.e. a fresh 512 MB allocation + copy per
@@ -93,6 +93,30 @@ def _grad_buffers(model, params, extra: int, id_lists, late=()):
             ops.concat_ids(id_lists, c["dirty"])
 
     return views, flat[n_late:front], after
+
+
+class _det_pass:
+    """Deterministic mode (ops.set_deterministic): the pass's flat gradient buffer gets a zeroed int64 shadow of the same
+    length, kept on the model across steps (the flush leaves it zero), and the library accumulates into it instead of
+    issuing fp32 atomics (include/carca_hip.h: carca_det_begin).  A model with a big item table sweeps that table's
+    range too (dense: the mode trades the touched-row saving for reproducibility)."""
+
+    def __init__(self, model):
+        info = model.__dict__["_flat_grad"]
+        self.flat, self.info = info["flat"], info
+        sh = model.__dict__.get("_det_shadow")
+        if sh is None or sh.numel() != self.flat.numel() or sh.device != self.flat.device:
+            sh = torch.zeros(self.flat.numel(), dtype=torch.int64, device=self.flat.device)
+            model.__dict__["_det_shadow"] = sh
+        self.shadow = sh
+        ops.det_begin(self.flat, sh)
+
+    def flush_staging(self):
+        ops.det_flush(self.flat, self.shadow, self.info["late"][1], self.info["front"])
+
+    def finish(self):
+        ops.det_flush(self.flat, self.shadow, 0, self.flat.numel())
+        ops.det_begin(None, None)
 
 
 class _Tail:
@@ -320,6 +344,7 @@ class _CarcaFn(torch.autograd.Function):
         id_lists = [sg[0] for sg in st["segs"]] if hasattr(emb, "items_embed") and len(st["segs"]) <= 4 else None
         late = emb.late_grad_params(st["emb_saved"]) if hasattr(emb, "late_grad_params") else ()
         grads, tail_buf, after_pass = _grad_buffers(model, params, plan.staging_floats(), id_lists, late)
+        det = _det_pass(model) if ops.deterministic() else None
         plan.build(dev, _Tail(tail_buf))
         gbp = {id(p): g for p, g in zip(params, grads)}
         ys = ctx.saved_tensors
@@ -363,11 +388,15 @@ class _CarcaFn(torch.autograd.Function):
             dx = ops.mask_mul(dx, st["m_embed"], 1.0 / (1.0 - st["p_emb"]), d, dpi)
         des = [dx] + des_t                      # d e per segment, [rows, dpi]; profile rows still unmasked
         wg.launch()
+        if det is not None:  # (the staging areas are about to be READ: their accumulated sums out of the shadow first)
+            det.flush_staging()
         plan.unpack(gbp)  # head-padded staging areas -> the real WQ / WK / WV / ffn gradients
         if emb_wt_idx is not None:
             emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi, wj_t=plan.wT.view(emb_wt_idx))
         else:
             emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi)
+        if det is not None:
+            det.finish()
         after_pass()
         ctx.st = None
         return (None, None, None) + tuple(grads)

@@ -31,8 +31,76 @@ int carca_num_cus() {
   }
   return n;
 }
+// ---- deterministic gradient accumulation (carca_common.h: grad_add) ------------------------------------------------
+static carca_det_binder g_det_binders[64];
+static int g_det_nbinders = 0;
+static CarcaDetCtx* g_det_ctx = nullptr;  // device memory, allocated at the first switch-on, lives as long as the process
+void carca_det_register(carca_det_binder fn) {
+  if (g_det_nbinders < 64) g_det_binders[g_det_nbinders++] = fn;
+}
+namespace {
+__global__ void det_set_kernel(CarcaDetCtx* ctx, float* base, unsigned long long* shadow, long long n) {
+  ctx->base = base;
+  ctx->shadow = shadow;
+  ctx->n = n;
+  ctx->scale = (float)(1ull << CARCA_DET_SHIFT);
+  ctx->inv_scale = 1.0f / (float)(1ull << CARCA_DET_SHIFT);
+}
+__global__ __launch_bounds__(256) void det_flush_kernel(float* __restrict__ flat, unsigned long long* __restrict__ shadow,
+                                                        long long lo, long long hi) {
+  const double inv = 1.0 / (double)(1ull << CARCA_DET_SHIFT);
+  for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long long)gridDim.x * blockDim.x) {
+    const long long s = (long long)shadow[i];
+    if (s != 0) {
+      flat[i] += (float)((double)s * inv);
+      shadow[i] = 0;
+    }
+  }
+}
+}  // namespace
+static int det_switch(bool on) {
+  if (on && !g_det_ctx) {
+    hipError_t e = hipMalloc((void**)&g_det_ctx, sizeof(CarcaDetCtx));
+    if (e != hipSuccess) {
+      carca_set_error("set_tuning: cannot allocate the determinism context: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    e = hipMemset(g_det_ctx, 0, sizeof(CarcaDetCtx));
+    if (e != hipSuccess) return (int)e;
+  }
+  for (int i = 0; i < g_det_nbinders; ++i) {
+    const int rc = g_det_binders[i](on ? g_det_ctx : nullptr);
+    if (rc != 0) {
+      carca_set_error("set_tuning: cannot bind the determinism context: %s", hipGetErrorString((hipError_t)rc));
+      return rc;
+    }
+  }
+  return CARCA_OK;
+}
+extern "C" int carca_det_begin(float* flat, long long n, unsigned long long* shadow, void* stream) {
+  CARCA_CHECK_ARG(g_det_ctx && carca_tuning(CARCA_TUNE_DETERMINISTIC) != 0,
+                  "det_begin: the deterministic mode is off (carca_set_tuning(8, 1))");
+  CARCA_CHECK_ARG((flat && shadow && n > 0) || (!flat && !shadow), "det_begin: buffer, shadow and size go together");
+  hipLaunchKernelGGL(det_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g_det_ctx, flat, shadow, flat ? n : 0);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+extern "C" int carca_det_flush(float* flat, unsigned long long* shadow, long long lo, long long hi, void* stream) {
+  CARCA_CHECK_ARG(flat && shadow && lo >= 0 && hi >= lo, "det_flush: null buffer or bad range");
+  if (hi == lo) return CARCA_OK;
+  long long blocks = (hi - lo + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(det_flush_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, flat, shadow, lo, hi);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
 extern "C" int carca_set_tuning(int key, int value) {
   CARCA_CHECK_ARG(key >= 0 && key < CARCA_TUNE_COUNT, "set_tuning: unknown key %d", key);
+  if (key == CARCA_TUNE_DETERMINISTIC && (value != 0) != (g_tuning[key] != 0)) {
+    const int rc = det_switch(value != 0);
+    if (rc != CARCA_OK) return rc;
+  }
   g_tuning[key] = value;
   return CARCA_OK;
 }

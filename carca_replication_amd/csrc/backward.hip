@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     if (tid < 128 && tid < d) {
       const float sg = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
       const float sb = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
-      atomicAdd(&dgamma[tid], sg);
-      atomicAdd(&dbeta[tid], sb);
+      grad_add(&dgamma[tid], sg);
+      grad_add(&dbeta[tid], sb);
     }
   }
 }
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_pairs_kernel(const float* _
     }
     __syncthreads();
     if (tid < 128 && tid < d) {
-      atomicAdd(&dgamma[tid], red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid]);
-      atomicAdd(&dbeta[tid], red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid]);
+      grad_add(&dgamma[tid], red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid]);
+      grad_add(&dbeta[tid], red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid]);
     }
   }
 }
@@ -176,7 +176,7 @@ __global__ void embed_scatter_kernel(const float* __restrict__ dz, int ld_dz, co
     if (id == 0) continue;
     const float* src = dz + (size_t)row * ld_dz;
     float* dst = d_items + (size_t)id * d;
-    for (int c = lane; c < d; c += 64) atomicAdd(&dst[c], scale * src[c]);
+    for (int c = lane; c < d; c += 64) grad_add(&dst[c], scale * src[c]);
   }
 }
 
@@ -200,7 +200,7 @@ __global__ void embed_scatter_segs_kernel(ScatterSegs S, int ld_dz, int d, float
     if (id == 0) continue;
     const float* src = S.dz[s] + (size_t)r * ld_dz;
     float* dst = d_items + (size_t)id * d;
-    for (int c = lane; c < d; c += 64) atomicAdd(&dst[c], scale * src[c]);
+    for (int c = lane; c < d; c += 64) grad_add(&dst[c], scale * src[c]);
   }
 }
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
       if (ids && ids[row] == 0) w = 0.f;
       s += w * x[(size_t)row * ld_x + c];
     }
-    atomicAdd(&out[c], s);
+    grad_add(&out[c], s);
   } else {
     // one block per position t (grid.x == T): rows t, t+T, t+2T, ...
     const int t = blockIdx.x;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
       if (ids && ids[row] == 0) w = 0.f;
       s += w * x[(size_t)row * ld_x + c];
     }
-    atomicAdd(&out[(size_t)t * cols + c], s);
+    grad_add(&out[(size_t)t * cols + c], s);
   }
 }
 
@@ -528,7 +528,9 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
   float* DST = PT + ATT_LMAX * ATT_SP;   // [64][ATT_SP]
   float* dls = DST + ATT_LMAX * ATT_SP;  // [64] dlogit of the chunk
   float* wps = dls + 64;                 // [DPO] ffn weight, head-padded
-  float* dwp = wps + DPO;                // [DPO] its gradient, accumulated over the user's targets
+  float* dwp = wps + DPO;                // [NW][DPO] its gradient, accumulated over the user's targets: one slot per
+                                         // wave (the target tiles are dealt to the waves statically), summed in wave
+                                         // order at the end -- an LDS atomic would add in the order the waves arrive
 
   // heads shared by two workgroups when users <= CUs / 2 (see sa_attn_bwd_kernel); dlogit is written by the first
   const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
@@ -550,10 +552,8 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
     *reinterpret_cast<f32x4*>(Ks + r * SO + 4 * c4) = k;
     *reinterpret_cast<f32x4*>(Vs + r * SO + 4 * c4) = v;
   }
-  for (int i = tid; i < DPO; i += 512) {
-    wps[i] = ffn_w_pad[i];
-    dwp[i] = 0.f;
-  }
+  for (int i = tid; i < DPO; i += 512) wps[i] = ffn_w_pad[i];
+  for (int i = tid; i < NW * DPO; i += 512) dwp[i] = 0.f;
 
   const float sqrt_dh = sqrtf((float)dh);
   const int ln = lane & 15, mq = lane >> 4;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float v = row16_sum(acc[r] * dl);
-              if (ln == 0) atomicAdd(&dwp[h * DHP + 16 * ft + 4 * mq + r], v);
+              if (ln == 0) dwp[wave * DPO + h * DHP + 16 * ft + 4 * mq + r] += v;  // (this wave's own slot)
             }
           }
         }
@@ -655,7 +655,12 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
       first_pass = false;
     }
   }
-  for (int i = tid; i < DPO; i += 512) atomicAdd(&d_ffn_w_pad[i], dwp[i]);
+  for (int i = tid; i < DPO; i += 512) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += dwp[w * DPO + i];
+    grad_add(&d_ffn_w_pad[i], s);
+  }
 }
 
 template <int DPI, int DHP, int NH>
@@ -686,7 +691,7 @@ int launch_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids
                           const float* ffn_w_pad, float* dkh, float* dvh, float* d_ffn_w_pad, int B, int L, int d,
                           int training, float dscale, hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
-  const size_t lds_bytes = sizeof(float) * (3 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP + 64 + 2 * G::DPO);
+  const size_t lds_bytes = sizeof(float) * (3 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP + 64 + (1 + 8) * G::DPO);
   auto kern = cross_attn_bwd_kernel<DPI, DHP, NH>;
   static bool attr_set = false;
   if (!attr_set) {

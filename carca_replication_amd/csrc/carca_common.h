@@ -111,6 +111,49 @@ __device__ __forceinline__ int unpad_feature(int fp, int dh, int dhp) {
   return r < dh ? h * dh + r : -1;
 }
 
+// ---- deterministic gradient accumulation (carca_set_tuning(CARCA_TUNE_DETERMINISTIC, 1); api.hip) ----------------
+// fp32 atomics make a gradient's last bits follow the order in which workgroups happen to arrive (and Adam turns a
+// round-off-sized difference of a near-cancelling sum into a +-lr step).  Under the mode every accumulation into the
+// backward's flat gradient buffer goes, as a 64-bit FIXED-POINT integer (value x 2^CARCA_DET_SHIFT, round to nearest),
+// into a shadow buffer of the same geometry: integer addition is associative, so the sum does not depend on the order,
+// bit for bit.  carca_det_flush adds the shadow into the fp32 buffer (one rounding per element) and clears it.
+// Resolution 2^-36 = 1.5e-11 per contribution (an fp32 ulp at 1e-4), range +-1.3e8.  Addresses outside the registered
+// buffer keep the plain fp32 atomic.
+struct CarcaDetCtx {
+  float* base;                 // the flat gradient buffer of the pass in flight (null: between passes)
+  unsigned long long* shadow;  // n 64-bit accumulators
+  long long n;
+  float scale, inv_scale;
+};
+#define CARCA_DET_SHIFT 36
+namespace {
+__device__ const CarcaDetCtx* g_carca_det = nullptr;  // one copy per translation unit, all bound to the same context (api.hip)
+}
+__device__ __forceinline__ void grad_add(float* p, float v) {
+  const CarcaDetCtx* c = g_carca_det;
+  if (__builtin_expect(c != nullptr, 0)) {
+    float* const base = c->base;
+    const long long off = p - base;
+    if (base && off >= 0 && off < c->n) {
+      atomicAdd(c->shadow + off, (unsigned long long)__float2ll_rn(v * c->scale));
+      return;
+    }
+  }
+  atomicAdd(p, v);
+}
+// every translation unit that includes this header registers a binder for its own copy of the symbol
+typedef int (*carca_det_binder)(const CarcaDetCtx*);
+void carca_det_register(carca_det_binder fn);
+namespace {
+int carca_det_bind_this_tu(const CarcaDetCtx* ctx) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_carca_det), &ctx, sizeof(ctx), 0, hipMemcpyHostToDevice);
+}
+struct CarcaDetRegistrar {
+  CarcaDetRegistrar() { carca_det_register(&carca_det_bind_this_tu); }
+};
+CarcaDetRegistrar g_carca_det_registrar;
+}  // namespace
+
 // error codes of the C ABI (include/carca_hip.h)
 #define CARCA_OK 0
 #define CARCA_ERR_UNSUPPORTED (-1)
@@ -158,7 +201,8 @@ __device__ __forceinline__ void carca_gather_rows(const CarcaGatherArgs& ga, int
 
 // tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice.
 // Keys 3..5 are used by number (see include/carca_hip.h).
-enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_COUNT = 8 };
+enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_DETERMINISTIC = 8,
+       CARCA_TUNE_COUNT = 10 };
 int carca_tuning(int key);
 int carca_num_cus();  // compute units of the current device (cached)
 // Timing events for this thread's NEXT row-GEMM launch (the roofline hooks of carca_forward): the launch binds them to

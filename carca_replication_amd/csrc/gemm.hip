@@ -921,11 +921,11 @@ __device__ __forceinline__ void wgrad_body(const WgradDev& args, int b) {
           if (args.diag_plain_store)
             D.dw[(size_t)n * D.ldw + kcol] = acc[t][r];
           else
-            atomicAdd(&D.dw[(size_t)n * D.ldw + kcol], acc[t][r]);
+            grad_add(&D.dw[(size_t)n * D.ldw + kcol], acc[t][r]);
         }
       }
   }
-  if (D.db && kb == 0 && tid < BNO && n0 + tid < D.N) atomicAdd(&D.db[n0 + tid], bsum);
+  if (D.db && kb == 0 && tid < BNO && n0 + tid < D.N) grad_add(&D.db[n0 + tid], bsum);
 }
 
 template <int BNO, int BKO, int BR, bool BUF = false>

@@ -82,6 +82,49 @@ __global__ void rank_kernel(const float* __restrict__ y, int B, int N, int k, co
   }
 }
 
+// The same sums in a FIXED order (deterministic mode, carca_set_tuning(8, 1)): one block, wave w takes users w, w + 16, ...
+// in turn, the sixteen partial sums are added in wave order and the block adds ONE term to each of the caller's sums --
+// the NDCG sum of the kernel above follows the order in which the waves' atomics arrive (last-bit differences run to run).
+__global__ __launch_bounds__(1024) void rank_ordered_kernel(const float* __restrict__ y, int B, int N, int k,
+                                                            const int32_t* __restrict__ pos, int32_t* __restrict__ rank,
+                                                            float* __restrict__ sums) {
+  __shared__ float red[3][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float hr = 0.f, nd = 0.f, ties = 0.f;
+  for (int u = wave; u < B; u += 16) {
+    const float* yr = y + (size_t)u * N;
+    const int pc = pos ? pos[u] : 0;
+    const float y0 = yr[pc];
+    float gt = 0.f, eq = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      if (j == pc) continue;
+      const float v = yr[j];
+      gt += v > y0 ? 1.f : 0.f;
+      eq += v == y0 ? 1.f : 0.f;
+    }
+    gt = wave_sum(gt);
+    eq = wave_sum(eq);
+    const int r = (int)gt;
+    if (rank && lane == 0) rank[u] = r;
+    if (r < k) {
+      hr += 1.0f;
+      nd += 1.0f / log2f((float)r + 2.0f);
+    }
+    ties += eq;
+  }
+  if (lane == 0) {
+    red[0][wave] = hr;
+    red[1][wave] = nd;
+    red[2][wave] = ties;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[threadIdx.x][w];
+    if (s != 0.f) sums[threadIdx.x] += s;  // (launches on one stream are ordered: a plain read-modify-write)
+  }
+}
+
 }  // namespace
 
 extern "C" int carca_bce_fwd(const float* y, const int32_t* y_true, const int32_t* ids, int n, float eps,
@@ -97,6 +140,11 @@ extern "C" int carca_rank_metrics(const float* y, int B, int N, int k, const int
                                   void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(y && sums && B >= 1 && N >= 1 && k >= 1, "rank_metrics: null pointer or bad dims");
+  if (carca_tuning(CARCA_TUNE_DETERMINISTIC) != 0) {
+    hipLaunchKernelGGL(rank_ordered_kernel, dim3(1), dim3(1024), 0, stream, y, B, N, k, pos, rank, sums);
+    CARCA_LAUNCH_CHECK();
+    return CARCA_OK;
+  }
   const int blocks = (B + 3) / 4;
   hipLaunchKernelGGL(rank_kernel, dim3(blocks), dim3(256), 0, stream, y, B, N, k, pos, rank, sums);
   CARCA_LAUNCH_CHECK();

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(DPI / 16 * 2 * 64) void row_chain_bwd_kernel(const 
   dg = quad4_sum(dg);
   db = quad4_sum(db);
   if (mq == 0 && n_ok) {
-    atomicAdd(&a.g_ln_w[n], dg);
-    atomicAdd(&a.g_ln_b[n], db);
+    grad_add(&a.g_ln_w[n], dg);
+    grad_add(&a.g_ln_b[n], db);
   }
   RC_STAMP(7);
 #undef RC_STAMP

@@ -308,10 +308,10 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = n0 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (n < D.N) atomicAdd(&D.dw[(size_t)n * D.ldw + kcol], acc[tt][r]);
+          if (n < D.N) grad_add(&D.dw[(size_t)n * D.ldw + kcol], acc[tt][r]);
         }
     }
-    if (do_db && n0 + x_c4 < D.N) atomicAdd(&D.db[n0 + x_c4], bsum);
+    if (do_db && n0 + x_c4 < D.N) grad_add(&D.db[n0 + x_c4], bsum);
   }
   if constexpr (DBG) {
     unsigned long long* dbg = carca_debug_ptr(args);

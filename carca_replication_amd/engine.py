@@ -68,7 +68,8 @@ def train_step(model, optim, batch, sharded: bool = False, global_batch: Optiona
         # kernel: an event recorded right before that launch (CarcaEmbedBwdDesc.ev_early) gates a side stream, RCCL's
         # own stream queues behind the side stream, and the call returns to issue the late range behind the kernel.
         denom = cdist.global_mask_count(o_x)
-        ev = _early_event() if p_x.is_cuda else None
+        # (deterministic mode: the early range's sums sit in the fixed-point shadow until the pass ends -- no early start)
+        ev = _early_event() if p_x.is_cuda and not ops.deterministic() else None
         ops.early_event = ev
         try:
             loss = _forward_backward(model, optim, batch, denom)

@@ -1002,6 +1002,40 @@ def _id_lists(id_lists):
     return keep, ptrs, counts, n
 
 
+# --------------------------------------------------------------------------------------------------
+# deterministic mode (include/carca_hip.h, tuning key 8): same inputs => same bits, run to run
+# --------------------------------------------------------------------------------------------------
+TUNE_DETERMINISTIC = 8
+_deterministic = False
+
+
+def set_deterministic(on: bool) -> None:
+    """No fp32 atomics in the backward pass from here on: gradient accumulations go through a 64-bit fixed-point shadow
+    of the pass's gradient buffer (order-independent integer sums), HR / NDCG sums are added in a fixed order.  A few
+    per cent slower (one extra sweep over the gradient buffer per step); gradients differ from the default path's by
+    fp32 round-off only.  Off by default -- torch's own CUDA backward is not deterministic either."""
+    global _deterministic
+    _lib.check(_lib.load().carca_set_tuning(TUNE_DETERMINISTIC, 1 if on else 0), "set_tuning")
+    _deterministic = bool(on)
+
+
+def deterministic() -> bool:
+    return _deterministic
+
+
+def det_begin(flat: Optional[Tensor], shadow: Optional[Tensor]) -> None:
+    if flat is None:
+        _lib.check(_lib.load().carca_det_begin(None, 0, None, _stream()), "det_begin")
+        return
+    if shadow.dtype != torch.int64 or shadow.numel() < flat.numel() or not shadow.is_contiguous():
+        raise CarcaHipError("det_begin: the shadow must be a contiguous int64 tensor of the gradient buffer's length")
+    _lib.check(_lib.load().carca_det_begin(flat.data_ptr(), flat.numel(), shadow.data_ptr(), _stream()), "det_begin")
+
+
+def det_flush(flat: Tensor, shadow: Tensor, lo: int, hi: int) -> None:
+    _lib.check(_lib.load().carca_det_flush(flat.data_ptr(), shadow.data_ptr(), int(lo), int(hi), _stream()), "det_flush")
+
+
 def mark_rows(mask: Tensor, ids: Tensor) -> None:
     """mask[ids] = 1 (uint8 row mask of an embedding table: CarcaAdamTensor.row_mask)."""
     ids32 = _ids32(ids.reshape(-1))

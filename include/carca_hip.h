@@ -49,8 +49,20 @@ int carca_abi_version(void);
  *          for batches of more users than CUs, two workgroups resident per CU)
  *   key 2  weight gradient: row-split slot target      key 4  minimum 32-row chunks per split
  *   key 3  weight gradient: plain stores instead of atomics (timing diagnostic, wrong results)
- *   key 5  grouped weight gradient: row-split slot target per product */
+ *   key 5  grouped weight gradient: row-split slot target per product
+ *   key 8  DETERMINISTIC MODE (1 = on): no fp32 atomics anywhere in the backward pass -- every accumulation into the
+ *          pass's gradient buffer (weight gradients, LayerNorm gamma / beta, bias sums, the embedding scatter-add) goes
+ *          into a 64-bit fixed-point shadow buffer (carca_det_begin / carca_det_flush below), whose integer sums do not
+ *          depend on the order in which workgroups arrive; HR / NDCG sums are added in a fixed order by one block.
+ *          Same inputs => same bits, run to run.  Reference: none (torch's CUDA backward has the same nondeterminism:
+ *          index_add / atomicAdd in embedding_dense_backward); it exists so that trajectory tests can be tight. */
 int carca_set_tuning(int key, int value);
+/* Deterministic mode, per backward pass: register the pass's flat fp32 gradient buffer `flat` (n floats) and its shadow
+ * (n uint64, ZERO on entry); kernels launched on `stream` afterwards accumulate gradients that land inside `flat` into
+ * the shadow.  carca_det_flush(lo, hi) adds shadow[lo:hi] / 2^36 into flat[lo:hi] and clears it -- before anything
+ * READS an accumulated range and at the end of the pass.  carca_det_begin(NULL, 0, NULL) ends the pass. */
+int carca_det_begin(float* flat, long long n, unsigned long long* shadow, void* stream);
+int carca_det_flush(float* flat, unsigned long long* shadow, long long lo, long long hi, void* stream);
 /* Diagnostic runs only: device buffer (>= 16 x #workgroups uint64) that the attention kernels fill with
  * s_memtime stamps at their phase boundaries; NULL (default) disables stamping. */
 int carca_set_debug_buffer(void* device_ptr);
