@@ -76,8 +76,15 @@ def _grad_buffers(model, params, extra: int, id_lists, late=()):
         flat = c["flat"]
         if not c["fresh"]:
             flat[:front].zero_()
+            # rows to clear: the ones this rank's last pass scattered into, and -- users sharded over ranks -- the ones the
+            # row exchange added for the OTHER ranks' users (engine.note_exchanged_rows; found by tools/two_rank_check.py:
+            # without them a rank's step-1 gradient still carried the other rank's step-0 rows)
+            lists = [c["dirty"]]
+            foreign = model.__dict__.get("_grad_foreign")
+            if foreign is not None:
+                lists.append(foreign)
             for i in big:
-                ops.zero_rows(flat[offs[i]: offs[i] + params[i].numel()].view(params[i].shape), [c["dirty"]])
+                ops.zero_rows(flat[offs[i]: offs[i] + params[i].numel()].view(params[i].shape), lists)
         c["fresh"] = False
     else:
         flat = torch.zeros(total, dtype=dt, device=dev)  # one fill launch for every gradient and staging area

@@ -87,6 +87,7 @@ def train_step(model, optim, batch, sharded: bool = False, global_batch: Optiona
                 early = cdist.allreduce_range(info["flat"], *info["early"])
         gathered = cdist.allreduce_gradients(params, sparse_rows=_sparse_tables(model, p_x, o_x), flat_info=info,
                                              early_work=early, sparse_pad_to=_row_exchange_len(p_x, o_x, global_batch))
+        note_exchanged_rows(model, gathered)
     _mark_touched_rows(model, optim, p_x, o_x, gathered)
     optim.step()
     return loss
@@ -106,6 +107,23 @@ def _side_stream(device):
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
+
+
+def note_exchanged_rows(model, gathered: Optional[dict], into: Optional[torch.Tensor] = None) -> None:
+    """A big item table's cached gradient buffer is cleared ROW-WISE before the next pass (autograd._grad_buffers) -- of
+    the rows this rank scattered into.  The row exchange of a sharded step adds the other ranks' rows to it: tell the
+    cache (model._grad_foreign, int32 ids).  into: a fixed buffer to copy the ids into (the hipGraph step: the captured
+    clearing launch reads that buffer), padded with the pad row's id 0."""
+    if not gathered:
+        return
+    ids = torch.cat([v.reshape(-1) for v in gathered.values() if v is not None]).to(torch.int32)
+    if into is None:
+        model.__dict__["_grad_foreign"] = ids
+        return
+    if ids.numel() > into.numel():
+        raise ValueError(f"note_exchanged_rows: {ids.numel()} exchanged ids, the captured step was sized for {into.numel()}")
+    into.zero_()
+    into[: ids.numel()].copy_(ids)
 
 
 def _mark_touched_rows(model, optim, p_x, o_x, gathered: Optional[dict] = None) -> None:
@@ -170,6 +188,13 @@ class GraphedTrainStep:
         self.denom = torch.ones(1, dtype=torch.float32, device=self.inputs[0].device) if sharded else None
         if sharded:
             self.denom.copy_(cdist.global_mask_count(self.inputs[3]))
+        self.foreign = None
+        if sharded and cdist._active() and _sparse_tables(model, self.inputs[0], self.inputs[3]):
+            # (a big item table: the exchanged rows of every rank, cleared by the captured pass -- see note_exchanged_rows)
+            per_rank = _row_exchange_len(self.inputs[0], self.inputs[3], global_batch) or \
+                (self.inputs[0].numel() + self.inputs[3].numel())
+            self.foreign = torch.zeros(cdist.world_size() * per_rank, dtype=torch.int32, device=self.inputs[0].device)
+            model.__dict__["_grad_foreign"] = self.foreign
         self.replays = torch.zeros(1, dtype=torch.int64, device=self.inputs[0].device)
         ops.set_dropout_seed_offset(self.replays)
         try:
@@ -210,6 +235,9 @@ class GraphedTrainStep:
                 self.params, sparse_rows=_sparse_tables(self.model, self.inputs[0], self.inputs[3]),
                 flat_info=cdist.flat_layout(self.model, self.params),
                 sparse_pad_to=_row_exchange_len(self.inputs[0], self.inputs[3], self.global_batch))
+            if self.foreign is not None:
+                self.model.__dict__["_grad_foreign"] = self.foreign
+                note_exchanged_rows(self.model, gathered, into=self.foreign)
         note_training_forward()  # the optimizer below rewrites the weights: packed inference copies are stale
         _mark_touched_rows(self.model, self.optim, self.inputs[0], self.inputs[3], gathered)
         self.optim.step()

@@ -69,9 +69,11 @@ class Adam(torch.optim.Optimizer):
 
     def state_dict(self):
         sd = super().state_dict()
-        for st in sd["state"].values():  # (the group's entries share ONE step tensor here; torch's format has one each)
-            if "step" in st:
-                st["step"] = st["step"].clone()
+        # The group's entries share ONE step tensor here; torch's format has one each.  The per-parameter dicts torch
+        # hands back ARE this optimizer's own state dicts: build new ones -- writing the clone into them cut the live
+        # state off the shared counter, and every later state_dict() (a checkpoint) reported the step count of the
+        # first call (found by tools/two_rank_check.py: a resumed optimizer took its next step with a stale bias correction).
+        sd["state"] = {k: (dict(st, step=st["step"].clone()) if "step" in st else st) for k, st in sd["state"].items()}
         return sd
 
     @torch.no_grad()

@@ -75,6 +75,31 @@ def test_adam_state_dict_interchangeable_with_torch():
         assert float((p2 - q).abs().max()) <= 1e-6
 
 
+def test_state_dict_reports_the_live_step_count_every_time():
+    """A checkpoint taken mid-run must not cut the optimizer's state off its own step counter: state_dict() after 2, 4
+    and 5 steps reports 2, 4 and 5 (the first version cloned the step tensor INTO the live state, and every later
+    checkpoint carried the step count of the first one: a resumed run took its next step with a stale bias correction)."""
+    from carca_replication_amd.optim import Adam
+
+    a, _ = _pair([(17, 9), (130,)], 6)
+    opt = Adam(a, lr=1e-3, betas=(0.9, 0.98))
+    seen = []
+    for n_steps in (2, 2, 1):
+        for _ in range(n_steps):
+            for p in a:
+                p.grad = torch.ones_like(p)
+            opt.step()
+        sd = opt.state_dict()
+        seen.append([float(st["step"]) for st in sd["state"].values()])
+        assert all(float(opt.state[p]["step"]) == seen[-1][0] for p in a)
+    assert seen == [[2.0, 2.0], [4.0, 4.0], [5.0, 5.0]]
+    # the snapshots are copies: stepping on does not move them
+    for p in a:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert [float(st["step"]) for st in sd["state"].values()] == [5.0, 5.0]
+
+
 def test_adam_skips_parameters_without_gradient_and_rejects_bad_input():
     from carca_replication_amd.optim import Adam
     from carca_replication_amd.ops import CarcaHipError
