@@ -453,13 +453,256 @@ def bce_with_grad(y_pred, y_true, mask, eps, denom=None, ids=None):
     return _BceFn.apply(y_pred, y_true, mask != 0, eps, denom)
 
 
-def embed_with_grad(module, x, a, c, target):
-    raise CarcaHipError("training through a stand-alone AllEmbedding is not built; train through CARCA.forward")
+# ----------------------------------------------------------------------------------------------------------------
+# torch.autograd through the STAND-ALONE modules (abstract.py:8-50: every block / embedding / encoding of the reference
+# is an ordinary differentiable nn.Module).  Training of the hot path goes through _CarcaFn above; these wrap the same
+# per-module backward entry points (carca_sa_block_bwd, carca_cross_score_bwd, carca_embed_bwd, ...) for a caller who
+# composes the modules himself.  Gradients: parameters, and the activations x / o / p (not ids, attrs, ctx).
+# ----------------------------------------------------------------------------------------------------------------
+def _standalone_pass(module, params, plan: _PackPlan, id_lists=None, late=()):
+    """Gradient buffers (one flat zero-filled buffer, autograd._grad_buffers) + the pack plan's copies for one module."""
+    grads, tail_buf, after = _grad_buffers(module, params, plan.staging_floats(), id_lists, late)
+    det = _det_pass(module) if ops.deterministic() else None
+    plan.build(params[0].device, _Tail(tail_buf))
+    return grads, {id(p): g for p, g in zip(params, grads)}, det, after
+
+
+def _pad_to(t: Tensor, width: int) -> Tensor:
+    if t.shape[-1] == width and t.is_contiguous():
+        return t
+    out = t.new_zeros(*t.shape[:-1], width)
+    out[..., : t.shape[-1]] = t
+    return out
+
+
+class _SaBlockFn(torch.autograd.Function):
+    """SelfAttentionBlock.forward (carca.py:297-318) with its saved tensors; backward = carca_sa_block_bwd."""
+
+    @staticmethod
+    def forward(ctx, module, x, ids, *params):
+        d, H = module.attn.d, module.attn.H
+        dpi, _, _ = ops.padded_dims(d, H)
+        B, L = x.shape[0], x.shape[1]
+        xp = _pad_to(x.detach()[..., :d], dpi)
+        p = module.drop_p()
+        y, saved = ops.sa_block_fwd(xp, ids, module.weights_struct(x.device), d, H, module.residual, save=True,
+                                    drop=(p, ops.new_dropout_seed(), 0) if p > 0 else None)
+        ctx.module, ctx.params, ctx.saved, ctx.ids, ctx.xp, ctx.p = module, params, saved, ids, xp, p
+        ctx.geom = (B, L, d, H, dpi, x.shape[-1])
+        return y[..., :d]
+
+    @staticmethod
+    def backward(ctx, dy):
+        module, params, sv = ctx.module, ctx.params, ctx.saved
+        B, L, d, H, dpi, x_cols = ctx.geom
+        plan = _PackPlan()
+        bp = plan.add_attn(module.attn, [ops.PackItem(module.ffn_1.weight[:, :, 0], dpi, dpi, transposed=True),
+                                         ops.PackItem(module.ffn_2.weight[:, :, 0], dpi, dpi, transposed=True)])
+        grads, gbp, det, _ = _standalone_pass(module, params, plan)
+        g = lambda q: gbp[id(q)]  # noqa: E731
+        wg = ops.WgradGroup()
+        dx = ops.sa_block_bwd(
+            _pad_to(dy, dpi).view(-1, dpi), ctx.ids, sv, ctx.xp.view(-1, dpi), (bp.wT(0), bp.wT(1), bp.wT(2), bp.wT(3), bp.wT(4)),
+            (module.norm1.weight.detach(), module.norm2.weight.detach()),
+            dict(g_w1=g(module.ffn_1.weight), g_b1=g(module.ffn_1.bias), g_w2=g(module.ffn_2.weight), g_b2=g(module.ffn_2.bias),
+                 g_wq=bp.g(0), g_wk=bp.g(1), g_wv=bp.g(2), g_bq=bp.g(3), g_bk=bp.g(4), g_bv=bp.g(5),
+                 g_ln1_w=g(module.norm1.weight), g_ln1_b=g(module.norm1.bias), g_ln2_w=g(module.norm2.weight),
+                 g_ln2_b=g(module.norm2.bias)),
+            B, L, d, H, module.residual, ctx.p, wg)
+        wg.launch()
+        if det is not None:
+            det.flush_staging()
+        plan.unpack(gbp)
+        if det is not None:
+            det.finish()
+        dxo = dx.view(B, L, dpi)[..., :d]
+        if x_cols != d:
+            dxo = _pad_to(dxo, x_cols)
+        return (None, dxo, None) + tuple(grads)
 
 
 def sa_block_with_grad(module, x, mask):
-    raise CarcaHipError("training through a stand-alone SelfAttentionBlock is not built; train through CARCA.forward")
+    from .modules import cached_parameters, note_training_forward
+
+    note_training_forward()
+    ops._need_cuda(x, mask)
+    return _SaBlockFn.apply(module, x, mask != 0, *cached_parameters(module))
+
+
+class _CrossFn(torch.autograd.Function):
+    """CrossAttentionBlock.forward (carca.py:338-349) on an already normed profile; backward = carca_cross_score_bwd
+    without its final-LayerNorm stage."""
+
+    @staticmethod
+    def forward(ctx, module, o, o_ids, p, p_ids, *params):
+        d, H = module.attn.d, module.attn.H
+        dpi, _, _ = ops.padded_dims(d, H)
+        B, N = o.shape[0], o.shape[1]
+        L = p.shape[1]
+        op_, pp = _pad_to(o.detach()[..., :d], dpi), _pad_to(p.detach()[..., :d], dpi)
+        cw = module.weights_struct(o.device, None)
+        pd = module.drop_p()
+        (y,), p_normed, csave = ops.cross_score_fwd(pp, p_ids, [(op_, o_ids)], cw, d, H, module.residual, module.training,
+                                                    save=True, drop=(pd, ops.new_dropout_seed(), 0) if pd > 0 else None)
+        ctx.module, ctx.params, ctx.csave, ctx.cw, ctx.pd = module, params, csave, cw, pd
+        ctx.t = (op_, o_ids, p_ids, p_normed, module.training)
+        ctx.geom = (B, N, L, d, H, dpi, o.shape[-1], p.shape[-1])
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        module, params, cs = ctx.module, ctx.params, ctx.csave
+        (y,) = ctx.saved_tensors
+        B, N, L, d, H, dpi, o_cols, p_cols = ctx.geom
+        op_, o_ids, p_ids, p_normed, training = ctx.t
+        plan = _PackPlan()
+        cp = plan.add_attn(module.attn, [])
+        wpad = plan.add_staging(ops.PackItem(module.ffn.weight, 1, cp.dpo, col_heads=(cp.dh, cp.dhp)), module.ffn.weight)
+        grads, gbp, det, _ = _standalone_pass(module, params, plan)
+        g = lambda q: gbp[id(q)]  # noqa: E731
+        masks = cs.get("m_attn") if ctx.pd > 0 else None
+        wg = ops.WgradGroup()
+        dp, des = ops.cross_score_bwd(
+            [(cs["qh"][0], y, dy.contiguous(), o_ids, op_.view(-1, dpi), masks[0] if masks is not None else None)], p_ids,
+            cs["kh"], cs["vh"], p_normed, None, (cp.wT(0), cp.wT(1), cp.wT(2)), ctx.cw.ffn_w_pad, module.ffn.weight.detach(), None,
+            dict(g_ffn_w=g(module.ffn.weight), g_ffn_b=g(module.ffn.bias), g_ffn_w_pad=plan.g.view(wpad).view(-1), g_wq=cp.g(0),
+                 g_wk=cp.g(1), g_wv=cp.g(2), g_bq=cp.g(3), g_bk=cp.g(4), g_bv=cp.g(5)),
+            B, L, d, H, module.residual, training, ctx.pd, wg)
+        wg.launch()
+        if det is not None:
+            det.flush_staging()
+        plan.unpack(gbp)
+        if det is not None:
+            det.finish()
+        do = des[0].view(B, N, dpi)[..., :d]
+        dpo_ = dp.view(B, L, dpi)[..., :d]
+        return (None, do if o_cols == d else _pad_to(do, o_cols), None, dpo_ if p_cols == d else _pad_to(dpo_, p_cols), None) + \
+            tuple(grads)
 
 
 def cross_with_grad(module, o, o_mask, p, p_mask):
-    raise CarcaHipError("training through a stand-alone CrossAttentionBlock is not built; train through CARCA.forward")
+    from .modules import cached_parameters, note_training_forward
+
+    note_training_forward()
+    ops._need_cuda(o, o_mask, p, p_mask)
+    y = _CrossFn.apply(module, o, o_mask != 0, p, p_mask != 0, *cached_parameters(module))
+    return y.squeeze()  # bare squeeze, as carca.py:346
+
+
+class _EmbedFn(torch.autograd.Function):
+    """Embedding.forward (carca.py:85-95 and the ablation variants) for one segment; backward = the module's
+    embed_backward (carca_embed_bwd for AllEmbedding)."""
+
+    @staticmethod
+    def forward(ctx, module, x, a, c, target, *params):
+        d = module.d
+        dpi, _, _ = ops.padded_dims(d, 1)
+        seg = (x, a, c, bool(target))
+        (e,), saved = module.embed_segments([seg], ld_e=dpi)
+        ctx.module, ctx.params, ctx.seg, ctx.saved, ctx.dpi = module, params, seg, saved, dpi
+        return e[..., :d]
+
+    @staticmethod
+    def backward(ctx, de):
+        module, params, seg, dpi = ctx.module, ctx.params, ctx.seg, ctx.dpi
+        x = seg[0]
+        late = module.late_grad_params(ctx.saved) if hasattr(module, "late_grad_params") else ()
+        ids = [x] if hasattr(module, "items_embed") else None
+        grads, gbp, det, after = _standalone_pass(module, params, _PackPlan(), ids, late)
+        module.embed_backward([_pad_to(de, dpi).view(-1, dpi)], [seg], ctx.saved, gbp, x.shape[1], dpi)
+        if det is not None:
+            det.finish()
+        after()
+        return (None, None, None, None, None) + tuple(grads)
+
+
+def embed_with_grad(module, x, a, c, target):
+    from .modules import cached_parameters, note_training_forward
+
+    if any(t is not None and t.requires_grad for t in (a, c)):
+        raise CarcaHipError("gradients with respect to attrs / ctx are not produced")
+    note_training_forward()
+    return _EmbedFn.apply(module, x, a, c, target, *cached_parameters(module))
+
+
+class _AddPosFn(torch.autograd.Function):
+    """Encoding.forward (carca.py:25-31, 54-60): x + table[:T]; d table[t] = sum over users of dy[:, t]."""
+
+    @staticmethod
+    def forward(ctx, x, table):
+        ctx.needs = (x.requires_grad, table.requires_grad)
+        return ops.add_positions(x.detach(), table.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        dtab = None
+        if ctx.needs[1]:
+            B, T, d = dy.shape
+            dtab = torch.zeros(T, d, dtype=torch.float32, device=dy.device)
+            ops.colsum(dy.contiguous().view(B * T, d), d, dtab, T=T)
+        return (dy if ctx.needs[0] else None), dtab
+
+
+def add_positions_with_grad(x, table):
+    return _AddPosFn.apply(x, table)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the row GEMM (MultiHeadAttention's stand-alone projections, carca.py:238-240)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        rows = x.detach().reshape(-1, x.shape[-1])
+        (y,) = ops.gemm_rows([dict(a0=ops._f32(rows).contiguous())], w.detach(), w.shape[0], w.shape[1], w.shape[0],
+                             bias=b.detach())
+        ctx.save_for_backward(x.detach(), w.detach())
+        ctx.needs = (x.requires_grad, w.requires_grad, b.requires_grad)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        n_out, n_in = w.shape
+        dy2 = dy.contiguous().view(-1, n_out)
+        dx = dw = db = None
+        if ctx.needs[0]:
+            (dx2,) = ops.gemm_rows([dict(a0=dy2)], w.t().contiguous(), n_in, n_out, n_in)
+            dx = dx2.view(*x.shape)
+        if ctx.needs[1] or ctx.needs[2]:
+            dw = torch.zeros_like(w)
+            db = torch.zeros(n_out, dtype=torch.float32, device=w.device)
+            ops.gemm_wgrad([dict(dy=dy2, x=x.reshape(-1, n_in).contiguous())], n_out, n_in, dw, db)
+        return dx, dw, db
+
+
+class _MhaCoreFn(torch.autograd.Function):
+    """The attention core of MultiHeadAttention.forward (carca.py:242-260) on projected q, k, v; differentiable in the
+    merged heads AND in the returned weights (return_w hands them out before dropout, carca.py:262-263)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, q_ids, k_ids, H, causal, want_w):
+        out, w = ops.mha_core(q.detach(), k.detach(), v.detach(), q_ids, k_ids, H, causal, want_w)
+        ctx.save_for_backward(q.detach(), k.detach(), v.detach())
+        ctx.t = (q_ids, k_ids, H, causal)
+        if want_w:
+            return out, w
+        ctx.mark_non_differentiable()
+        return out, None
+
+    @staticmethod
+    def backward(ctx, d_out, d_w):
+        q, k, v = ctx.saved_tensors
+        q_ids, k_ids, H, causal = ctx.t
+        if d_out is None and d_w is None:
+            return (None,) * 8
+        dq, dk, dv = ops.mha_core_bwd(q, k, v, q_ids, k_ids, H, causal, d_out, d_w)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def mha_with_grad(module, query, key, value, q_mask, k_mask, causal, return_w):
+    q = _LinearFn.apply(query, module.WQ.weight, module.WQ.bias)
+    k = _LinearFn.apply(key, module.WK.weight, module.WK.bias)
+    v = _LinearFn.apply(value, module.WV.weight, module.WV.bias)
+    out, w = _MhaCoreFn.apply(q, k, v, q_mask != 0, k_mask != 0, module.H, causal, bool(return_w))
+    return (w, out) if return_w else out

@@ -182,11 +182,15 @@ extern "C" int carca_cross_score_bwd(const CarcaCrossBwdDesc* D, CarcaWgradDesc*
   CARCA_CHECK_ARG(D->B >= 1 && D->L >= 1 && D->d >= 1 && D->H >= 1 && D->d % D->H == 0 && D->ngroups >= 1 &&
                       D->ngroups <= CARCA_MAX_GROUPS && D->drop_p >= 0.f && D->drop_p < 1.f,
                   "cross_score_bwd: bad dims");
-  CARCA_CHECK_ARG(D->p_ids && D->kh && D->vh && D->p_normed && D->enc_out && D->wq_t && D->wk_t && D->wv_t &&
-                      D->ffn_w_pad && D->ffn_w && D->norm_w && D->g_ffn_w && D->g_ffn_b && D->g_ffn_w_pad && D->g_wq &&
-                      D->g_wk && D->g_wv && D->g_bq && D->g_bk && D->g_bv && D->g_norm_w && D->g_norm_b &&
-                      D->workspace && D->dx,
+  CARCA_CHECK_ARG(D->p_ids && D->kh && D->vh && D->p_normed && D->wq_t && D->wk_t && D->wv_t &&
+                      D->ffn_w_pad && D->ffn_w && D->g_ffn_w && D->g_ffn_b && D->g_ffn_w_pad && D->g_wq &&
+                      D->g_wk && D->g_wv && D->g_bq && D->g_bk && D->g_bv && D->workspace && D->dx,
                   "cross_score_bwd: null pointer");
+  // norm_w = NULL: the stand-alone CrossAttentionBlock (carca.py:338-349 called on an already normed profile): no final
+  // LayerNorm in front of it, dx = d p_normed
+  const bool has_norm = D->norm_w != nullptr;
+  CARCA_CHECK_ARG(!has_norm || (D->enc_out && D->g_norm_w && D->g_norm_b),
+                  "cross_score_bwd: the final LayerNorm needs enc_out and its two gradient buffers");
   int dpi, dhp, dpo;
   if (int rc = carca_padded_dims(D->d, D->H, &dpi, &dhp, &dpo)) return rc;
   const int rows = D->B * D->L, d = D->d, ng = D->ngroups;
@@ -224,15 +228,17 @@ extern "C" int carca_cross_score_bwd(const CarcaCrossBwdDesc* D, CarcaWgradDesc*
       sg.rowscale = D->residual ? dls[i] : nullptr;
     }
     g[0].lda0 = dpo; g[0].K0 = dpo; g[0].bt0 = D->wq_t; g[0].ldb0 = dpo;
-    g[0].N = d; g[0].ldc = dpi; g[0].ncols_out = dpi; g[0].gate_slope = 0.01f; g[0].mask_rows = 1;
+    // (inside CARCA the targets were embedded as e * mask: d e is masked the same way.  The stand-alone block's o is an
+    // input of its own: a pad target still scores sigma(w . o + b) through the residual, and d o = dlogit (x) w there)
+    g[0].N = d; g[0].ldc = dpi; g[0].ncols_out = dpi; g[0].gate_slope = 0.01f; g[0].mask_rows = has_norm ? 1 : 0;
     g[0].colvec = D->residual ? D->ffn_w : nullptr;
-    g[1] = gemm_product(dkh, dpo, D->wk_t, dpo, dpo, d, dp, dpi, rows);
+    g[1] = gemm_product(dkh, dpo, D->wk_t, dpo, dpo, d, has_norm ? dp : D->dx, dpi, rows);
     g[1].seg[0].a1 = dvh; g[1].lda1 = dpo; g[1].K1 = dpo; g[1].bt1 = D->wv_t; g[1].ldb1 = dpo;
     if ((rc = carca_gemm_rows_group(g, 2, stream))) return rc;
   }
   // final LayerNorm (carca.py:421)
-  if ((rc = carca_layernorm_bwd(dp, dpi, D->enc_out, dpi, D->norm_w, rows, d, nullptr, 0, D->dx, dpi, dpi, D->g_norm_w,
-                                D->g_norm_b, stream)))
+  if (has_norm && (rc = carca_layernorm_bwd(dp, dpi, D->enc_out, dpi, D->norm_w, rows, d, nullptr, 0, D->dx, dpi, dpi,
+                                            D->g_norm_w, D->g_norm_b, stream)))
     return rc;
   CarcaWgradDesc* w = wgrads + *n_wgrads;
   int n = 0;

@@ -249,6 +249,94 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
   if (lane + 64 < dh) orow[lane + 64] = acc1;
 }
 
+// Backward of mha_core_kernel, one wave per (user, head, query) like the forward: the weights are recomputed, then
+//   dW_j = dO . v_j (+ the caller's gradient of the returned weights),  dS_j = W_j (dW_j - sum_k W_k dW_k) / sqrt(dh)
+// (masked entries: W = 0 and no gradient, carca.py:256),  dq = sum_j dS_j k_j  (this wave's row: plain store),
+// dk_j += dS_j q,  dv_j += W_j dO  (rows shared by the queries of a user: accumulated -- grad_add).
+__global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                           const float* __restrict__ v, int ldk,
+                                                           const int32_t* __restrict__ q_ids, const int32_t* __restrict__ k_ids,
+                                                           int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
+                                                           const float* __restrict__ d_out, int ldo,
+                                                           const float* __restrict__ d_w, float* __restrict__ dq,
+                                                           float* __restrict__ dk, float* __restrict__ dv) {
+  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wid >= (long)B * H * Tq) return;
+  const int t = (int)(wid % Tq);
+  const int h = (int)((wid / Tq) % H);
+  const int b = (int)(wid / ((long)Tq * H));
+  const int dh = d / H;
+  const float* qr = q + ((long)b * Tq + t) * ldq + h * dh;
+  const float* dor = d_out ? d_out + ((long)b * Tq + t) * ldo + h * dh : nullptr;
+  const bool q_ok = q_ids[(long)b * Tq + t] != 0;
+  const float sqrt_dh = sqrtf((float)dh);
+  float sc[MHA_KPL], dwj[MHA_KPL];
+  bool ok[MHA_KPL];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < MHA_KPL; ++i) {
+    const int j = lane + 64 * i;
+    sc[i] = -3.0e38f;
+    dwj[i] = 0.f;
+    ok[i] = false;
+    if (j < Tk) {
+      const float* kr = k + ((long)b * Tk + j) * ldk + h * dh;
+      const float* vr = v + ((long)b * Tk + j) * ldk + h * dh;
+      float dot = 0.f, dd = 0.f;
+      for (int c = 0; c < dh; ++c) {
+        dot += qr[c] * kr[c];
+        if (dor) dd += dor[c] * vr[c];
+      }
+      ok[i] = q_ok && k_ids[(long)b * Tk + j] != 0 && (!has_causal || j - t <= causal);
+      sc[i] = ((ok[i] ? 0.0f : -4294967296.0f) + dot) / sqrt_dh;
+      mx = fmaxf(mx, sc[i]);
+      if (d_w) dd += d_w[(((long)h * B + b) * Tq + t) * Tk + j];
+      dwj[i] = dd;
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MHA_KPL; ++i)
+    if (lane + 64 * i < Tk) {
+      sc[i] = expf(sc[i] - mx);
+      sum += sc[i];
+    }
+  sum = wave_sum(sum);
+  float wd = 0.f;
+#pragma unroll
+  for (int i = 0; i < MHA_KPL; ++i) {
+    sc[i] = (lane + 64 * i < Tk && ok[i]) ? sc[i] / sum : 0.f;
+    wd += sc[i] * dwj[i];
+  }
+  wd = wave_sum(wd);
+  float ds[MHA_KPL];
+#pragma unroll
+  for (int i = 0; i < MHA_KPL; ++i) ds[i] = sc[i] * (dwj[i] - wd) / sqrt_dh;
+  // dq[c] = sum_j dS_j k_j[c]: a lane owns the head's columns lane and lane + 64, the dS travel by shuffle
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MHA_KPL; ++i)
+    for (int l = 0; l < 64 && l + 64 * i < Tk; ++l) {
+      const float dsj = __shfl(ds[i], l), wj = __shfl(sc[i], l);
+      if (dsj == 0.f && wj == 0.f) continue;  // (uniform: the shuffled values are the same in every lane)
+      const long krow = ((long)b * Tk + l + 64 * i) * ldk + h * dh;
+      if (lane < dh) {
+        a0 += dsj * k[krow + lane];
+        grad_add(&dk[krow + lane], dsj * qr[lane]);
+        if (dor) grad_add(&dv[krow + lane], wj * dor[lane]);
+      }
+      if (lane + 64 < dh) {
+        a1 += dsj * k[krow + lane + 64];
+        grad_add(&dk[krow + lane + 64], dsj * qr[lane + 64]);
+        if (dor) grad_add(&dv[krow + lane + 64], wj * dor[lane + 64]);
+      }
+    }
+  float* dqr = dq + ((long)b * Tq + t) * ldq + h * dh;
+  if (lane < dh) dqr[lane] = a0;
+  if (lane + 64 < dh) dqr[lane + 64] = a1;
+}
 
 }  // namespace
 
@@ -358,6 +446,23 @@ extern "C" int carca_mha_core(const float* q, int ldq, const float* k, const flo
   const long waves = (long)B * H * Tq;
   hipLaunchKernelGGL(mha_core_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, q, ldq, k, v, ldk,
                      q_ids, k_ids, B, Tq, Tk, d, H, has_causal, causal, out, ldo, w_out);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+extern "C" int carca_mha_core_bwd(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
+                                  const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
+                                  const float* d_out, int ldo, const float* d_w, float* dq, float* dk, float* dv,
+                                  void* stream_) {
+  CARCA_CHECK_ARG(q && k && v && q_ids && k_ids && (d_out || d_w) && dq && dk && dv, "mha_core_bwd: null pointer");
+  CARCA_CHECK_ARG(B >= 1 && Tq >= 1 && Tk >= 1 && d >= 1 && H >= 1 && d % H == 0 && ldq >= d && ldk >= d &&
+                      (!d_out || ldo >= d),
+                  "mha_core_bwd: bad dims");
+  CARCA_CHECK_SUPPORTED(Tk <= 64 * MHA_KPL && d / H <= 128, "mha_core_bwd: Tk=%d > %d keys per query, or d/H=%d > 128", Tk,
+                        64 * MHA_KPL, d / H);
+  const long waves = (long)B * H * Tq;
+  hipLaunchKernelGGL(mha_core_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, q, ldq, k, v,
+                     ldk, q_ids, k_ids, B, Tq, Tk, d, H, has_causal, causal, d_out, ldo, d_w, dq, dk, dv);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

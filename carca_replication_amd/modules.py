@@ -119,9 +119,13 @@ class LearnableEncoding(Encoding):
 
     def forward(self, x: Tensor) -> Tensor:
         """Stand-alone use of the ABC (abstract.py:31, carca.py:25-31): x [B, T, d] + encoding[:T].  Inside CARCA the
-        table rides in the embedding GEMM's epilogue instead.  Inference only: gradients flow through CARCA.forward."""
-        _no_standalone_grad(x, self)
-        return ops.add_positions(x, self.position_table(x.shape[1]))
+        table rides in the embedding GEMM's epilogue instead.  Differentiable in x and in the table."""
+        table = self.position_table(x.shape[1])
+        if torch.is_grad_enabled() and (x.requires_grad or table.requires_grad):
+            from .autograd import add_positions_with_grad
+
+            return add_positions_with_grad(x, table)
+        return ops.add_positions(x, table)
 
 
 class PositionalEncoding(Encoding):
@@ -141,7 +145,10 @@ class PositionalEncoding(Encoding):
 
     def forward(self, x: Tensor) -> Tensor:
         """Stand-alone use of the ABC (abstract.py:31, carca.py:54-60): x [B, T, d] + pe[:, :T]."""
-        _no_standalone_grad(x, self)
+        if torch.is_grad_enabled() and x.requires_grad:
+            from .autograd import add_positions_with_grad
+
+            return add_positions_with_grad(x, self.position_table(x.shape[1]))
         return ops.add_positions(x, self.position_table(x.shape[1]))
 
 
@@ -283,7 +290,8 @@ class AllEmbedding(Embedding):
         n_attrs = F - n_ctx
         ids_seg = [sg[0] for sg in segs]
         nseg = len(des)
-        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
+        if not segs[0][3]:  # (segment 0 is the profile: the only one with a position term, carca.py:91)
+            _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
         g_joint_w, g_joint_b = gbp[id(self.joint_embed.weight)], gbp[id(self.joint_embed.bias)]
         # d W_jz = sqrt(d) (de*mask)^T E[x];  d b_j = cs
         ops.gemm_wgrad([dict(dy=des[i], x=E, x_gather=True, ids=ids_seg[i]) for i in range(nseg)], d, d, g_joint_w[:, :d],
@@ -351,7 +359,8 @@ class AllEmbedding(Embedding):
                       dict(g_items=gbp[id(self.items_embed.weight)], g_feats_w=gbp[id(self.feats_embed.weight)],
                            g_feats_b=gbp[id(self.feats_embed.bias)], g_joint_w=gbp[id(self.joint_embed.weight)],
                            g_joint_b=gbp[id(self.joint_embed.bias)]),
-                      table, d, g_feats, n_attrs, n_ctx, L, gbp[id(enc_w)] if enc_w is not None else None)
+                      table, d, g_feats, n_attrs, n_ctx, L,
+                      gbp[id(enc_w)] if (enc_w is not None and not segs[0][3]) else None)  # (targets carry no position term)
 
     def forward(self, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
         """`mask` must be get_mask(x) (it always is in the reference, carca.py:413-426); the kernel uses x != 0."""
@@ -372,8 +381,9 @@ class AllEmbedding(Embedding):
 # ------------------------------------------------------------------------------------------------
 def _standalone_embed(module, x, a, c, target):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise CarcaHipError(f"training through a stand-alone {type(module).__name__} is not built; train through "
-                            f"CARCA.forward")
+        from .autograd import embed_with_grad
+
+        return embed_with_grad(module, x, a, c, target)
     (e,), _ = module.embed_segments([(x, a, c, target)], ld_e=module.d)
     return e
 
@@ -415,7 +425,8 @@ class _FeatsEmbedding(Embedding):
         n_attrs, n_ctx = self._split(segs)
         ids_seg = [sg[0] for sg in segs]
         nseg = len(des)
-        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
+        if not segs[0][3]:  # (a target segment carries no position term)
+            _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
         ops.gemm_wgrad([dict(dy=des[i], x=qs[i], ids=ids_seg[i]) for i in range(nseg)], d, g, gbp[id(Wj)],
                        gbp[id(self.joint_embed.bias)], mask_rows=True)
         wj_t = ops.PackedWeights([ops.PackItem(Wj, g, dpi, transposed=True)], des[0].device)
@@ -478,7 +489,8 @@ class IdEmbedding(Embedding):
     def embed_backward(self, des, segs, saved, gbp, L: int, dpi: int) -> None:
         d = self.d
         ids_seg = [sg[0] for sg in segs]
-        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
+        if not segs[0][3]:  # (a target segment carries no position term)
+            _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
         for i in range(len(des)):  # rows with id 0 are skipped: that is the e * mask of carca.py:170
             ops.embed_scatter(des[i], ids_seg[i], d, float(d) ** 0.5, gbp[id(self.items_embed.weight)])
 
@@ -515,7 +527,8 @@ class MLPIdEmbedding(Embedding):
         sd = float(d) ** 0.5
         ids_seg = [sg[0] for sg in segs]
         nseg = len(des)
-        _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
+        if not segs[0][3]:  # (a target segment carries no position term)
+            _pos_grad(self.enc, des[0], ids_seg[0], d, L, gbp)
         # d W = sqrt(d) (d e * mask)^T E[x]; the table rows are gathered inside the product
         gw = torch.zeros_like(gbp[id(W)])
         ops.gemm_wgrad([dict(dy=des[i], x=E.detach(), x_gather=True, ids=ids_seg[i]) for i in range(nseg)], d, g, gw,
@@ -636,13 +649,18 @@ class MultiHeadAttention(nn.Module):
         return mats + vecs
 
     def forward(self, query, key, value, q_mask, k_mask, causal: int = None, return_w: bool = False):
-        """Stand-alone MultiHeadAttention.forward (carca.py:228-265), inference only: three row GEMMs for the projections
-        and carca_mha_core for the attention (the blocks' fused kernels never come here).  Returns the merged heads
-        [B, Tq, d], or (weights [H*B, Tq, Tk] before dropout, output) with return_w -- the reference's order."""
-        _no_standalone_grad(query, self)
+        """Stand-alone MultiHeadAttention.forward (carca.py:228-265): three row GEMMs for the projections and
+        carca_mha_core for the attention (the blocks' fused kernels never come here).  Returns the merged heads
+        [B, Tq, d], or (weights [H*B, Tq, Tk] before dropout, output) with return_w -- the reference's order.
+        Differentiable (autograd.mha_with_grad: carca_mha_core_bwd + row / weight-gradient GEMMs)."""
         if self.training and self.dropout.p > 0:
-            raise CarcaHipError("stand-alone MultiHeadAttention applies no dropout: call it in eval mode")
+            raise CarcaHipError("stand-alone MultiHeadAttention applies no dropout: call it in eval mode or with p = 0")
         ops._need_cuda(query, key, value, q_mask, k_mask)
+        if torch.is_grad_enabled() and (any(t.requires_grad for t in (query, key, value)) or
+                                        any(p.requires_grad for p in self.parameters())):
+            from .autograd import mha_with_grad
+
+            return mha_with_grad(self, query, key, value, q_mask, k_mask, causal, return_w)
         d = self.d
         proj = []
         for x, lin in ((query, self.WQ), (key, self.WK), (value, self.WV)):

@@ -688,8 +688,8 @@ def sa_block_bwd(dy: Tensor, ids: Tensor, saved: dict, x_in: Tensor, wT, ln_w, g
     return dx
 
 
-def cross_score_bwd(groups, p_ids: Tensor, kh: Tensor, vh: Tensor, p_normed: Tensor, enc_out: Tensor, wT, ffn_w_pad_ptr: int,
-                    ffn_w: Tensor, norm_w: Tensor, grads: dict, B: int, L: int, d: int, H: int, residual: bool,
+def cross_score_bwd(groups, p_ids: Tensor, kh: Tensor, vh: Tensor, p_normed: Tensor, enc_out: Optional[Tensor], wT,
+                    ffn_w_pad_ptr: int, ffn_w: Tensor, norm_w: Optional[Tensor], grads: dict, B: int, L: int, d: int, H: int, residual: bool,
                     training: bool, drop_p: float, wg: WgradGroup):
     """Backward of the final LayerNorm + CrossAttentionBlock over all target groups as ONE host call
     (carca_cross_score_bwd).  groups: [(qh, y [B,N], dy [B,N], ids [B,N], o [B*N, DPI], m_attn or None)];
@@ -721,12 +721,13 @@ def cross_score_bwd(groups, p_ids: Tensor, kh: Tensor, vh: Tensor, p_normed: Ten
         des.append(de)
     p_ids32 = _ids32(p_ids)
     dx = torch.empty(B * L, dpi, dtype=torch.float32, device=kh.device)
+    # (norm_w = None: the stand-alone decoder, no final LayerNorm in front of it -- dx = d p_normed)
     D.p_ids, D.kh, D.vh, D.p_normed, D.enc_out = (p_ids32.data_ptr(), kh.data_ptr(), vh.data_ptr(), p_normed.data_ptr(),
-                                                   enc_out.data_ptr())
-    if p_normed.stride(-2) != dpi or enc_out.stride(-2) != dpi:
+                                                   _ptr(enc_out))
+    if p_normed.stride(-2) != dpi or (enc_out is not None and enc_out.stride(-2) != dpi):
         raise CarcaHipError("cross_score_bwd: p_normed / enc_out must have row stride DPI")
     D.wq_t, D.wk_t, D.wv_t = (t.data_ptr() for t in wT)
-    D.ffn_w_pad, D.ffn_w, D.norm_w = ffn_w_pad_ptr, ffn_w.data_ptr(), norm_w.data_ptr()
+    D.ffn_w_pad, D.ffn_w, D.norm_w = ffn_w_pad_ptr, ffn_w.data_ptr(), _ptr(norm_w)
     for k, t in grads.items():
         setattr(D, k, t.data_ptr())
     D.workspace, D.dx = ws.data_ptr(), dx.data_ptr()
@@ -923,6 +924,25 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, q_ids: Tensor, k_ids: Tensor, H: i
                                           qi.data_ptr(), ki.data_ptr(), B, Tq, Tk, d, H, int(causal is not None),
                                           int(causal or 0), out.data_ptr(), d, _ptr(w), _stream()), "mha_core")
     return out, w
+
+
+def mha_core_bwd(q: Tensor, k: Tensor, v: Tensor, q_ids: Tensor, k_ids: Tensor, H: int, causal: Optional[int],
+                 d_out: Optional[Tensor], d_w: Optional[Tensor]):
+    """Backward of mha_core: (dq, dk, dv) for projected q [B, Tq, d], k / v [B, Tk, d]."""
+    B, Tq, d = q.shape
+    Tk = k.shape[1]
+    q2, k2, v2 = (_f32(t).reshape(-1, d).contiguous() for t in (q, k, v))
+    qi, ki = _ids32(q_ids.reshape(-1)), _ids32(k_ids.reshape(-1))
+    do = _f32(d_out).reshape(-1, d).contiguous() if d_out is not None else None
+    dw = _f32(d_w).contiguous() if d_w is not None else None
+    dq = torch.empty(B * Tq, d, dtype=torch.float32, device=q.device)
+    dk = torch.zeros(B * Tk, d, dtype=torch.float32, device=q.device)
+    dv = torch.zeros(B * Tk, d, dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().carca_mha_core_bwd(q2.data_ptr(), d, k2.data_ptr(), v2.data_ptr(), d, qi.data_ptr(), ki.data_ptr(),
+                                              B, Tq, Tk, d, H, int(causal is not None), int(causal or 0), _ptr(do), d,
+                                              _ptr(dw), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _stream()),
+               "mha_core_bwd")
+    return dq.view(B, Tq, d), dk.view(B, Tk, d), dv.view(B, Tk, d)
 
 
 def _user_rows(t: Tensor, name: str) -> Tensor:

@@ -392,6 +392,13 @@ int carca_add_positions(const float* x, int ldx, const float* pos, float* out, i
 int carca_mha_core(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
                    const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal, float* out,
                    int ldo, float* w_out /*or NULL*/, void* stream);
+/* Backward of carca_mha_core (torch.autograd over carca.py:242-260): d_out [B*Tq, ldo] (or NULL) and d_w [H*B, Tq, Tk]
+ * (or NULL: the gradient of the returned weights) -> dq [B*Tq, ldq] (written), dk, dv [B*Tk, ldk] (ACCUMULATED: zero
+ * them first).  The weights are recomputed from q, k and the masks. */
+int carca_mha_core_bwd(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
+                       const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
+                       const float* d_out /*or NULL*/, int ldo, const float* d_w /*or NULL*/, float* dq, float* dk, float* dv,
+                       void* stream);
 /* Inverse of carca_pack_weights for gradients: real[r][c] (+)= packed[rp][cp] (same descriptor fields:
  * src = real tensor, dst = packed buffer).  accumulate = 0 overwrites, 1 adds. */
 int carca_unpack_grads(const CarcaPackDesc* descs, int n, int accumulate, void* stream);
@@ -450,7 +457,9 @@ typedef struct CarcaCrossBwdDesc {
   const float *wq_t, *wk_t, *wv_t;     /* [DPI, DPO] transposed head-padded copies */
   const float* ffn_w_pad;              /* [DPO] decoder.ffn.weight, head-padded (CarcaCaWeights.ffn_w_pad) */
   const float* ffn_w;                  /* [d] decoder.ffn.weight as is */
-  const float* norm_w;                 /* [d] final LayerNorm gamma */
+  const float* norm_w;                 /* [d] final LayerNorm gamma; NULL = the stand-alone CrossAttentionBlock on an already
+                                          normed profile: no LayerNorm stage (enc_out, g_norm_* unused, dx = d p_normed)
+                                          and de is the gradient of the block's INPUT o, not masked by ids */
   float *g_ffn_w, *g_ffn_b;            /* [d], [1] */
   float* g_ffn_w_pad;                  /* [DPO] head-padded staging of the attention part of d ffn.weight */
   float *g_wq, *g_wk, *g_wv, *g_bq, *g_bk, *g_bv; /* head-padded staging: [DPO, d], [DPO] */

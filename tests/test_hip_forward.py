@@ -478,8 +478,9 @@ def test_standalone_encodings_add_their_table():
         assert torch.equal(pe(view), view + pe.pe[:, :7])
         with pytest.raises(CarcaHipError):
             le(torch.randn(3, 12, 10, device="cuda"))  # longer than max_len
-    with pytest.raises(CarcaHipError):  # gradients flow through CARCA.forward, not through the stand-alone module
-        le(x)
+    # with gradients enabled the same call is differentiable (tests/test_hip_standalone_grad.py)
+    y = le(x)
+    assert y.requires_grad and torch.equal(y.detach(), x + le.encoding.weight[:7].detach())
 
 
 # ---- the eval-mode SelfAttentionBlock kernel (csrc/sa_eval.hip) ----------------------------------------------------------

@@ -1,0 +1,169 @@
+"""torch.autograd through the STAND-ALONE modules of the reference's surface (abstract.py:8-50, carca.py:15-95, 204-349):
+SelfAttentionBlock, CrossAttentionBlock, MultiHeadAttention, the encodings and AllEmbedding used on their own are ordinary
+differentiable nn.Modules in the reference.  Here their backward is the hot path's per-module entry points
+(carca_sa_block_bwd, carca_cross_score_bwd, carca_embed_bwd, carca_mha_core_bwd) behind autograd.Functions; every
+gradient -- parameters and input activations -- is checked against torch.autograd over the CPU oracle's restatement of
+the same lines (fp64), to 1e-4 of each tensor's largest entry (typically 1e-6)."""
+import pytest
+import torch
+
+from oracle import carca_oracle as O
+from tests.model_util import model_from_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(d, H, L, B, n_items=200, g=40, n_ctx=3, n_attrs=17, encoding="identity", seed=0):
+    cfg = O.CarcaConfig(d=d, H=H, n_blocks=1, encoding=encoding)
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=seed), seed=seed + 1, scale=0.2)
+    model = model_from_params(P, cfg).cuda().train()
+    gen = torch.Generator().manual_seed(seed + 2)
+    ln = torch.randint(0, L + 1, (B,), generator=gen)
+    ln[0], ln[1 % B] = L, 1
+    mask = (torch.arange(L)[None, :] >= (L - ln)[:, None]).float()
+    if B > 3:
+        mask[3, L // 2] = 0.0  # a pad inside a profile
+    return cfg, P, model, mask, gen
+
+
+def _check(name, got, want, tol=1e-4, floor=1e-7):
+    """floor: absolute slack for a tensor whose true gradient is 0 -- the attention key biases (softmax is invariant to a
+    shift of all scores of a query), computed as the fp32 round-off of sums whose terms are the size of the OTHER gradients."""
+    want = want.float()
+    scale = float(want.abs().max())
+    err = float((got.detach().cpu().float() - want).abs().max())
+    assert err <= tol * scale + floor, (name, err, scale)
+
+
+def _check_params(prefix, module, P64, suffix=""):
+    refs = {n: P64[prefix + n].grad for n, _ in module.named_parameters()}
+    floor = 1e-5 * max([float(r.abs().max()) for r in refs.values() if r is not None] + [1e-2])
+    for n, prm in module.named_parameters():
+        got = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+        _check(n + suffix, got, refs[n] if refs[n] is not None else torch.zeros_like(got.cpu()), floor=floor)
+
+
+def _P64(P):
+    return {k: v.double().clone().requires_grad_(v.is_floating_point()) for k, v in P.items()}
+
+
+@pytest.mark.parametrize("d,H,L,B", [(90, 3, 50, 5), (64, 2, 20, 4), (128, 4, 33, 3)])
+@pytest.mark.parametrize("residual", [True, False])
+def test_self_attention_block_is_differentiable(d, H, L, B, residual):
+    cfg, P, model, mask, gen = _setup(d, H, L, B)
+    cfg.residual_sa = residual
+    blk = model.encoder[0]
+    blk.residual = residual
+    x = torch.randn(B, L, d, generator=gen)
+    dy = torch.randn(B, L, d, generator=gen)
+    xg = x.cuda().requires_grad_(True)
+    y = blk(xg, mask.cuda())
+    assert y.shape == (B, L, d) and y.requires_grad
+    y.backward(dy.cuda())
+    P64 = _P64(P)
+    x64 = x.double().requires_grad_(True)
+    y64 = O.sa_block(P64, cfg, 0, x64, mask.double())
+    y64.backward(dy.double())
+    _check("y", y, y64.detach(), 2e-5)
+    _check("dx", xg.grad, x64.grad)
+    _check_params("encoder.0.", blk, P64)
+
+
+@pytest.mark.parametrize("d,H,L,N,B", [(90, 3, 50, 101, 4), (64, 2, 20, 7, 5), (128, 4, 33, 1, 3)])
+@pytest.mark.parametrize("training", [True, False])
+def test_cross_attention_block_is_differentiable(d, H, L, N, B, training):
+    cfg, P, model, p_mask, gen = _setup(d, H, L, B)
+    dec = model.decoder.train(training)
+    o = torch.randn(B, N, d, generator=gen)
+    p = torch.randn(B, L, d, generator=gen)
+    o_mask = (torch.rand(B, N, generator=gen) > 0.15).float()
+    og, pg = o.cuda().requires_grad_(True), p.cuda().requires_grad_(True)
+    y = dec(og, o_mask.cuda(), pg, p_mask.cuda())
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.cuda())
+    P64 = _P64(P)
+    o64, p64 = o.double().requires_grad_(True), p.double().requires_grad_(True)
+    y64 = O.cross_block(P64, cfg, o64, o_mask.double(), p64, p_mask.double(), training)
+    assert tuple(y64.shape) == tuple(y.shape)  # the bare squeeze (carca.py:346)
+    y64.backward(dy.double())
+    _check("y", y, y64.detach(), 2e-5)
+    _check("do", og.grad, o64.grad)
+    _check("dp", pg.grad, p64.grad)
+    _check_params("decoder.", dec, P64)
+
+
+@pytest.mark.parametrize("causal", [None, 0, -1])
+def test_multi_head_attention_is_differentiable_in_outputs_and_weights(causal):
+    d, H, Tq, Tk, B = 90, 3, 11, 50, 4
+    cfg, P, model, k_mask, gen = _setup(d, H, Tk, B)
+    attn = model.decoder.attn.eval()  # (dropout 0 either way; eval mirrors the reference's deterministic call)
+    q = torch.randn(B, Tq, d, generator=gen)
+    kv = torch.randn(B, Tk, d, generator=gen)
+    q_mask = (torch.rand(B, Tq, generator=gen) > 0.2).float()
+    qg, kg = q.cuda().requires_grad_(True), kv.cuda().requires_grad_(True)
+    w, out = attn(qg, kg, kg, q_mask.cuda(), k_mask.cuda(), causal=causal, return_w=True)
+    d_out = torch.randn(B, Tq, d, generator=gen)
+    d_w = torch.randn(B, H, Tq, Tk, generator=gen)
+    # the reference's weights are head-major [H*B, Tq, Tk] (head h of user b at h*B + b, carca.py:242-244)
+    (out * d_out.cuda()).sum().backward(retain_graph=True)
+    g_out = {n: prm.grad.clone() for n, prm in attn.named_parameters()}
+    gq_out, gk_out = qg.grad.clone(), kg.grad.clone()
+    for t in list(attn.parameters()) + [qg, kg]:
+        t.grad = None
+    (w * d_w.transpose(0, 1).reshape(H * B, Tq, Tk).cuda()).sum().backward()
+    P64 = _P64(P)
+    q64, k64 = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    w64, out64 = O.mha(P64, "decoder.attn.", H, q64, k64, k64, q_mask.double(), k_mask.double(), causal)
+    _check("out", out, out64.detach(), 2e-5)
+    _check("w", w.view(H, B, Tq, Tk).transpose(0, 1), w64.detach(), 2e-5)
+    (out64 * d_out.double()).sum().backward(retain_graph=True)
+    _check("dq (out)", gq_out, q64.grad)
+    _check("dk (out)", gk_out, k64.grad)
+    floor = 1e-5 * max(float(P64["decoder.attn." + n].grad.abs().max()) for n in g_out)
+    for n in g_out:
+        _check(n + " (out)", g_out[n], P64["decoder.attn." + n].grad, floor=floor)
+    for t in list(P64.values()) + [q64, k64]:
+        t.grad = None
+    (w64 * d_w.double()).sum().backward()
+    _check("dq (w)", qg.grad, q64.grad)
+    _check("dk (w)", kg.grad, k64.grad)
+    floor = 1e-5 * max(float(P64["decoder.attn." + n].grad.abs().max()) for n in g_out if not n.startswith("WV"))
+    for n, prm in attn.named_parameters():
+        ref = P64["decoder.attn." + n].grad
+        if n.startswith("WV"):
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0  # the weights do not depend on V
+            continue
+        _check(n + " (w)", prm.grad, ref if ref is not None else torch.zeros_like(prm.grad.cpu()), floor=floor)
+
+
+@pytest.mark.parametrize("encoding", ["learnable", "positional", "identity"])
+@pytest.mark.parametrize("target", [False, True])
+def test_all_embedding_and_encodings_are_differentiable(encoding, target):
+    d, H, L, B = 90, 3, 12, 5
+    cfg, P, model, mask, gen = _setup(d, H, L, B, encoding=encoding)
+    emb = model.embeds
+    n_items, n_attrs, n_ctx = emb.items_embed.weight.shape[0], 17, 3
+    x = (torch.randint(1, n_items, (B, L), generator=gen) * mask.long()).int()
+    x[2, -3:] = x[2, -1]  # the same item three times: its row's gradient is a sum
+    a = torch.rand(B, L, n_attrs, generator=gen)
+    c = torch.rand(B, L, n_ctx, generator=gen)
+    de = torch.randn(B, L, d, generator=gen)
+    e = emb(x.cuda(), a.cuda(), c.cuda(), mask.cuda(), target)
+    assert e.shape == (B, L, d) and e.requires_grad
+    e.backward(de.cuda())
+    P64 = _P64(P)
+    e64 = O.embedding(P64, cfg, x.long(), a.double(), c.double(), (x != 0).double(), target)
+    e64.backward(de.double())
+    _check("e", e, e64.detach(), 2e-5)
+    _check_params("embeds.", emb, P64)
+    # the encodings on their own (abstract.py:31): x + table, differentiable in both
+    if encoding != "identity":
+        enc = emb.enc
+        for prm in enc.parameters():
+            prm.grad = None
+        xe = torch.randn(B, L, d, generator=gen)
+        xeg = xe.cuda().requires_grad_(True)
+        enc(xeg).backward(de.cuda())
+        assert torch.equal(xeg.grad, de.cuda())
+        if encoding == "learnable":
+            _check("encoding.weight", enc.encoding.weight.grad[:L], de.sum(0))
