@@ -18,6 +18,7 @@ CONFIGS = {
     "CLI B=256 d=64 g=256 H=2 3 blocks n_attrs=512": dict(B=256, L=50, N=101, d=64, g=256, H=2, nb=3, n_attrs=512, n_ctx=6, n_items=12102),
     "small n_attrs=64                             ": dict(B=128, L=50, N=101, d=90, g=450, H=3, nb=2, n_attrs=64, n_ctx=6, n_items=12102),
 }
+results = []
 only = os.environ.get("ONLY")  # e.g. ONLY=C5 (prefix of the configuration's name) for a rocprofv3 run of one of them
 for name, c in CONFIGS.items():
     if only and not name.startswith(only):
@@ -41,4 +42,13 @@ for name, c in CONFIGS.items():
     F = c["n_attrs"] + c["n_ctx"]
     flop = c["B"] * ((c["L"] + c["N"]) * (2 * F * c["g"] + 2 * (c["d"] + c["g"]) * c["d"]) + c["nb"] * (10 * c["L"] * c["d"] ** 2 + 4 * c["L"] ** 2 * c["d"])
                      + 2 * c["N"] * c["d"] ** 2 + 4 * c["L"] * c["d"] ** 2 + 4 * c["N"] * c["L"] * c["d"] + 2 * c["N"] * c["d"])
+    results.append(dict(config=" ".join(name.split()), ms_per_batch=dt * 1e3, users_per_s=c["B"] / dt,
+                        algorithmic_tflops=flop / dt / 1e12, **c))
     print(f"{name}: {dt*1e3:7.3f} ms/batch  {c['B']/dt:10.0f} users/s  {flop/dt/1e12:6.1f} TFLOP/s (algorithmic)", flush=True)
+
+if os.environ.get("JSON_OUT"):  # e.g. JSON_OUT=gpurun_out/r03_configs.json (copied to profiles/ by hand)
+    import json
+
+    with open(os.environ["JSON_OUT"], "w") as fh:
+        json.dump(dict(what="eval forward, one MI355X, inputs resident in HBM, 0.3 s pre-heat + 100 steps (tools/bench_configs.py)",
+                       peak_fp32_mfma_tflops=157.3, results=results), fh, indent=1)
