@@ -19,6 +19,7 @@
 //     "no row" offset and a dummy LDS address where it is not its job -- so the loop stays branch-free.
 //     Columns past K / K1 are loaded as they come (the next row's data, zeros past the end of the buffer) into
 //     accumulator columns that are never written out.
+#include <algorithm>
 #include <type_traits>
 #include "carca_common.h"
 #include "../../include/carca_hip.h"
@@ -42,14 +43,61 @@ struct WgradCuDev {
   // 1.134 .. 1.417 M cycles; 1.295 .. 1.364 M with a weight of 270 / 256, those workgroups then 2 % early: 264)
   long per_w, n_fast;
   int slow_w;
+  // Workgroups work in GROUPS of nnb: the members of a group walk the same (k block, chunk) range, one n block each, so
+  // that an X chunk (32 rows x 384 columns, 49 KB) is fetched from HBM once and found in the L2 by the other members --
+  // with consecutive workgroups on consecutive item ranges the nnb readers of a chunk came by at unrelated times and the
+  // kernel read X nnb times over (PMC: 2.13 GB per launch at C2 against 357 MB algorithmic).  A group's members sit on
+  // ONE XCD (workgroup b runs on XCD b % nxcd): gpx groups per XCD, the slots left over form groups across XCDs (they
+  // still meet in the memory-side cache), workgroups beyond ngroups x nnb have no work.
+  int nxcd, gpx, ngroups;
+  // Output tiles are SUMMED WITHOUT ATOMICS: a workgroup that leaves a k block stores its 96 x 384 partial tile (plain,
+  // 256 contiguous bytes per wave store) into its slot of `part`, and wgrad_reduce_kernel, launched behind this one, adds
+  // each tile's partials in group order into dW.  (36,864 fp32 atomics per flush and workgroup, all workgroups at once
+  // when the kernel ends: the stamps put ~8 % of the kernel outside its chunk loop.  Tried first: the workgroup that
+  // arrives LAST at a tile reduces it inside this kernel -- agent-scope fences flush / invalidate the whole L2 of an XCD
+  // under the workgroups still streaming through it (kernel 1.41 M -> 1.75 M cycles), and with agent-scope stores
+  // instead the reducing workgroups became the tail, 1.47 M -> 1.54 M cycles for the slowest.)
+  // Fixed summation order: dW is bit-reproducible run to run without the deterministic mode's shadow buffer.
+  float* part;    // [ngroups][slots_pg][nnb][96 x 384], register order: element (tt, r) of thread tid at (16 tt + r) 768 + tid
+  int slots_pg;   // k blocks a group's range can touch (2 unless the product is short); 0 = flush with fp32 atomics (A/B switch,
+                  // tuning variant 14, and products whose tiles get so many partials that the atomics are cheaper)
+  long* gbegin;   // [ngroups + 1] first unit of every group (written by the row-table kernel: the reduce kernel reads
+  int* klo;       // [nkb][2] first / last group with units in the k block     them instead of redoing 64-bit divisions)
   int src1_kb;  // k block that also carries the second k-source's columns, or -1
   unsigned long long* dbg;    // phase stamps of a diagnostic run (tuning variant 3)
 };
 __device__ __forceinline__ unsigned long long* carca_debug_ptr(const WgradCuDev& a) { return a.dbg; }
 
+// the groups' unit ranges (stream-K over (k block, chunk) units in weight units of 1/256 unit, see WgradCuDev)
+struct WgRanges {
+  long total, n_fast, per_w;
+  int slow_w, ngroups;
+  __device__ long item_at(long wt) const {
+    const long fast_w = n_fast * 256;
+    return wt <= fast_w ? wt / 256 : n_fast + (wt - fast_w) / slow_w;
+  }
+  __device__ long begin_of(int g) const { return g >= ngroups ? total : min(total, item_at((long)g * per_w)); }
+  __device__ int group_of(long u) const {  // the group whose range holds unit u
+    const long wt = u <= n_fast ? u * 256 : n_fast * 256 + (u - n_fast) * slow_w;
+    int g = (int)min((long)ngroups - 1, wt / per_w);
+    while (g > 0 && begin_of(g) > u) --g;
+    while (g + 1 < ngroups && begin_of(g + 1) <= u) ++g;
+    return g;
+  }
+};
+
 __global__ void wgrad_rowtab_kernel(const WgradCuDev args, unsigned* tab) {
   const CarcaWgradDesc& D = args.d;
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  {
+    const int nchunks = args.chunk_start[D.nseg];
+    const WgRanges rg{(long)args.nkb * nchunks, args.n_fast, args.per_w, args.slow_w, args.ngroups};
+    if (v <= args.ngroups) args.gbegin[v] = rg.begin_of(v);
+    if (v < args.nkb) {
+      args.klo[2 * v] = rg.group_of((long)v * nchunks);
+      args.klo[2 * v + 1] = rg.group_of((long)(v + 1) * nchunks - 1);
+    }
+  }
   if (v >= args.V) return;
   const int c = v >> 5;
   int s = 0;
@@ -96,30 +144,42 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int nchunks = args.chunk_start[D.nseg];
-  const long total = (long)args.nnb * args.nkb * nchunks;
-  auto item_at = [&](long wt) -> long {  // weight units -> item index (monotonic: consecutive blocks tile [0, total))
-    const long fast_w = args.n_fast * 256;
-    return wt <= fast_w ? wt / 256 : args.n_fast + (wt - fast_w) / args.slow_w;
-  };
-  const long w_begin = min(total, item_at((long)blockIdx.x * args.per_w));
-  const long w_end = blockIdx.x + 1 == gridDim.x ? total : min(total, item_at((long)(blockIdx.x + 1) * args.per_w));
+  const long total = (long)args.nkb * nchunks;  // (k block, chunk) units of a group; its members take an n block each
+  const WgRanges rg{total, args.n_fast, args.per_w, args.slow_w, args.ngroups};
+  int grp, nb;
+  {
+    const int per_xcd = (int)gridDim.x / args.nxcd, x = (int)blockIdx.x % args.nxcd, sl = (int)blockIdx.x / args.nxcd;
+    const int in_groups = args.gpx * args.nnb;  // slots of an XCD that belong to its own groups
+    if (sl < in_groups) {
+      grp = x * args.gpx + sl / args.nnb;
+      nb = sl % args.nnb;
+    } else {
+      const int l = x * (per_xcd - in_groups) + (sl - in_groups);
+      grp = args.nxcd * args.gpx + l / args.nnb;
+      nb = l % args.nnb;
+    }
+  }
+  if (grp >= args.ngroups) return;
+  const long w_begin = rg.begin_of(grp);
+  const long w_end = rg.begin_of(grp + 1);
 
   // staging slots of this thread: dY (row tid / 24, float4 tid % 24), X rows tid / 96 + 8 i, float4 tid % 96
   const int y_r = tid / 24, y_c4 = tid - y_r * 24;
   const int x_r = tid / 96, x_c4 = tid - x_r * 96;
   const __amdgpu_buffer_rsrc_t tab_rsrc = carca_rsrc(args.tab);
 
+  f32x16 acc[3];  // the output tile of the k block in progress: kept across the runs (row segments) inside it
+  int acc_kb = -1;
   for (long w = w_begin; w < w_end;) {
     // ---- one run of chunks inside one output tile and one row segment (so that every buffer resource is a
     // loop invariant: a scalar load inside the loop would wait on lgkmcnt, i.e. on the LDS reads in flight) ----
-    const int ot = (int)(w / nchunks), c_begin = (int)(w - (long)ot * nchunks);
+    const int kb = (int)(w / nchunks), c_begin = (int)(w - (long)kb * nchunks);
     int seg = 0;
 #pragma unroll
     for (int q = 1; q < CARCA_MAX_SEGS; ++q)
       if (q < D.nseg && c_begin >= args.chunk_start[q]) seg = q;
     const int c_end = (int)min((long)args.chunk_start[seg + 1], c_begin + (w_end - w));
     w += c_end - c_begin;
-    const int kb = ot / args.nnb, nb = ot - kb * args.nnb;  // n block fastest: neighbours share the X columns
     const int n0 = nb * WG_BN, k0 = kb * WG_BK;
     const bool do_db = D.db != nullptr && kb == 0;
     const __amdgpu_buffer_rsrc_t y_rsrc =
@@ -174,11 +234,13 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
         *reinterpret_cast<f32x4*>(&Xs[buf * WG_XB + (x_r + 8 * i) * WG_XS + 4 * x_c4]) = v;
     };
 
-    f32x16 acc[3];
+    if (kb != acc_kb) {
+      acc_kb = kb;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
     float bsum = 0.f;  // column (tid % 96) of dY over rows 4 (tid / 96) .. +3 of every chunk (kb == 0 tiles)
 
     // fragments of one group of 4 MFMA steps (8 rows): xb[j], y[j][t] for step j; A = dY (n index), B = X (k index)
@@ -299,17 +361,28 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
     if constexpr (DBG) w_loop += __builtin_amdgcn_s_memtime() - t_loop;
 #undef CARCA_PIN
 
-    // ---- flush: D row (= n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (= virtual k) = lane&31 ------------
-    const int vk = k0 + wave * 32 + lr;
-    const int kcol = s1w ? (lr < D.K1 ? D.K + lr : -1) : vk < D.K ? vk : -1;
-    if (kcol >= 0) {
+    // ---- flush, once per (group, k block): D row (= n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (= virtual k) = lane&31
+    if ((w >= w_end || (int)(w / nchunks) != kb) && args.slots_pg == 0) {
+      const int vk = k0 + wave * 32 + lr;
+      const int kcol = s1w ? (lr < D.K1 ? D.K + lr : -1) : vk < D.K ? vk : -1;
+      if (kcol >= 0) {
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = n0 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (n < D.N) grad_add(&D.dw[(size_t)n * D.ldw + kcol], acc[tt][r]);
+          }
+      }
+    } else if (w >= w_end || (int)(w / nchunks) != kb) {
+      // the partial tile -> this group's slot for the k block
+      const int kb_first = (int)(w_begin / nchunks);
+      const size_t tile_fl = (size_t)WG_BN * WG_BK;
+      float* const mine = args.part + ((size_t)(grp * args.slots_pg + (kb - kb_first)) * args.nnb + nb) * tile_fl;
 #pragma unroll
       for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = n0 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (n < D.N) grad_add(&D.dw[(size_t)n * D.ldw + kcol], acc[tt][r]);
-        }
+        for (int r = 0; r < 16; ++r) mine[(tt * 16 + r) * WG_NT + tid] = acc[tt][r];  // (register order)
     }
     if (do_db && n0 + x_c4 < D.N) grad_add(&D.db[n0 + x_c4], bsum);
   }
@@ -322,6 +395,39 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
       o[2] = w_vm;
       o[3] = w_bar;
     }
+  }
+}
+
+// dW tile (kb, nb) += its groups' partial tiles, in group order.  grid (nkb x nnb, 36): a thread takes four consecutive
+// floats of the tile in register order (element e = (tt, r) of the threads tid .. tid + 3 of gemm_wgrad_cu_kernel: the
+// same n, four consecutive k) -- one 16-byte load per partial.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradCuDev args) {
+  const CarcaWgradDesc& D = args.d;
+  const int nchunks = args.chunk_start[D.nseg];
+  const int kb = (int)blockIdx.x / args.nnb, nb = (int)blockIdx.x - kb * args.nnb;
+  const int j4 = (int)blockIdx.y * 256 + threadIdx.x;  // float4 index inside the tile, 0 .. 9215
+  const int e = (4 * j4) / WG_NT, tid = 4 * j4 - e * WG_NT;
+  const int lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const bool s1w = kb == args.src1_kb && wave == WG_NW - 1;
+  const long u0 = (long)kb * nchunks, u1 = u0 + nchunks;
+  const int g_lo = args.klo[2 * kb], g_hi = args.klo[2 * kb + 1];
+  const size_t tile_fl = (size_t)WG_BN * WG_BK;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int g2 = g_lo; g2 <= g_hi; ++g2) {
+    const long b2 = args.gbegin[g2];
+    if (min(args.gbegin[g2 + 1], u1) <= max(b2, u0)) continue;
+    const float* src = args.part + ((size_t)(g2 * args.slots_pg + (kb - (int)(b2 / nchunks))) * args.nnb + nb) * tile_fl;
+    sum += *reinterpret_cast<const f32x4*>(src + 4 * (size_t)j4);
+  }
+  const int tt = e >> 4, r = e & 15;
+  const int n = nb * WG_BN + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+  if (n >= D.N) return;
+  float* row = D.dw + (size_t)n * D.ldw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vk = kb * WG_BK + wave * 32 + lr + i;
+    const int kcol = s1w ? (lr + i < D.K1 ? D.K + lr + i : -1) : vk < D.K ? vk : -1;
+    if (kcol >= 0) row[kcol] += sum[i];
   }
 }
 
@@ -389,13 +495,41 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   // (24 chunk-tiles per CU: the d x F product of the re-associated embedding backward, 26 per CU at C2, runs 2x faster
   // here than on the tile kernel; the joint-embedding dW, 5 per CU, does not)
   if (!forced && (total < (long)g_num_cus * 24 || chunks < 8)) return 1;
-  const long n_slow = (desc->K1 > 0 && g.src1_kb >= 0 && g.src1_kb == g.nkb - 1) ? (long)g.nnb * chunks : 0;
-  g.n_fast = total - n_slow;
+  // groups of nnb workgroups (see WgradCuDev): per XCD as many whole groups as fit, the left-over slots group across XCDs
+  g.nxcd = (g_num_cus % 8 == 0 && g.nnb <= g_num_cus / 8) ? 8 : 1;
+  const int per_xcd = g_num_cus / g.nxcd;
+  g.gpx = per_xcd / g.nnb;
+  g.ngroups = g.nxcd * g.gpx + (g.nxcd * (per_xcd - g.gpx * g.nnb)) / g.nnb;
+  if (g.ngroups < 1) return 1;  // (more n blocks than CUs: the tile kernel)
+  const long units = (long)g.nkb * chunks;
+  const long n_slow = (desc->K1 > 0 && g.src1_kb >= 0 && g.src1_kb == g.nkb - 1) ? (long)chunks : 0;
+  g.n_fast = units - n_slow;
   g.slow_w = carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 13 ? 256 : 264;  // (variant 13: equal item counts -- A/B switch)
   const long total_w = g.n_fast * 256 + n_slow * g.slow_w;
-  g.per_w = (total_w + g_num_cus - 1) / g_num_cus;
-  const int grid = (int)((total_w + g.per_w - 1) / g.per_w);
+  g.per_w = (total_w + g.ngroups - 1) / g.ngroups;
+  g.ngroups = (int)((total_w + g.per_w - 1) / g.per_w);  // (a short product: fewer groups than the chip could host)
+  const int grid = g_num_cus;
   g.V = chunks * WG_BR;
+  {  // k blocks a group's range can touch: walk the groups' first and last units
+    auto item_at = [&](long wt) -> long {
+      const long fast_w = g.n_fast * 256;
+      return wt <= fast_w ? wt / 256 : g.n_fast + (wt - fast_w) / g.slow_w;
+    };
+    auto begin_of = [&](int gi) -> long { return gi >= g.ngroups ? units : std::min(units, item_at((long)gi * g.per_w)); };
+    int spg = 1;
+    for (int gi = 0; gi < g.ngroups; ++gi) {
+      const long b = begin_of(gi), e = begin_of(gi + 1);
+      if (e > b) spg = std::max(spg, (int)((e - 1) / chunks - b / chunks) + 1);
+    }
+    g.slots_pg = spg;
+  }
+  // Partials pay when a tile receives FEW of them: every partial is 147 KB written and read back (C2's feats_embed: 5.6 per
+  // tile, 45 MB, ~14 us of reduce kernel against ~60 us of atomics).  A product of few tiles cut over all the groups (the
+  // d x F product of the re-associated backward: 11 tiles, 23 partials each) keeps the atomics.
+  const long n_tiles = (long)g.nkb * g.nnb, n_parts = (long)g.ngroups * g.nnb;
+  if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 14 || n_parts > 8 * n_tiles) g.slots_pg = 0;
+  const size_t part_floats = (size_t)g.ngroups * g.slots_pg * g.nnb * WG_BN * WG_BK;
+  const size_t cnt_ints = ((size_t)2 * (g.ngroups + 1) + 2 * g.nkb + 5) / 4 * 4;  // gbegin (8-byte entries) | klo
   if (!g_tab_init) {
     for (int i = 0; i < TAB_RING; ++i) (void)hipEventCreateWithFlags(&g_tab_ev[i], hipEventDisableTiming);
     g_tab_init = true;
@@ -403,16 +537,18 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   int slot = -1;
   unsigned* tab;
   if (carca_stream_capturing(stream)) {  // hipGraph capture: a table of the graph's own, no ring slot, no guard event
-    tab = (unsigned*)carca_capture_alloc((size_t)3 * g.V * sizeof(unsigned), false, nullptr);
+    tab = (unsigned*)carca_capture_alloc(((size_t)3 * g.V + cnt_ints) * sizeof(unsigned) + part_floats * sizeof(float),
+                                         false, nullptr);
     if (!tab) return 1;
   } else {
     slot = g_tab_next;
     g_tab_next = (g_tab_next + 1) % TAB_RING;
     if (g_tab_used[slot]) (void)hipEventSynchronize(g_tab_ev[slot]);  // its last consumer: normally long finished
-    if ((size_t)3 * g.V > g_tab_elems[slot]) {
+    const size_t need = (size_t)3 * g.V + cnt_ints + part_floats;  // row table | group ranges | partial tiles
+    if (need > g_tab_elems[slot]) {
       if (g_tab[slot]) (void)hipFree(g_tab[slot]);
       g_tab[slot] = nullptr;
-      g_tab_elems[slot] = (size_t)3 * g.V * 2;
+      g_tab_elems[slot] = need + need / 8;
       if (hipMalloc(&g_tab[slot], g_tab_elems[slot] * sizeof(unsigned)) != hipSuccess) {
         g_tab_elems[slot] = 0;
         return 1;
@@ -421,12 +557,21 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
     tab = g_tab[slot];
   }
   g.tab = tab;
-  hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((g.V + 255) / 256), dim3(256), 0, stream, g, tab);
+  {
+    unsigned* aux = tab + (size_t)3 * g.V;  // (V is a multiple of 32 and the buffer comes from hipMalloc: 16-byte aligned)
+    g.gbegin = (long*)aux;
+    g.klo = (int*)(aux + 2 * (size_t)(g.ngroups + 1));
+    g.part = (float*)(aux + cnt_ints);
+  }
+  hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((std::max(g.V, std::max(g.ngroups + 1, g.nkb)) + 255) / 256), dim3(256), 0, stream,
+                     g, tab);
   g.dbg = carca_debug_buffer();
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 3 && g.dbg)
     hipLaunchKernelGGL(gemm_wgrad_cu_kernel<1>, dim3(grid), dim3(WG_NT), 0, stream, g);
   else
     hipLaunchKernelGGL(gemm_wgrad_cu_kernel<0>, dim3(grid), dim3(WG_NT), 0, stream, g);
+  if (g.slots_pg > 0)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g.nkb * g.nnb, WG_BN * WG_BK / 1024), dim3(256), 0, stream, g);
   if (slot >= 0) {
     (void)hipEventRecord(g_tab_ev[slot], stream);
     g_tab_used[slot] = true;

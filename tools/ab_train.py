@@ -26,11 +26,13 @@ batch = tuple(t.cuda() for t in (profile[0], profile[1], profile[2], o_x, torch.
                                   torch.cat([pos[2], pos[2]], 1), torch.cat([(px != 0).int(), torch.zeros_like(px)], 1)))
 from carca_replication_amd.optim import Adam as _Adam  # noqa: E402
 opt = _Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))
+if os.environ.get("FOLD") == "1":  # the opt-in re-associated embedding (CARCA.fold_embedding(True, training=True))
+    model.fold_embedding(True, training=True)
 lib = _lib.load()
 res = {s: [] for s in settings}
 for rnd in range(4):
     for s in settings:
-        for k in range(8):
+        for k in range(8):  # (keys 8+ are modes, not variants)
             lib.carca_set_tuning(k, 0)
         for kv in filter(None, s.split(",")):
             k, v = kv.split("=")
