@@ -242,9 +242,10 @@ def measure_scoring_scaling(c, model, device, batches=(1024, 4096), reps=30):
         o[..., :d] = torch.randn(B, N, d, device=device, generator=gen)
         o_ids = torch.randint(1, 5, (B, N), device=device, dtype=torch.int32, generator=gen)
         res = {}
-        for name in ("baseline_lengths", "full_profiles"):
-            ln = (torch.randint(3, L + 1, (B,), device=device, generator=gen) if name == "baseline_lengths"
-                  else torch.full((B,), L, device=device))
+        ln_drawn = torch.randint(3, L + 1, (B,), device=device, generator=gen)
+        for name in ("baseline_lengths", "full_profiles", "length_sorted"):
+            ln = {"baseline_lengths": ln_drawn, "full_profiles": torch.full((B,), L, device=device),
+                  "length_sorted": torch.sort(ln_drawn, descending=True)[0]}[name]
             p_ids = ((torch.arange(L, device=device)[None, :] >= (L - ln)[:, None]).int() * 7).contiguous()
             run = lambda: ops.cross_score_fwd(x, p_ids, [(o, o_ids)], cw, d, H, True, False)  # noqa: E731
             for _ in range(8):
@@ -264,10 +265,15 @@ def measure_scoring_scaling(c, model, device, batches=(1024, 4096), reps=30):
                   "users": B, "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                   "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_ms": res["baseline_lengths"],
                   "frac_full_profiles": tf_full / PEAK_F32_MFMA_TFLOPS, "avg_ms_full_profiles": res["full_profiles"],
+                  "frac_length_sorted": B * ca / (res["length_sorted"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                  "avg_ms_length_sorted": res["length_sorted"],
                   "algorithmic_gflop_per_launch": B * ca / 1e9, "launches_timed": reps,
                   "timing": "side pass, untimed by the headline: back-to-back launches of the kernel alone between two "
                             "events (launch gaps included); `frac` at BASELINE.md's profile lengths U{3..50}, "
-                            "`frac_full_profiles` with every profile at L = 50"}
+                            "`frac_full_profiles` with every profile at L = 50, `frac_length_sorted` the SAME users "
+                            "as `frac` ordered by profile length (what device_data.DeviceLoader(order='length') "
+                            "delivers: the persistent workgroups take users w, w + #CUs, ... and a user's cost is its "
+                            "key tiles, so sorted neighbours give every workgroup the same mix)"}
     return out
 
 

@@ -231,3 +231,22 @@ def test_device_loader_epoch_equals_the_host_dataset_epoch(tmp_path, monkeypatch
     m_dev.embeds.register_attr_table(None)
     e_host = evaluate(m_dev, host["test"], "cuda", 10)
     assert e_dev[0] == e_host[0] and abs(e_dev[1] - e_host[1]) < 1e-6 and abs(e_dev[2] - e_host[2]) < 1e-6
+
+
+def test_length_ordered_loader_visits_the_same_users():
+    """DeviceLoader(order="length"): the evaluation split's users, longest history first -- same users, same batches'
+    worth of metrics (sums over users), and refused together with shuffle."""
+    from carca_replication_amd.device_data import DeviceInteractions, DeviceLoader
+
+    profiles, ctx, attrs = _log(n_users=40, n_items=90, seed=6)
+    log = DeviceInteractions(profiles, ctx, attrs.shape[0])
+    a = DeviceLoader(log, "test", 16, 6, 10)
+    b = DeviceLoader(log, "test", 16, 6, 10, order="length")
+    assert sorted(a.users.tolist()) == sorted(b.users.tolist()) and len(a) == len(b)
+    lens = [len(profiles[log.user_ids[i]]) for i in b.users.tolist()]
+    assert lens == sorted(lens, reverse=True)
+    rows = torch.cat([bt[0] for bt in b])  # p_x of every batch: profile lengths never grow along the epoch
+    filled = (rows != 0).sum(1).tolist()
+    assert filled == sorted(filled, reverse=True)
+    with pytest.raises(ValueError):
+        DeviceLoader(log, "train", 16, 6, shuffle=True, order="length")
