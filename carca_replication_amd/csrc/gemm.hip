@@ -36,6 +36,11 @@ struct GemmDev {
   int diag;                 // timing experiments of gemm_rows_n96_kernel (tuning key 5; wrong results): 1 no loads, 2 no MFMAs, 4 plain epilogue, 8 no stores
   int has_pas;              // one-block-per-CU kernel: block nrb * ncb (one past the tiles) runs the item-row gather
   CarcaGatherArgs pas;
+  // gemm_rows_sk_kernel: K steps of every full tile that the row block's cheap workgroup computes, its partial tiles
+  // [nrb][ncb - 1][384 x 96] (register order) and their flags (0 = empty, 1 = ready; the taker resets its flag)
+  int sk_don;
+  float* sk_part;
+  int* sk_flag;
 };
 
 template <int BM, int BN, int BK, int PF = 1, bool BUF = false>
@@ -559,6 +564,335 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// gemm_rows_sk_kernel: gemm_rows_cu_kernel with the PADDING of the last column block given back.
+// N = 450 is 4 x 96 + 66: the fifth column block of every row block multiplies 96 columns for 66 results, and since
+// every workgroup owns one tile the launch lasts as long as a full tile -- 6.3 % of the MFMA work is padding (DESIGN,
+// section "Next").  Here the fifth tile is CHEAP: two 32-column MFMA tiles + the last XC <= 2 columns as VALU dot
+// products on the A fragments the wave holds anyway (4 XC fused multiply-adds per 8-k group beside 8 MFMAs), and the time
+// its workgroup saves goes to the four others: it computes the LAST `don` K steps of each of their tiles first (a
+// 384 x 96 partial tile each, handed over through memory with a flag), then its own tile; the owners run `don` steps less
+// and add the partial in their epilogue -- which is ~0.75 of the kernel later, so nobody ever waits (the flag is there
+// for correctness).  A giver waits for nobody, every workgroup is resident (one round, one workgroup per CU): no cycle.
+// cu_tile is gemm_rows_cu_kernel's body over a K-step range [t_lo, t_hi) with the three endings.
+enum { SK_PLAIN = 0, SK_GIVE = 1, SK_TAKE = 2 };
+template <int TN, int XC, int MODE>
+__device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__ As, float* __restrict__ Bs, const int rb,
+                                        const int n0, const int t_lo, const int t_hi, const bool with_tail,
+                                        float* __restrict__ part, int* flag) {
+  constexpr int BM = 384, BNS = 32 * TN + XC, BK = 32, NW = 12, NT = 768, LS = BK + 4, C4 = BK / 4;
+  constexpr int A_PER = BM * C4 / NT, B_PER = (BNS * C4 + NT - 1) / NT;
+  constexpr int A_BUF = BM * LS, B_BUF = BNS * LS;
+  constexpr int XCA = XC > 0 ? XC : 1;
+  static_assert(B_PER == 1 && 2 * B_BUF + (NT - BNS * C4) * 4 <= 2 * 96 * LS + 1024, "B tile: one slot per thread, inside the kernel's Bs");
+  const CarcaGemmDesc& D = args.d;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+    if (i < D.nseg && rb >= args.rb_start[i]) s = i;
+  const CarcaGemmSeg sg = D.seg[s];
+  const int row0 = (rb - args.rb_start[s]) * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt0 = (D.K0 + BK - 1) / BK, nt1 = (D.K1 + BK - 1) / BK;
+  const int ntiles = nt0 + nt1;
+
+  size_t aoff0[A_PER], aoff1[A_PER];
+  unsigned a_byte[A_PER];
+  int a_lds[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int slot = tid + i * NT, r = slot / C4, c4 = slot - r * C4;
+    const int gr = min(row0 + r, sg.rows - 1);
+    const int ub = gr / sg.T, ut = gr - ub * sg.T;
+    aoff0[i] = sg.a0_gather ? (size_t)sg.ids[gr] * D.lda0
+               : sg.a0_bstride ? (size_t)ub * sg.a0_bstride + (size_t)ut * D.lda0
+                               : (size_t)gr * D.lda0;
+    aoff1[i] = sg.a1_bstride ? (size_t)ub * sg.a1_bstride + (size_t)ut * D.lda1 : (size_t)gr * D.lda1;
+    a_byte[i] = (unsigned)((aoff0[i] + c4 * 4) * sizeof(float));
+    a_lds[i] = r * LS + c4 * 4;
+  }
+  const bool b_live = tid < BNS * C4;  // (threads past the B tile's slots load a clamped row and store into the dummy strip)
+  const int b_r = b_live ? tid / C4 : 0, b_c4 = tid % C4;
+  const int b_gn = min(n0 + b_r, D.N - 1);
+  const unsigned b_byte = (unsigned)(((size_t)b_gn * D.ldb0 + b_c4 * 4) * sizeof(float));
+  const int b_at0 = b_live ? b_r * LS + b_c4 * 4 : 2 * B_BUF + (tid - BNS * C4) * 4;
+  const int b_at1 = b_live ? B_BUF + b_r * LS + b_c4 * 4 : 2 * B_BUF + (tid - BNS * C4) * 4;
+
+  f32x4 ra[A_PER], rbv;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sg.a0, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)D.bt0, 0, -1, 0x00020000);
+  int k_byte = t_lo * BK * (int)sizeof(float);  // scalar: byte offset of the NEXT tile to load inside a row
+  auto load_fast = [&](int i) {
+    const u32x4 v = i < A_PER ? __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_byte[i < A_PER ? i : 0], k_byte, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_byte, k_byte, 0);
+    f32x4 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(v[e]);
+    if (i < A_PER)
+      ra[i < A_PER ? i : 0] = f;
+    else
+      rbv = f;
+  };
+  auto store_slot = [&](int i, int buf) {
+    if (i < A_PER)
+      *reinterpret_cast<f32x4*>(&As[buf * A_BUF + a_lds[i < A_PER ? i : 0]]) = ra[i < A_PER ? i : 0];
+    else
+      *reinterpret_cast<f32x4*>(&Bs[buf ? b_at1 : b_at0]) = rbv;
+  };
+  auto load4 = [](const float* p, bool full, int kk, int klen) -> f32x4 {
+    if (full) return *reinterpret_cast<const f32x4_u*>(p);
+    f32x4 v;
+    v[0] = kk + 0 < klen ? p[0] : 0.f;
+    v[1] = kk + 1 < klen ? p[1] : 0.f;
+    v[2] = kk + 2 < klen ? p[2] : 0.f;
+    v[3] = kk + 3 < klen ? p[3] : 0.f;
+    return v;
+  };
+  auto load_tail = [&](int t) {
+    const bool src1 = t >= nt0;
+    const int k0 = (src1 ? t - nt0 : t) * BK;
+    const int klen = src1 ? D.K1 : D.K0;
+    const float* abase = src1 ? sg.a1 : sg.a0;
+    const float* bbase = src1 ? D.bt1 : D.bt0;
+    const int ldb = src1 ? D.ldb1 : D.ldb0;
+    const bool full = k0 + BK <= klen;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int c4 = (tid + i * NT) % C4;
+      ra[i] = load4(abase + (src1 ? aoff1[i] : aoff0[i]) + k0 + c4 * 4, full, k0 + c4 * 4, klen);
+    }
+    rbv = load4(bbase + (size_t)b_gn * ldb + k0 + b_c4 * 4, full, k0 + b_c4 * 4, klen);
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+  f32x4 xacc[XCA];  // per column: the four k positions of the lane's quad, summed at the end
+#pragma unroll
+  for (int c = 0; c < XCA; ++c) xacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 31, lh = lane >> 5;
+  const float* a_frag = &As[(wave * 32 + lr) * LS + 4 * lh];
+  const float* b_frag = &Bs[lr * LS + 4 * lh];
+  const float* x_frag = &Bs[(32 * TN) * LS + 4 * lh];  // the XC extra rows of the B tile: one k quad per half wave
+  f32x4 fa0, fa1, fb0[TN], fb1[TN], fx0[XCA], fx1[XCA];
+
+#define CARCA_PIN() __builtin_amdgcn_sched_barrier(0)
+  constexpr int NR = TN + 1, NRX = NR + XC;
+  auto read_frag = [&](int j, int buf, int kg, f32x4& fa, f32x4(&fb)[TN], f32x4(&fx)[XCA]) {
+    if (j == 0)
+      fa = *reinterpret_cast<const f32x4*>(a_frag + buf * A_BUF + kg * 8);
+    else if (j < NR)
+      fb[j - 1] = *reinterpret_cast<const f32x4*>(b_frag + buf * B_BUF + (j - 1) * 32 * LS + kg * 8);
+    else
+      fx[j - NR] = *reinterpret_cast<const f32x4*>(x_frag + buf * B_BUF + (j - NR) * LS + kg * 8);
+  };
+  auto mfma_group = [&](const f32x4& fa, const f32x4(&fb)[TN], const f32x4(&fx)[XCA], auto&& aux) {
+#pragma unroll
+    for (int i = 0; i < 4 * TN; ++i) {
+      acc[i % TN] = mfma32(fa[i / TN], fb[i % TN][i / TN], acc[i % TN]);
+      CARCA_PIN();
+      if constexpr (XC > 0) {
+        if (i < XC) {
+          // two v_pk_fma_f32, written out: left to the compiler the same four FMAs cost 70 spilled VGPRs (it re-plans the
+          // fragment registers of the whole pinned step around them)
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const int c = i < XC ? i : 0;
+          f32x2 a0 = {fa[0], fa[1]}, a1 = {fa[2], fa[3]};
+          f32x2 w0 = {fx[c][0], fx[c][1]}, w1 = {fx[c][2], fx[c][3]};
+          f32x2 x0 = {xacc[c][0], xacc[c][1]}, x1 = {xacc[c][2], xacc[c][3]};
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(x0) : "v"(a0), "v"(w0));
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(x1) : "v"(a1), "v"(w1));
+          xacc[c] = f32x4{x0[0], x0[1], x1[0], x1[1]};
+        }
+      }
+      aux(i);
+      CARCA_PIN();
+    }
+  };
+  static_assert(NRX <= 4 * TN && NR + A_PER + B_PER <= 4 * TN, "a group's gaps hold its reads and the tile's staging slots");
+  auto step = [&](auto cur_tag, int t) {
+    constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
+    const bool has1 = t + 1 < t_hi, has2 = t + 2 < t_hi;
+    mfma_group(fa0, fb0, fx0, [&](int i) {
+      if (i < NRX) read_frag(i, CUR, 1, fa1, fb1, fx1);
+    });
+    mfma_group(fa1, fb1, fx1, [&](int i) {
+      if (i < NRX) read_frag(i, CUR, 2, fa0, fb0, fx0);
+      if (i >= NR && i < NR + A_PER + B_PER && has1) store_slot(i - NR, NXT);
+    });
+    mfma_group(fa0, fb0, fx0, [&](int i) {
+      if (i < NRX) read_frag(i, CUR, 3, fa1, fb1, fx1);
+      if (i >= NR && i < NR + A_PER + B_PER && has2) load_fast(i - NR);
+    });
+    if (has2) k_byte += BK * sizeof(float);
+    CARCA_PIN();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // raw: the loads of tile t+2 stay in flight across it
+    CARCA_PIN();
+    mfma_group(fa1, fb1, fx1, [&](int i) {
+      if (i < NRX && has1) read_frag(i, NXT, 0, fa0, fb0, fx0);
+    });
+  };
+
+  __syncthreads();  // (a workgroup that runs several tiles: the previous one is done with both LDS buffers)
+  if (t_hi > t_lo) {
+#pragma unroll
+    for (int i = 0; i < A_PER + B_PER; ++i) load_fast(i);
+    k_byte += BK * sizeof(float);
+#pragma unroll
+    for (int i = 0; i < A_PER + B_PER; ++i) store_slot(i, 0);
+    if (t_hi - t_lo > 1) {
+#pragma unroll
+      for (int i = 0; i < A_PER + B_PER; ++i) load_fast(i);
+      k_byte += BK * sizeof(float);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NRX; ++j) read_frag(j, 0, 0, fa0, fb0, fx0);
+    int t = t_lo;
+    for (; t + 1 < t_hi; t += 2) {
+      step(std::integral_constant<int, 0>{}, t);
+      step(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < t_hi) step(std::integral_constant<int, 0>{}, t);
+  }
+#undef CARCA_PIN
+  if (with_tail) {
+    for (int t = D.K0 / BK; t < ntiles; ++t) {
+      load_tail(t);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A_PER + B_PER; ++i) store_slot(i, 0);
+      __syncthreads();
+#pragma unroll
+      for (int kg = 0; kg < BK / 8; ++kg) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(a_frag + kg * 8);
+        f32x4 b[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(b_frag + tn * 32 * LS + kg * 8);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tn] = mfma32(a[st], b[tn][st], acc[tn]);
+        if constexpr (XC > 0) {
+#pragma unroll
+          for (int c = 0; c < XC; ++c) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(x_frag + c * LS + kg * 8);
+            xacc[c] = __builtin_elementwise_fma(a, w, xacc[c]);
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr (MODE == SK_GIVE) {
+    // the partial tile in register order (256 contiguous bytes per wave store), written through the XCD's L2 (the taker
+    // may sit on another XCD), then the flag
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __hip_atomic_store(&part[(tn * 16 + r) * NT + tid], acc[tn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if constexpr (MODE == SK_TAKE) {
+    if (tid == 0) {
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+      __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ready for the next launch)
+    }
+    __syncthreads();
+    // (plain loads: this XCD has not touched these lines since the kernel began -- a launch starts with an invalidated L2)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tn][r] += part[(tn * 16 + r) * NT + tid];
+  }
+
+  // ---- epilogue (as gemm_rows_cu_kernel) ------------------------------------------------------------
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + tn * 32 + lr;
+    if (n >= D.ncols_out) continue;
+    const bool n_ok = n < D.N;
+    const float bias = (n_ok && D.bias) ? D.bias[n] : 0.f;
+    const float cv = (n_ok && D.colvec) ? D.colvec[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= sg.rows) continue;
+      float v = 0.f;
+      if (n_ok) {
+        v = (D.alpha != 0.f ? D.alpha * acc[tn][r] : acc[tn][r]) + bias;
+        if (sg.add_pos) v += D.pos[(size_t)(row % sg.T) * D.N + n];
+        if (sg.add) v += sg.add[(size_t)row * D.ld_add + n];
+        if (sg.rowscale) v += sg.rowscale[row] * cv;
+        if (sg.gate) {
+          const float gv = sg.gate[(size_t)row * D.ld_gate + n];
+          const float gs = D.gate_scale != 0.f ? D.gate_scale : 1.0f;
+          v *= gv > 0.f ? gs : ((gv < 0.f || !D.gate_zero_drops) ? D.gate_slope * gs : 0.f);
+        }
+        if (D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;
+      }
+      sg.c[(size_t)row * D.ldc + n] = v;
+    }
+  }
+  if constexpr (XC > 0) {
+    // the VALU columns: lane (lr, lh) holds row wave * 32 + lr's sum over the k quads of its half; the launcher admits
+    // this kernel only for the plain epilogue (alpha, bias, row mask)
+    const int row = row0 + wave * 32 + lr;
+#pragma unroll
+    for (int c = 0; c < XC; ++c) {
+      const float mine = (xacc[c][0] + xacc[c][1]) + (xacc[c][2] + xacc[c][3]);
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine), __float_as_uint(mine), false, false);
+      const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      const int n = n0 + 32 * TN + c;
+      if (lh == 0 && row < sg.rows && n < D.N) {
+        float v = (D.alpha != 0.f ? D.alpha * tot : tot) + (D.bias ? D.bias[n] : 0.f);
+        if (D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;
+        sg.c[(size_t)row * D.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int XC>
+__global__ __launch_bounds__(768) void gemm_rows_sk_kernel(const GemmDev args) {
+  __shared__ __attribute__((aligned(16))) float As[2 * 384 * 36];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * 96 * 36 + 1024];
+  const CarcaGemmDesc& D = args.d;
+  const int id = blockIdx.x, total = args.nrb * args.ncb;
+  if (args.has_pas && id == total) {
+    carca_gather_rows<16>(args.pas, (int)threadIdx.x >> 6, 12, (int)threadIdx.x & 63);
+    return;
+  }
+  const int xcd = id & 7, q8 = total >> 3, r8 = total & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  const int rb = wg / args.ncb, j = wg - rb * args.ncb;
+  const int nfast = D.K0 / 32, nfull = args.ncb - 1;
+  if (j == 0) {  // the row block's cheap workgroup (first of the block's five to be dispatched)
+    // (args.diag, tuning key 5, timing experiments with wrong results: 1 no partial tiles, 2 takers do not wait / add,
+    // 4 no cheap tile)
+    for (int cb = 0; cb < nfull && !(args.diag & 1); ++cb)
+      cu_tile<3, 0, SK_GIVE>(args, As, Bs, rb, cb * 96, nfast - args.sk_don, nfast, false,
+                             args.sk_part + ((size_t)rb * nfull + cb) * (384 * 96), args.sk_flag + rb * nfull + cb);
+    if (!(args.diag & 4)) cu_tile<2, XC, SK_PLAIN>(args, As, Bs, rb, nfull * 96, 0, nfast, true, nullptr, nullptr);
+  } else {
+    const int cb = j - 1;
+    if (args.diag & 2)
+      cu_tile<3, 0, SK_PLAIN>(args, As, Bs, rb, cb * 96, 0, nfast - args.sk_don, true, nullptr, nullptr);
+    else
+      cu_tile<3, 0, SK_TAKE>(args, As, Bs, rb, cb * 96, 0, nfast - args.sk_don, true,
+                           args.sk_part + ((size_t)rb * nfull + cb) * (384 * 96), args.sk_flag + rb * nfull + cb);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // gemm_rows_n96_kernel: the same product for a NARROW output (64 < N <= 96: the joint embedding e = [z ; q] W_j^T,
 // carca.py:89) over one k-source with a short K (540 at C2).  The 128 x 32 blocks above leave one dependent chain per
 // K step on eight waves a CU and two unequal rounds of blocks; here ONE 768-thread block per CU takes 80 rows x all 96
@@ -1010,6 +1344,99 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream, co
   return CARCA_OK;
 }
 
+// gemm_rows_sk_kernel's launch (see the kernel): returns 1 when the product is not its shape -- the caller then launches
+// gemm_rows_cu_kernel<0, 3>.  The partial tiles and flags live in a two-slot ring of the library's own (a slot is reused
+// behind the event of its last launch; inside a hipGraph capture the graph gets storage of its own).
+constexpr int SK_RING = 2;
+float* g_sk_buf[SK_RING] = {nullptr};
+size_t g_sk_bytes[SK_RING] = {0};
+hipEvent_t g_sk_ev[SK_RING];
+bool g_sk_used[SK_RING] = {false}, g_sk_init = false;
+int g_sk_next = 0;
+
+static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, const CarcaGatherArgs* pas, int* rode) {
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
+  if (variant == 15 || variant == 158) return 1;  // (15: never -- A/B switch; 158: 15 + 8)
+  const int ncb = (desc->ncols_out + 95) / 96, nfull = ncb - 1;
+  if (ncb < 2 || desc->ncols_out != desc->N) return 1;
+  const int rem = desc->N - 96 * nfull, xc = rem - 64;
+  if (xc < 1 || xc > 2) return 1;  // (the cheap tile is two MFMA column tiles + 1..2 VALU columns)
+  if (desc->colvec || desc->pos || desc->gate_scale != 0.f) return 1;
+  int rb = 0;
+  GemmDev g{};
+  g.d = *desc;
+  for (int s = 0; s < desc->nseg; ++s) {
+    const CarcaGemmSeg& sg = desc->seg[s];
+    if (sg.add || sg.gate || sg.rowscale || sg.add_pos) return 1;  // (the VALU columns take the plain epilogue only)
+    if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
+    g.rb_start[s] = rb;
+    rb += (sg.rows + 383) / 384;
+  }
+  g.rb_start[desc->nseg] = rb;
+  g.nrb = rb;
+  g.ncb = ncb;
+  int grid = rb * ncb;
+  const int nfast = desc->K0 / 32, ntail = (desc->K0 + 31) / 32 - nfast + (desc->K1 + 31) / 32;
+  if (grid > carca_num_cus() || nfast < 64) return 1;  // (one round: every workgroup resident, nobody waits for an unborn giver)
+  // balance: owner (nfast - don + ntail) steps of a full tile; giver nfull * don of them + its own (nfast + ntail) steps at
+  // c of a full step (two MFMA column tiles of three + the VALU columns).  Tuning key 4 overrides don.
+  const double c = (2.0 + 0.08 * xc) / 3.0;
+  int don = (int)((1.0 - c) * (nfast + ntail) / ncb + 0.5);
+  if (carca_tuning(4) > 0) don = carca_tuning(4);
+  if (don < 1 || don >= nfast) return 1;
+  g.sk_don = don;
+  g.diag = carca_tuning(5);
+  // The item-row gather does NOT ride in this launch (rode stays 0: the caller launches it, 8 us): the lone passenger
+  // workgroup is a latency chain of ~100 rounds that takes ~455 us on an idle chip and ~540 us beside the tiles -- invisible
+  // under gemm_rows_cu_kernel's 535 us, the long pole here (measured: 0.640 ms per forward with it, 0.614 without; more
+  // rows or both 64-column pieces in flight made the compiler serialise the loads: 1.2 / 0.74 ms).
+  (void)pas;
+  (void)rode;
+  const size_t n_part = (size_t)rb * nfull, flag_bytes = (n_part * sizeof(int) + 255) / 256 * 256;
+  const size_t bytes = flag_bytes + n_part * 384 * 96 * sizeof(float);
+  int slot = -1;
+  char* buf;
+  if (carca_stream_capturing(stream)) {
+    buf = (char*)carca_capture_alloc(bytes, false, nullptr);
+    if (!buf) return (int)hipErrorOutOfMemory;
+    (void)hipMemsetAsync(buf, 0, flag_bytes, stream);
+  } else {
+    if (!g_sk_init) {
+      for (int i = 0; i < SK_RING; ++i) (void)hipEventCreateWithFlags(&g_sk_ev[i], hipEventDisableTiming);
+      g_sk_init = true;
+    }
+    slot = g_sk_next;
+    g_sk_next = (g_sk_next + 1) % SK_RING;
+    if (g_sk_used[slot]) (void)hipEventSynchronize(g_sk_ev[slot]);
+    if (bytes > g_sk_bytes[slot]) {
+      if (g_sk_buf[slot]) (void)hipFree(g_sk_buf[slot]);
+      g_sk_buf[slot] = nullptr;
+      g_sk_bytes[slot] = 0;
+      if (hipMalloc((void**)&g_sk_buf[slot], bytes) != hipSuccess) return 1;
+      g_sk_bytes[slot] = bytes;
+      (void)hipMemset(g_sk_buf[slot], 0, flag_bytes);  // (the flags: zero between launches from here on -- every taker resets its own)
+    }
+    buf = (char*)g_sk_buf[slot];
+  }
+  g.sk_flag = (int*)buf;
+  g.sk_part = (float*)(buf + flag_bytes);
+  hipEvent_t e0, e1;
+  const bool ev = carca_take_launch_events(&e0, &e1);
+  if (xc == 1) {
+    if (ev) hipExtLaunchKernelGGL((gemm_rows_sk_kernel<1>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
+    else hipLaunchKernelGGL((gemm_rows_sk_kernel<1>), dim3(grid), dim3(768), 0, stream, g);
+  } else {
+    if (ev) hipExtLaunchKernelGGL((gemm_rows_sk_kernel<2>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
+    else hipLaunchKernelGGL((gemm_rows_sk_kernel<2>), dim3(grid), dim3(768), 0, stream, g);
+  }
+  if (slot >= 0) {
+    (void)hipEventRecord(g_sk_ev[slot], stream);
+    g_sk_used[slot] = true;
+  }
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
 static int launch_gemm_rows_n96(const CarcaGemmDesc* desc, hipStream_t stream) {
   GemmDev g{};
   g.d = *desc;
@@ -1137,7 +1564,10 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   switch (c) {
     case GEMM_NARROW_BUF: return launch_gemm_rows<128, 32, 32, 4, true>(desc, stream);
     case GEMM_NARROW: return launch_gemm_rows<128, 32, 32, 4>(desc, stream);
-    case GEMM_CU: return launch_gemm_rows_cu<0>(desc, stream);
+    case GEMM_CU: {
+      const int rc = launch_gemm_rows_sk(desc, stream, nullptr, nullptr);
+      return rc == 1 ? launch_gemm_rows_cu<0>(desc, stream) : rc;
+    }
     case GEMM_CU_STAMPS: return launch_gemm_rows_cu<1>(desc, stream);
     case GEMM_CU128: return launch_gemm_rows_cu<0, 4>(desc, stream);
     case GEMM_WIDE64: return launch_gemm_rows<64, 96, 32, 4, true>(desc, stream);
@@ -1153,8 +1583,11 @@ int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* 
   *rode = 0;
   GemmChoice c;
   if (int rc = gemm_rows_choose(desc, &c)) return rc;
-  if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 8) ga = nullptr;  // (8: never let the gather ride -- A/B switch)
-  if (c == GEMM_CU) return launch_gemm_rows_cu<0, 3>(desc, stream, ga, rode);
+  if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 8 || carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 158) ga = nullptr;  // (8: never let the gather ride -- A/B switch)
+  if (c == GEMM_CU) {
+    const int rc = launch_gemm_rows_sk(desc, stream, ga, rode);
+    return rc == 1 ? launch_gemm_rows_cu<0, 3>(desc, stream, ga, rode) : rc;
+  }
   if (c == GEMM_CU128) return launch_gemm_rows_cu<0, 4>(desc, stream, ga, rode);
   return carca_gemm_rows(desc, stream_);
 }
