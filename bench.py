@@ -542,7 +542,7 @@ def main():
             "timeline": {"gpu_span_ms": gpu_span_ms, "host_issue_ms": host_issue_ms,
                          "note": "GPU time between the first and last launch of the timed region, and host time to "
                                  "issue them; wall >> gpu_span means the host, not the GPU, set the pace"},
-            "roofline": {"kernel": "gemm_rows_cu_kernel (384x96 tile, one block per CU), feature GEMM launch (AllEmbedding feats_embed, carca.py:86)",
+            "roofline": {"kernel": "gemm_rows_sk_kernel (384x96 tiles, one workgroup per CU; the last column block's workgroup trades its padding for K steps of its neighbours), feature GEMM launch (AllEmbedding feats_embed, carca.py:86)",
                          "bound": "mfma", "achieved": feat_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": traffic_note,

@@ -878,10 +878,18 @@ __global__ __launch_bounds__(768) void gemm_rows_sk_kernel(const GemmDev args) {
   if (j == 0) {  // the row block's cheap workgroup (first of the block's five to be dispatched)
     // (args.diag, tuning key 5, timing experiments with wrong results: 1 no partial tiles, 2 takers do not wait / add,
     // 4 no cheap tile)
-    for (int cb = 0; cb < nfull && !(args.diag & 1); ++cb)
+    // Its own tile FIRST, in step with the four owners: the five workgroups of a row block stream the same A rows through
+    // their XCD's L2.  (Partials first -- the first version -- put this workgroup ~30 K steps behind the others and it
+    // fetched the whole A row block from HBM again: PMC 482 -> 823 MB per launch.)  The owners then find their partial
+    // between 0.79 and 0.95 of the kernel; the last one is what the launcher's choice of `don` leaves a margin for.
+    const int n_before = (args.diag & 8) ? nfull / 2 : 0;  // (diag 8: half of the partial tiles BEFORE the cheap tile)
+    for (int cb = 0; cb < n_before && !(args.diag & 1); ++cb)
       cu_tile<3, 0, SK_GIVE>(args, As, Bs, rb, cb * 96, nfast - args.sk_don, nfast, false,
                              args.sk_part + ((size_t)rb * nfull + cb) * (384 * 96), args.sk_flag + rb * nfull + cb);
     if (!(args.diag & 4)) cu_tile<2, XC, SK_PLAIN>(args, As, Bs, rb, nfull * 96, 0, nfast, true, nullptr, nullptr);
+    for (int cb = n_before; cb < nfull && !(args.diag & 1); ++cb)
+      cu_tile<3, 0, SK_GIVE>(args, As, Bs, rb, cb * 96, nfast - args.sk_don, nfast, false,
+                             args.sk_part + ((size_t)rb * nfull + cb) * (384 * 96), args.sk_flag + rb * nfull + cb);
   } else {
     const int cb = j - 1;
     if (args.diag & 2)
@@ -1378,10 +1386,12 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   int grid = rb * ncb;
   const int nfast = desc->K0 / 32, ntail = (desc->K0 + 31) / 32 - nfast + (desc->K1 + 31) / 32;
   if (grid > carca_num_cus() || nfast < 64) return 1;  // (one round: every workgroup resident, nobody waits for an unborn giver)
-  // balance: owner (nfast - don + ntail) steps of a full tile; giver nfull * don of them + its own (nfast + ntail) steps at
-  // c of a full step (two MFMA column tiles of three + the VALU columns).  Tuning key 4 overrides don.
+  // balance: owner (nfast - don + ntail) steps of a full tile; giver its own (nfast + ntail) steps at c of a full step (two
+  // MFMA column tiles of three + the VALU columns: 0.74 measured) + nfull x (don + p) of them, p = 1.5 steps of pipeline fill
+  // per partial tile -- and it must END first (the last owner waits for its partial).  C2: 6 (tools/sk_sweep.py: 4 / 5 / 6 /
+  // 7 / 8 steps 526 / 522 / 520 / 532 / 548 us).  Tuning key 4 overrides don.
   const double c = (2.0 + 0.08 * xc) / 3.0;
-  int don = (int)((1.0 - c) * (nfast + ntail) / ncb + 0.5);
+  int don = (int)(((1.0 - c) * (nfast + ntail) - 1.5 * nfull) / ncb);
   if (carca_tuning(4) > 0) don = carca_tuning(4);
   if (don < 1 || don >= nfast) return 1;
   g.sk_don = don;

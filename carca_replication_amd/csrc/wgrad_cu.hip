@@ -496,7 +496,9 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   // here than on the tile kernel; the joint-embedding dW, 5 per CU, does not)
   if (!forced && (total < (long)g_num_cus * 24 || chunks < 8)) return 1;
   // groups of nnb workgroups (see WgradCuDev): per XCD as many whole groups as fit, the left-over slots group across XCDs
-  g.nxcd = (g_num_cus % 8 == 0 && g.nnb <= g_num_cus / 8) ? 8 : 1;
+  // (one n block: nothing to share -- consecutive workgroups take consecutive ranges, as before the groups; tuning variant 16
+  // forces that numbering for any nnb: A/B switch)
+  g.nxcd = (g_num_cus % 8 == 0 && g.nnb <= g_num_cus / 8 && g.nnb > 1 && carca_tuning(CARCA_TUNE_GEMM_VARIANT) != 16) ? 8 : 1;
   const int per_xcd = g_num_cus / g.nxcd;
   g.gpx = per_xcd / g.nnb;
   g.ngroups = g.nxcd * g.gpx + (g.nxcd * (per_xcd - g.gpx * g.nnb)) / g.nnb;
