@@ -628,3 +628,42 @@ def test_stream_scoring_kernel_equals_oracle_and_per_user_kernels(d, H, L, Ns, B
         assert bool(torch.isfinite(outs["stream"][gi]).all())
         assert float((outs["stream"][gi] - outs["fold"][gi]).abs().max()) < 2e-6
         assert float((outs["stream"][gi] - outs["mat"][gi]).abs().max()) < 2e-6
+
+
+def test_stream_k_feature_gemm_hands_over_fresh_partials():
+    """gemm_rows_sk_kernel (C2's feature GEMM): the last column block's workgroup computes the last K steps of its four
+    neighbours' tiles and hands them over through memory (agent-scope stores, a flag, plain loads on the taker's side --
+    which rely on every launch starting with an invalidated L2).  Alternating two DIFFERENT batches through the same
+    two-slot ring must give, every time, what the one-tile-per-workgroup kernel (tuning variant 15) gives for that batch:
+    a stale partial (5 % of the K sum, from another batch) would show at 1e-2; the two kernels group the K sum
+    differently, so they agree to round-off, not bitwise."""
+    from carca_replication_amd import _lib
+
+    cfg = O.CarcaConfig(d=90, H=3, n_blocks=1)
+    n_items, n_attrs, n_ctx, g, L, N, B = 3000, 4096, 6, 450, 50, 101, 128
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    model = model_from_params(P, cfg).eval()
+    batches = []
+    for seed in (11, 12):
+        profile, target, _ = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=seed)
+        batches.append((dev(profile), dev(target)))
+    lib = _lib.load()
+    with torch.no_grad():
+        lib.carca_set_tuning(0, 15)
+        try:
+            want = [model(profile=p, targets=[t]).clone() for p, t in batches]
+        finally:
+            lib.carca_set_tuning(0, 0)
+        assert float((want[0] - want[1]).abs().max()) > 1e-2  # (the batches really differ)
+        for it in range(8):
+            p, t = batches[it % 2]
+            got = model(profile=p, targets=[t])
+            assert float((got - want[it % 2]).abs().max()) < 2e-5, it
+    # and the embedding itself (q = [a ; c] W_f^T + b_f, every column incl. the two VALU ones) against the oracle
+    profile, target, _ = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=11)
+    trace = {}
+    with torch.no_grad():
+        model.forward_nograd(dev(profile), [dev(target)], trace=trace)
+    p_x, p_a, p_c = profile
+    want_e = O.embedding(P, cfg, p_x[:4].long(), p_a[:4], p_c[:4], (p_x[:4] != 0).float(), False)
+    assert float((trace["p_embed"][:4].cpu() - want_e).abs().max()) < 2e-5
