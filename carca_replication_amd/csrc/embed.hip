@@ -14,12 +14,15 @@
 
 namespace {
 
-// (one wave per row, lanes over columns)
+// (a wave takes RIF rows at a time, lanes over columns.  RIF = 4 with one round per wave: a row is a chain of two dependent
+// round trips -- id, then the row -- and with one row per wave and 2.4 rounds per wave the kernel was 8.2 us of latency for
+// 14 MB of traffic; it has its own launch again since the feature GEMM gave its idle CU's slack away, gemm.hip)
+template <int RIF>
 __global__ void gather_items_kernel(const CarcaGatherArgs ga) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  carca_gather_rows<1>(ga, wave, nwaves, lane);
+  carca_gather_rows<RIF>(ga, wave, nwaves, lane);
 }
 
 }  // namespace
@@ -62,8 +65,12 @@ extern "C" int carca_embed_fwd(const CarcaRowSeg* segs, int nseg, int n_attrs, i
 
   ga.items_w = items_w; ga.zq = zq; ga.d = d; ga.ldz = ldz; ga.total_rows = total_rows; ga.scale = (float)sqrt((double)d);
   auto launch_gather = [&]() -> int {
-    const int blocks = min((total_rows + 3) / 4, 2048);
-    hipLaunchKernelGGL(gather_items_kernel, dim3(blocks), dim3(256), 0, stream, ga);
+    const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);  // (18: one row per wave, 2048 blocks at most -- A/B switch)
+    if (variant == 18) {
+      hipLaunchKernelGGL(gather_items_kernel<1>, dim3(min((total_rows + 3) / 4, 2048)), dim3(256), 0, stream, ga);
+    } else {
+      hipLaunchKernelGGL(gather_items_kernel<4>, dim3(min((total_rows + 15) / 16, 8192)), dim3(256), 0, stream, ga);
+    }
     CARCA_LAUNCH_CHECK();
     return CARCA_OK;
   };

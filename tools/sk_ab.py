@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 model = bench.build_model(c, dev)
 _, _, profile, target = bench.build_inputs(c, 1234, dev)
 lib = _lib.load()
-CONF = {"cu + passenger": (15, 0), "sk, own gather launch": (0, 0), "cu, own gather launch": (158, 0)}
+CONF = {"cu + passenger": (15, 0), "sk, own gather launch": (0, 0), "sk, gather one row per wave (18)": (18, 0), "cu, own gather launch": (158, 0)}
 res = {k: [] for k in CONF}
 with torch.no_grad():
     for rnd in range(5):
