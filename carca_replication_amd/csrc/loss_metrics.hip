@@ -5,20 +5,46 @@
 namespace {
 
 // One 1024-thread block: fixed summation order, so the loss is bitwise reproducible run to run.
+// Up to 16 elements per thread (n <= 16384: every batch of the reference's shapes) are loaded ONCE, all at the same time,
+// through clamped indices (no load sits behind a branch: hipcc would wait for each before issuing the next), and the
+// gradient pass reuses the registers -- the two-pass loop over global memory was 12.7 us of dependent round trips for
+// 12,800 elements on one CU; larger batches keep the loop.
+constexpr int BCE_PER = 16;
 __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ y, const int32_t* __restrict__ y_true,
                                                    const int32_t* __restrict__ ids, int n, float eps,
                                                    float* __restrict__ scratch, float* __restrict__ loss_out,
                                                    float* __restrict__ dy, const float* __restrict__ denom) {
   __shared__ float red[2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool small = n <= 1024 * BCE_PER;
+  float pr[BCE_PER], tr[BCE_PER], mr[BCE_PER];
   float sl = 0.f, sm = 0.f;
-  for (int i = tid; i < n; i += 1024) {
-    const float m = ids[i] != 0 ? 1.f : 0.f;
-    const float t = (float)y_true[i];
-    const float p = y[i];
-    const float l = -(t * logf(p + eps) + (1.0f - t) * logf(1.0f - p + eps));
-    sl += l * m;
-    sm += m;
+  if (small) {
+#pragma unroll
+    for (int j = 0; j < BCE_PER; ++j) {
+      const int i = min(tid + 1024 * j, n - 1);
+      pr[j] = y[i];
+      tr[j] = (float)y_true[i];
+      mr[j] = ids[i] != 0 ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < BCE_PER; ++j) {  // (same order of additions as the loop below: element tid + 1024 j in turn)
+      if (tid + 1024 * j >= n) mr[j] = 0.f;
+      const float l = -(tr[j] * logf(pr[j] + eps) + (1.0f - tr[j]) * logf(1.0f - pr[j] + eps));
+      if (tid + 1024 * j < n) {
+        sl += l * mr[j];
+        sm += mr[j];
+      }
+    }
+  } else {
+    for (int i = tid; i < n; i += 1024) {
+      const float m = ids[i] != 0 ? 1.f : 0.f;
+      const float t = (float)y_true[i];
+      const float p = y[i];
+      const float l = -(t * logf(p + eps) + (1.0f - t) * logf(1.0f - p + eps));
+      sl += l * m;
+      sm += m;
+    }
   }
   sl = wave_sum(sl);
   sm = wave_sum(sm);
@@ -43,12 +69,19 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ y, 
   if (dy) {
     __syncthreads();
     const float inv = 1.0f / red[0][0];
-    for (int i = tid; i < n; i += 1024) {
-      const float m = ids[i] != 0 ? 1.f : 0.f;
-      const float t = (float)y_true[i];
-      const float p = y[i];
-      // d/dp of -(t log(p+eps) + (1-t) log(1-p+eps)); NOT (p - t)/(p(1-p)) because of eps
-      dy[i] = m * inv * (-(t / (p + eps)) + (1.0f - t) / (1.0f - p + eps));
+    // d/dp of -(t log(p+eps) + (1-t) log(1-p+eps)); NOT (p - t)/(p(1-p)) because of eps
+    if (small) {
+#pragma unroll
+      for (int j = 0; j < BCE_PER; ++j)
+        if (tid + 1024 * j < n)
+          dy[tid + 1024 * j] = mr[j] * inv * (-(tr[j] / (pr[j] + eps)) + (1.0f - tr[j]) / (1.0f - pr[j] + eps));
+    } else {
+      for (int i = tid; i < n; i += 1024) {
+        const float m = ids[i] != 0 ? 1.f : 0.f;
+        const float t = (float)y_true[i];
+        const float p = y[i];
+        dy[i] = m * inv * (-(t / (p + eps)) + (1.0f - t) / (1.0f - p + eps));
+      }
     }
   }
 }

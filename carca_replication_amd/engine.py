@@ -245,9 +245,11 @@ class GraphedTrainStep:
 
 
 @torch.no_grad()
-def eval_batch(model, batch, k: int = 10, sums: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+def eval_batch(model, batch, k: int = 10, sums: Optional[torch.Tensor] = None,
+               count_users: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Scores one (p_x, p_a, p_c, o_x, o_a, o_c, y_true) eval batch (train.py:42-51); accumulates
-    [HR@k sum, NDCG@k sum, ties, loss sum, users] into `sums` (device float[5]) with no host sync."""
+    [HR@k sum, NDCG@k sum, ties, loss sum, users] into `sums` (device float[5]) with no host sync.
+    count_users=False: the caller counts the users itself (a host integer: one tiny launch less per batch)."""
     p_x, p_a, p_c, o_x, o_a, o_c, y_true = as_batch7(batch)
     y = model(profile=(p_x, p_a, p_c), targets=[(o_x, o_a, o_c)])
     y2 = y.reshape(p_x.shape[0], -1)
@@ -259,5 +261,6 @@ def eval_batch(model, batch, k: int = 10, sums: Optional[torch.Tensor] = None) -
     else:
         loss = _loss_fn(y2, y_true, get_mask(o_x))
     sums[3] += loss
-    sums[4] += p_x.shape[0]
+    if count_users:
+        sums[4] += p_x.shape[0]
     return y, sums
