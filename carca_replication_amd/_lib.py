@@ -264,6 +264,7 @@ SIGNATURES = {
     "carca_stream_wait_event": (_i, [_fp, _fp]),
     "carca_bce_fwd": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp, _fp, _fp]),
     "carca_rank_metrics": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    "carca_eval_metrics": (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _fp, _fp]),
     "carca_layernorm_fwd": (_i, [_fp, _i, _fp, _i, _i, _i, _fp, _fp, _fp]),
     "carca_dot_score_fwd": (_i, [_fp, _i, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     "carca_dot_score_bwd": (_i, [_fp, _i, _fp, _i, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, _i, _fp]),

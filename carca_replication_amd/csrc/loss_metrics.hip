@@ -158,7 +158,118 @@ __global__ __launch_bounds__(1024) void rank_ordered_kernel(const float* __restr
   }
 }
 
+// One evaluation batch's metrics in ONE launch (train.py:45-51: BCE loss, compute_HR, compute_NDCG): sums[0..2] as
+// rank_ordered_kernel (fixed order), sums[3] += the batch's masked-mean BCE loss (bce_kernel's arithmetic and order),
+// sums[4] += B.  The evaluation loop issued a rank kernel, a loss kernel and two one-element adds per batch -- ~15 us of
+// launches behind a 610 us forward.  n = B N <= 16384.
+__global__ __launch_bounds__(1024) void eval_metrics_kernel(const float* __restrict__ y, const int32_t* __restrict__ y_true,
+                                                            const int32_t* __restrict__ ids, int B, int N, int k, float eps,
+                                                            float* __restrict__ sums) {
+  __shared__ float red[5][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = B * N;
+  float pr[BCE_PER], tr[BCE_PER], mr[BCE_PER];
+#pragma unroll
+  for (int j = 0; j < BCE_PER; ++j) {
+    const int i = min(tid + 1024 * j, n - 1);
+    pr[j] = y[i];
+    tr[j] = (float)y_true[i];
+    mr[j] = ids[i] != 0 ? 1.f : 0.f;
+  }
+  float hr = 0.f, nd = 0.f, ties = 0.f;
+  constexpr int UPW = 12;  // users per wave whose scores are all requested before the first is looked at (N <= 128)
+  if (N <= 128 && B <= 16 * UPW) {
+    // (the reference's evaluation shape, 1 + 100 candidates: a wave's <= 12 users are 24 loads in flight instead of a chain
+    // of 12 dependent round trips)
+    float v0[UPW], v1[UPW], y0[UPW];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+      const int u = min(wave + 16 * i, B - 1);
+      const float* yr = y + (size_t)u * N;
+      y0[i] = yr[0];
+      v0[i] = yr[min(1 + lane, N - 1)];
+      v1[i] = yr[min(65 + lane, N - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+      const bool in0 = 1 + lane < N, in1 = 65 + lane < N;
+      float gt = (in0 && v0[i] > y0[i] ? 1.f : 0.f) + (in1 && v1[i] > y0[i] ? 1.f : 0.f);
+      float eq = (in0 && v0[i] == y0[i] ? 1.f : 0.f) + (in1 && v1[i] == y0[i] ? 1.f : 0.f);
+      gt = wave_sum(gt);
+      eq = wave_sum(eq);
+      if (wave + 16 * i < B) {
+        const int r = (int)gt;
+        if (r < k) {
+          hr += 1.0f;
+          nd += 1.0f / log2f((float)r + 2.0f);
+        }
+        ties += eq;
+      }
+    }
+  } else {
+    for (int u = wave; u < B; u += 16) {  // (the positive is candidate 0: data.py:165,190)
+      const float* yr = y + (size_t)u * N;
+      const float y0 = yr[0];
+      float gt = 0.f, eq = 0.f;
+      for (int j = 1 + lane; j < N; j += 64) {
+        const float v = yr[j];
+        gt += v > y0 ? 1.f : 0.f;
+        eq += v == y0 ? 1.f : 0.f;
+      }
+      gt = wave_sum(gt);
+      eq = wave_sum(eq);
+      const int r = (int)gt;
+      if (r < k) {
+        hr += 1.0f;
+        nd += 1.0f / log2f((float)r + 2.0f);
+      }
+      ties += eq;
+    }
+  }
+  float sl = 0.f, sm = 0.f;
+#pragma unroll
+  for (int j = 0; j < BCE_PER; ++j) {
+    const float l = -(tr[j] * logf(pr[j] + eps) + (1.0f - tr[j]) * logf(1.0f - pr[j] + eps));
+    if (tid + 1024 * j < n) {
+      sl += l * mr[j];
+      sm += mr[j];
+    }
+  }
+  sl = wave_sum(sl);
+  sm = wave_sum(sm);
+  if (lane == 0) {
+    red[0][wave] = hr;
+    red[1][wave] = nd;
+    red[2][wave] = ties;
+    red[3][wave] = sl;
+    red[4][wave] = sm;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float a = lane < 16 ? red[3][lane] : 0.f, b = lane < 16 ? red[4][lane] : 0.f;  // (bce_kernel's order: a wave reduction of the sixteen)
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane < 3) {
+      float s = 0.f;
+      for (int w = 0; w < 16; ++w) s += red[lane][w];
+      if (s != 0.f) sums[lane] += s;
+    }
+    if (lane == 3) sums[3] += a / b;
+    if (lane == 4) sums[4] += (float)B;
+  }
+}
+
 }  // namespace
+
+extern "C" int carca_eval_metrics(const float* y, const int32_t* y_true, const int32_t* ids, int B, int N, int k, float eps,
+                                  float* sums, void* stream_) {
+  CARCA_CHECK_ARG(y && y_true && ids && sums && B >= 1 && N >= 1 && k >= 1, "eval_metrics: null pointer or bad dims");
+  CARCA_CHECK_SUPPORTED((long)B * N <= 1024L * BCE_PER, "eval_metrics: B x N = %ld > %d (use carca_rank_metrics + carca_bce_fwd)",
+                        (long)B * N, 1024 * BCE_PER);
+  hipLaunchKernelGGL(eval_metrics_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_, y, y_true, ids, B, N, k, eps, sums);
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
 
 extern "C" int carca_bce_fwd(const float* y, const int32_t* y_true, const int32_t* ids, int n, float eps,
                              float* scratch, float* loss_out, float* dy, const float* denom, void* stream_) {

@@ -245,22 +245,25 @@ class GraphedTrainStep:
 
 
 @torch.no_grad()
-def eval_batch(model, batch, k: int = 10, sums: Optional[torch.Tensor] = None,
-               count_users: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+def eval_batch(model, batch, k: int = 10, sums: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Scores one (p_x, p_a, p_c, o_x, o_a, o_c, y_true) eval batch (train.py:42-51); accumulates
-    [HR@k sum, NDCG@k sum, ties, loss sum, users] into `sums` (device float[5]) with no host sync.
-    count_users=False: the caller counts the users itself (a host integer: one tiny launch less per batch)."""
+    [HR@k sum, NDCG@k sum, ties, loss sum, users] into `sums` (device float[5]) with no host sync -- one launch
+    (carca_eval_metrics) for batches of up to 16384 scores, else the rank kernel, the loss kernel and two adds."""
     p_x, p_a, p_c, o_x, o_a, o_c, y_true = as_batch7(batch)
     y = model(profile=(p_x, p_a, p_c), targets=[(o_x, o_a, o_c)])
     y2 = y.reshape(p_x.shape[0], -1)
     if sums is None:
         sums = torch.zeros(5, dtype=torch.float32, device=y.device)
+    if (o_x.dtype == torch.int32 and y2.is_contiguous() and y2.numel() <= ops.EVAL_METRICS_MAX and sums.is_contiguous()
+            and y_true.shape == y2.shape):
+        # HR / NDCG / loss / user count of the batch in ONE launch (the positive is candidate 0, data.py:165,190)
+        ops.eval_metrics(y2, y_true, o_x, k, sums)
+        return y, sums
     ops.rank_metrics(y2, k, sums=sums[:3])
     if o_x.dtype == torch.int32 and y2.is_contiguous():  # the loss kernel masks by ids != 0 itself (no float mask)
         loss, _ = ops.bce_fwd(y2, y_true, o_x, 1e-8)
     else:
         loss = _loss_fn(y2, y_true, get_mask(o_x))
     sums[3] += loss
-    if count_users:
-        sums[4] += p_x.shape[0]
+    sums[4] += p_x.shape[0]
     return y, sums

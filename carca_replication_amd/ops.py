@@ -486,6 +486,23 @@ def bce_fwd(y: Tensor, y_true: Tensor, ids: Tensor, eps: float = 1e-8, want_grad
     return loss[0], dy
 
 
+EVAL_METRICS_MAX = 16384  # elements of one batch that carca_eval_metrics takes
+
+
+def eval_metrics(y: Tensor, y_true: Tensor, ids: Tensor, k: int, sums: Tensor, eps: float = 1e-8) -> None:
+    """sums [5] += [HR@k, NDCG@k, ties, masked-mean BCE loss, users] of one evaluation batch y [B, N] (positive in column
+    0), one launch (train.py:45-51)."""
+    _need_cuda(y, y_true, ids, sums)
+    y = _f32(y)
+    B, N = y.shape
+    yt, ids32 = _ids32(y_true), _ids32(ids)
+    if sums.dtype != torch.float32 or sums.numel() < 5 or not sums.is_contiguous() or yt.numel() != y.numel() or \
+            ids32.numel() != y.numel():
+        raise CarcaHipError("eval_metrics: sums must be float32[5], y_true / ids of y's shape")
+    _lib.check(_lib.load().carca_eval_metrics(y.data_ptr(), yt.data_ptr(), ids32.data_ptr(), B, N, k, eps, sums.data_ptr(),
+                                              _stream()), "eval_metrics")
+
+
 def rank_metrics(y: Tensor, k: int, sums: Optional[Tensor] = None, want_rank: bool = False,
                  pos: Optional[Tensor] = None):
     """Accumulates [HR@k sum, NDCG@k sum, ties] into `sums` (device float[3]) for y [B, N]; the positive sits in

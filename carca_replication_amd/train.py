@@ -90,14 +90,12 @@ def evaluate(model: Model, loader: DataLoader, device: str, k: int) -> Tuple[flo
     device_data.DeviceLoader (batches built in HBM; the model needs its attribute table: register_attr_table)."""
     model = model.eval().to(device)
     sums = torch.zeros(5, dtype=torch.float32, device=device)
-    n_batches = users = 0
+    n_batches = 0
     with torch.no_grad():
         for batch in loader:
-            dev_batch = to(*engine.as_batch7(batch), device=device)
-            engine.eval_batch(model, dev_batch, k=k, sums=sums, count_users=False)
+            engine.eval_batch(model, to(*engine.as_batch7(batch), device=device), k=k, sums=sums)
             n_batches += 1
-            users += dev_batch[0].shape[0]
-    hr, ndcg, _ties, loss_sum, _ = (float(v) for v in sums.cpu())
+    hr, ndcg, _ties, loss_sum, users = (float(v) for v in sums.cpu())
     return hr / users, ndcg / users, loss_sum / max(n_batches, 1)
 
 

@@ -628,6 +628,11 @@ int carca_bce_fwd(const float* y, const int32_t* y_true, const int32_t* ids, int
  * rank[u] = #{j != p : y[u][j] > y[u][p]}; sums[0] += [rank < k], sums[1] += [rank<k]/log2(rank+2),
  * sums[2] += #{j != p : y[u][j] == y[u][p]} (ties: the reference's unstable sort is undefined there).
  * sums is accumulated into (caller zeroes it once per evaluation). */
+/* One evaluation batch of train.py:41-51 in one launch: sums[0..2] as carca_rank_metrics with the positive in column 0
+ * (data.py:165,190), sums[3] += BinaryCrossEntropy(y, y_true, ids != 0) (carca.py:441-444), sums[4] += B; fixed summation
+ * order (reproducible).  B x N <= 16384, else CARCA_ERR_UNSUPPORTED (use the two calls). */
+int carca_eval_metrics(const float* y /*[B,N]*/, const int32_t* y_true, const int32_t* ids, int B, int N, int k, float eps,
+                       float* sums /*[5]*/, void* stream);
 int carca_rank_metrics(const float* y /*[B,N]*/, int B, int N, int k, const int32_t* pos /*[B] or NULL*/,
                        int32_t* rank /*[B] or NULL*/, float* sums /*[3]*/, void* stream);
 

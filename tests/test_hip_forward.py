@@ -667,3 +667,29 @@ def test_stream_k_feature_gemm_hands_over_fresh_partials():
     p_x, p_a, p_c = profile
     want_e = O.embedding(P, cfg, p_x[:4].long(), p_a[:4], p_c[:4], (p_x[:4] != 0).float(), False)
     assert float((trace["p_embed"][:4].cpu() - want_e).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("B,N", [(128, 101), (7, 21), (16, 1001), (1, 2)])
+def test_eval_metrics_in_one_launch_equals_the_separate_kernels(B, N):
+    """carca_eval_metrics (HR@k, NDCG@k, ties, masked-mean BCE loss, user count of one evaluation batch in one launch,
+    train.py:45-51) against carca_rank_metrics + carca_bce_fwd, and the loss against the oracle's."""
+    from carca_replication_amd import ops
+
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    y = torch.rand(B, N, generator=g).clamp(1e-4, 1 - 1e-4)
+    y[B // 2, 1] = y[B // 2, 0]  # a tie
+    ids = torch.randint(0, 50, (B, N), generator=g).int()
+    ids[:, 0] = 7
+    y_true = torch.zeros(B, N, dtype=torch.int32)
+    y_true[:, 0] = 1
+    yd, idd, ytd = y.cuda(), ids.cuda(), y_true.cuda()
+    sums = torch.zeros(5, device="cuda")
+    sums[0] = 3.0  # (accumulated into)
+    ops.eval_metrics(yd, ytd, idd, 10, sums)
+    ref, _ = ops.rank_metrics(yd, 10)
+    loss, _ = ops.bce_fwd(yd, ytd, idd, 1e-8)
+    assert float(sums[0]) == 3.0 + float(ref[0]) and float(sums[2]) == float(ref[2]) >= 1.0
+    assert abs(float(sums[1]) - float(ref[1])) <= 1e-5 * max(1.0, float(ref[1]))
+    assert float(sums[3]) == float(loss) and float(sums[4]) == B
+    want = O.bce_loss(y, y_true, (ids != 0).float())
+    assert abs(float(sums[3]) - float(want)) < 2e-6
