@@ -5,7 +5,7 @@
 // Why another kernel.  Above #CUs users cross_fold_kernel ran as 8-wave workgroups, two per CU, each (target tile, head)
 // job fetching its head's W_Q tile (12 KB at d = 90) and its target rows (6 KB) from L2: 21 jobs x 18 KB + W_K 36 KB +
 // the profile = ~430 KB per user through a CU's load-return path, which delivers 12-20 B per cycle whatever the source
-//  -- ~27 k cycles per user against an MFMA floor of 18 k, and the phases of a user (LayerNorm, K
+// (TUNING.md) -- ~27 k cycles per user against an MFMA floor of 18 k, and the phases of a user (LayerNorm, K
 // projection, jobs) are separated by workgroup barriers that idle three of four SIMD slots in turn.  Here
 //   * W_Q and W_K (fragment order, 2 x 36 KB at d = 90) are brought into LDS ONCE per workgroup and stay there for all of
 //     its users: the only per-user global traffic is the profile rows (once) and the target rows;
