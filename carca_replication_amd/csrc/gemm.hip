@@ -1113,6 +1113,11 @@ struct WgradDev {
   int chunk_start[CARCA_MAX_SEGS + 1];  // 32-row chunks per segment, prefix sums
   int nnb, nkb, nkb0, nsplit, chunks_per_split;
   int diag_plain_store;  // diagnostic (tuning key 3): overwrite instead of atomicAdd, to time the kernel without atomics
+  // Row splits WITHOUT atomics: block (split, nb, kb) stores its 96 x 128 tile plainly, in register order, at
+  // part[((split * nnb + nb) * nkb + kb) * 12288 ..] and wgrad_part_reduce adds a tile's splits in order into dw.  (A/B at
+  // C2 with plain stores in place of the atomics, wrong results: train step -43 us -- an fp32 atomic costs ~5 ns and the
+  // thirteen d x d products + the joint-embedding dW issue 11 M of them per step.)  NULL = atomics (grad_add).
+  float* part;
 };
 
 template <int BNO, int BKO, int BR, bool BUF>
@@ -1252,7 +1257,13 @@ __device__ __forceinline__ void wgrad_body(const WgradDev& args, int b) {
 
   // D row (= n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (= k) = lane&31
   const int k = k0 + wave * 32 + lr;
-  if (k < klen) {
+  if (args.part) {
+    float* dst = args.part + ((size_t)(split * args.nnb + nb) * args.nkb + kb) * (BNO * BKO);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * NT + tid] = acc[t][r];
+  } else if (k < klen) {
     const int kcol = (src1 ? D.K : 0) + k;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -1289,6 +1300,51 @@ __global__ __launch_bounds__(256) void gemm_wgrad_group_kernel(const WgradDev* _
   for (int i = 1; i < idx.n; ++i)
     if ((int)blockIdx.x >= idx.block_start[i]) p = i;
   wgrad_body<BNO, BKO, BR, true>(devs[p], (int)blockIdx.x - idx.block_start[p]);
+}
+
+// dw tile (nb, kb) += its splits' partial tiles, in split order (fixed: bit-reproducible).  12 blocks of 256 threads per
+// tile; a thread takes four consecutive floats of the register-order tile: the same n, four consecutive k.
+__device__ __forceinline__ void wgrad_part_reduce_body(const WgradDev& g, int lb) {
+  const CarcaWgradDesc& D = g.d;
+  const int tile = lb / 12, sl = lb - tile * 12;
+  const int nb = tile / g.nkb, kb = tile - nb * g.nkb;
+  const int q = (sl * 256 + (int)threadIdx.x) * 4;  // 0 .. 12284
+  const int e = q >> 8, t = q & 255;
+  const int wave = t >> 6, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+  const size_t tile_fl = 96 * 128;
+  // eight splits' loads in flight at a time (a plain loop waits for every load before it issues the next: 22 us for
+  // 40 MB); the additions stay in split order
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  const float* base = g.part + ((size_t)nb * g.nkb + kb) * tile_fl + q;
+  const size_t step = (size_t)g.nnb * g.nkb * tile_fl;
+  int s = 0;
+  for (; s + 8 <= g.nsplit; s += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(s + i) * step);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += v[i];
+  }
+  for (; s < g.nsplit; ++s) sum += *reinterpret_cast<const f32x4*>(base + (size_t)s * step);
+  const int tt = e >> 4, r = e & 15;
+  const int n = nb * 96 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+  if (n >= D.N) return;
+  const bool src1 = kb >= g.nkb0;
+  const int k0 = (src1 ? kb - g.nkb0 : kb) * 128, klen = src1 ? D.K1 : D.K;
+  float* row = D.dw + (size_t)n * D.ldw + (src1 ? D.K : 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + wave * 32 + lr + i;
+    if (k < klen) row[k] += sum[i];
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_part_reduce_kernel(const WgradDev g) { wgrad_part_reduce_body(g, blockIdx.x); }
+__global__ __launch_bounds__(256) void wgrad_part_reduce_group_kernel(const WgradDev* __restrict__ devs,
+                                                                      const WgradGroupIndex idx) {
+  int p = 0;
+  for (int i = 1; i < idx.n; ++i)
+    if ((int)blockIdx.x >= idx.block_start[i]) p = i;
+  wgrad_part_reduce_body(devs[p], (int)blockIdx.x - idx.block_start[p]);
 }
 
 }  // namespace
@@ -1690,7 +1746,8 @@ static int wgrad_prepare(const CarcaWgradDesc* desc, WgradDev& g, bool* fits_out
   // (N = 90, K = 540, 19328 rows: 1024 slots 74.5 us, 768 65.8, 640 61.6, 512 59.6, 384 57.5, 256 67.6)
   const int slots = slot_budget > 0 ? slot_budget
                     : carca_tuning(CARCA_TUNE_WGRAD_SLOTS) > 0 ? carca_tuning(CARCA_TUNE_WGRAD_SLOTS)
-                    : tiles >= 64 ? 1024 : 384;
+                    : tiles >= 64 ? 1024 : 640;  // (640 since the splits end in plain stores: 384 / 512 / 640 / 768 / 1024 -> train
+                                                 // step 1.749 / 1.743 / 1.737 / 1.740 / 1.736 ms, tools/ab_train.py "2=...")
   int nsplit = tiles >= slots ? 1 : slots / tiles;
   const int min_chunks = carca_tuning(4) > 0 ? carca_tuning(4) : 2;  // (measured on the d x d products: 4 -> 21 us, 2 -> 18 us, 1 -> 23 us)
   nsplit = max(1, min(nsplit, (chunks + min_chunks - 1) / min_chunks));
@@ -1716,6 +1773,44 @@ static int wgrad_prepare(const CarcaWgradDesc* desc, WgradDev& g, bool* fits_out
   return tiles * g.nsplit;
 }
 
+// Partial tiles of the row splits (WgradDev.part): a four-slot ring of the library's own, a slot reused behind the event of
+// its last reduce launch; inside a hipGraph capture the graph gets storage of its own.  Tuning variant 19 = atomics (A/B).
+namespace {
+constexpr int WPART_RING = 4;
+float* g_wpart[WPART_RING] = {nullptr};
+size_t g_wpart_floats[WPART_RING] = {0};
+hipEvent_t g_wpart_ev[WPART_RING];
+bool g_wpart_used[WPART_RING] = {false}, g_wpart_init = false;
+int g_wpart_next = 0;
+float* wpart_take(size_t floats, hipStream_t stream, int* slot) {
+  *slot = -1;
+  if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 19 || carca_tuning(3) != 0) return nullptr;
+  if (carca_stream_capturing(stream)) return (float*)carca_capture_alloc(floats * sizeof(float), false, nullptr);
+  if (!g_wpart_init) {
+    for (int i = 0; i < WPART_RING; ++i) (void)hipEventCreateWithFlags(&g_wpart_ev[i], hipEventDisableTiming);
+    g_wpart_init = true;
+  }
+  const int s = g_wpart_next;
+  g_wpart_next = (g_wpart_next + 1) % WPART_RING;
+  if (g_wpart_used[s]) (void)hipEventSynchronize(g_wpart_ev[s]);
+  if (floats > g_wpart_floats[s]) {
+    if (g_wpart[s]) (void)hipFree(g_wpart[s]);
+    g_wpart[s] = nullptr;
+    g_wpart_floats[s] = 0;
+    if (hipMalloc((void**)&g_wpart[s], (floats + floats / 8) * sizeof(float)) != hipSuccess) return nullptr;
+    g_wpart_floats[s] = floats + floats / 8;
+  }
+  *slot = s;
+  return g_wpart[s];
+}
+void wpart_done(int slot, hipStream_t stream) {
+  if (slot >= 0) {
+    (void)hipEventRecord(g_wpart_ev[slot], stream);
+    g_wpart_used[slot] = true;
+  }
+}
+}  // namespace
+
 extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int rc = wgrad_check(desc)) return rc;
@@ -1729,10 +1824,17 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   WgradDev g;
   bool fits = false;
   const int grid = wgrad_prepare(desc, g, &fits);
+  int pslot = -1;
+  const int tiles = g.nnb * g.nkb;
+  if (g.nsplit > 1) g.part = wpart_take((size_t)g.nsplit * tiles * BNO * BKO, stream, &pslot);  // (one split: nothing to combine)
   if (fits)
     hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR, true>), dim3(grid), dim3(256), 0, stream, g);
   else
     hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR>), dim3(grid), dim3(256), 0, stream, g);
+  if (g.part) {
+    hipLaunchKernelGGL(wgrad_part_reduce_kernel, dim3(tiles * 12), dim3(256), 0, stream, g);
+    wpart_done(pslot, stream);
+  }
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
@@ -1781,8 +1883,9 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
       host = g_group_host + (size_t)slot * WGRAD_GROUP_MAX;
       dev = g_group_dev + (size_t)slot * WGRAD_GROUP_MAX;
     }
-    WgradGroupIndex idx{};
-    int blocks = 0;
+    WgradGroupIndex idx{}, ridx{};
+    int blocks = 0, rblocks = 0;
+    size_t part_floats = 0;
     while (done < n && idx.n < WGRAD_GROUP_MAX) {
       bool fits = false;
       WgradDev g;
@@ -1792,7 +1895,8 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
       // Second look with the kernel trace (tools/train_trace.sh, 13 products of a C2 backward pass in one launch):
       // 1024 slots per product (100 two-chunk splits each) 105 us, 64 -> 72 us, 48 -> 73, 40 -> 76, 32 -> 76, 24 -> 92,
       // 16 -> 108: every split ends with a 96 x 128 tile of atomics, so fewer, longer splits win until the chip runs dry
-      const int budget = carca_tuning(5) > 0 ? carca_tuning(5) : 64;
+      // (with partial tiles instead of atomics: 32 -> 1.766 ms per train step, 64 -> 1.744, 96 -> 1.742, 128 -> 1.752)
+      const int budget = carca_tuning(5) > 0 ? carca_tuning(5) : 96;
       const int grid = wgrad_prepare(&descs[done], g, &fits, budget);
       const bool big = (long)descs[done].N * (descs[done].K + descs[done].K1) > 96 * 1024;  // single-product path decides
       if (!fits || big || variant == 6) {  // (variant 6: never group -- A/B switch)
@@ -1802,13 +1906,31 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
       }
       host[idx.n] = g;
       idx.block_start[idx.n] = blocks;
+      ridx.block_start[idx.n] = rblocks;
       blocks += grid;
+      rblocks += g.nnb * g.nkb * 12;
+      part_floats += (size_t)g.nsplit * g.nnb * g.nkb * BNO * BKO;
       ++idx.n;
       ++done;
     }
     if (idx.n == 0) continue;
     idx.block_start[idx.n] = blocks;
+    ridx.n = idx.n;
+    ridx.block_start[idx.n] = rblocks;
+    int pslot = -1;
+    float* part = wpart_take(part_floats, stream, &pslot);
+    if (part) {  // every product its own stretch of the slot
+      size_t at = 0;
+      for (int i = 0; i < idx.n; ++i) {
+        host[i].part = part + at;
+        at += (size_t)host[i].nsplit * host[i].nnb * host[i].nkb * BNO * BKO;
+      }
+    }
     hipLaunchKernelGGL((gemm_wgrad_group_kernel<BNO, BKO, BR>), dim3(blocks), dim3(256), 0, stream, dev, idx);
+    if (part) {
+      hipLaunchKernelGGL(wgrad_part_reduce_group_kernel, dim3(rblocks), dim3(256), 0, stream, dev, ridx);
+      wpart_done(pslot, stream);
+    }
     if (slot >= 0) {
       (void)hipEventRecord(g_group_ev[slot], stream);
       g_group_used[slot] = true;
