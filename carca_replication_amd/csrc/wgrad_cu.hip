@@ -412,12 +412,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradCuDev args
   const long u0 = (long)kb * nchunks, u1 = u0 + nchunks;
   const int g_lo = args.klo[2 * kb], g_hi = args.klo[2 * kb + 1];
   const size_t tile_fl = (size_t)WG_BN * WG_BK;
+  // four groups' partials in flight at a time (a plain loop waits for every load before the next is issued), added in group
+  // order; a group without units in this k block contributes its slot 0 times 0
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-  for (int g2 = g_lo; g2 <= g_hi; ++g2) {
-    const long b2 = args.gbegin[g2];
-    if (min(args.gbegin[g2 + 1], u1) <= max(b2, u0)) continue;
-    const float* src = args.part + ((size_t)(g2 * args.slots_pg + (kb - (int)(b2 / nchunks))) * args.nnb + nb) * tile_fl;
-    sum += *reinterpret_cast<const f32x4*>(src + 4 * (size_t)j4);
+  for (int g0 = g_lo; g0 <= g_hi; g0 += 4) {
+    f32x4 v[4];
+    float live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g2 = min(g0 + i, g_hi);
+      const long b2 = args.gbegin[g2];
+      const bool has = g0 + i <= g_hi && min(args.gbegin[g2 + 1], u1) > max(b2, u0);
+      const int slot_kb = has ? kb - (int)(b2 / nchunks) : 0;
+      const float* src = args.part + ((size_t)(g2 * args.slots_pg + slot_kb) * args.nnb + nb) * tile_fl;
+      v[i] = *reinterpret_cast<const f32x4*>(src + 4 * (size_t)j4);
+      live[i] = has ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (live[i] != 0.f) sum += v[i];
   }
   const int tt = e >> 4, r = e & 15;
   const int n = nb * WG_BN + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
