@@ -187,14 +187,14 @@ class CrossBwdDesc(C.Structure):
 class EmbedBwdSeg(C.Structure):
     _fields_ = [(n, _fp) for n in ("de", "ids", "attrs", "ctx", "attrs_table")] + [
         ("attrs_bstride", C.c_int64), ("ctx_bstride", C.c_int64), ("rows", C.c_int32), ("T", C.c_int32),
-        ("attrs_table_rows", C.c_int32)]
+        ("attrs_table_rows", C.c_int32), ("joint_only", C.c_int32)]
 
 
 class EmbedBwdDesc(C.Structure):
     _fields_ = ([("seg", EmbedBwdSeg * MAX_SEGS)] + [(n, C.c_int32) for n in ("nseg", "d", "g", "n_attrs", "n_ctx", "ld_de", "L")]
                 + [("zq", _fp), ("joint_wt", _fp), ("ld_joint_wt", C.c_int32)]
                 + [(n, _fp) for n in ("g_items", "g_feats_w", "g_feats_b", "g_joint_w", "g_joint_b", "g_pos", "workspace",
-                                      "ev_early")])
+                                      "ev_early")] + [("skip_joint", C.c_int32)])
 
 
 class SaWeights(C.Structure):
@@ -326,7 +326,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.carca_abi_version() != 1:
+        if lib.carca_abi_version() != 2:
             raise CarcaHipError("libcarca_hip.so ABI version mismatch")
         _lib = lib
         return lib

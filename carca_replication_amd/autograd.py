@@ -141,6 +141,78 @@ class _Tail:
         return out
 
 
+# The embedding backward of the TARGET rows beside the encoder backward of the profile rows.  After the decoder's backward
+# the pass has two independent halves: d e of the target rows is final (targets reach the loss through the decoder only,
+# carca.py:338-349), and everything left on the profile side -- two SelfAttentionBlock backwards -- is a chain of
+# one-workgroup-per-user launches that fill half the CUs.  The target rows' embedding backward (two thirds of the pass's
+# largest product, d feats_embed) is issued on a second stream right there, with the one-workgroup-per-CU weight-gradient
+# kernel held to half the chip (tuning key 10), and the profile rows' embedding backward follows the chain on the first
+# stream with the other half.  The second stream sums into buffers of its own (the tail of the flat gradient buffer: zeroed
+# by the same fill) that are added at the join: the weight-gradient kernels end in a read-modify-write of dW.
+# Off: deterministic mode (its shadow buffer covers the real gradients), sharded steps (the early-gradients event sits
+# inside the one call), the re-associated embedding path, other embeddings / decoders.
+SPLIT_EMBED_BWD = True
+SPLIT_SIDE_CUS = 128       # CU budget of the second stream's weight-gradient launch; the first stream's gets the rest
+SPLIT_MAIN_TARGET_USERS = 0.0  # share of the FIRST target segment's users left to the first stream (balance)
+_SIDE_STREAMS = {}
+
+
+class _SideEmbed:
+    def __init__(self, emb, gbp, tail: "_Tail", device):
+        self.params = emb.side_grad_params()
+        self.ok = True
+        self.tmp = {}
+        for q in self.params:
+            t = tail.take(q.numel())
+            if t is None:
+                self.ok = False
+                return
+            self.tmp[id(q)] = t[: q.numel()].view(q.shape)
+        self.gbp = dict(gbp)
+        self.gbp.update(self.tmp)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        self.stream = _SIDE_STREAMS[key]
+        self.cus = ops.num_cus()
+
+    @staticmethod
+    def floats(emb) -> int:
+        return sum((q.numel() + 3) // 4 * 4 for q in emb.side_grad_params())
+
+    def launch(self, emb, des, segs, zq, L, dpi, wj_t) -> None:
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            ops.set_tuning(10, min(SPLIT_SIDE_CUS, self.cus))
+            try:
+                emb.embed_backward(des, segs, zq, self.gbp, L, dpi, wj_t=wj_t, skip_joint=True)
+            finally:
+                ops.set_tuning(10, 0)
+
+    def main_cus(self) -> int:
+        return max(8, self.cus - min(SPLIT_SIDE_CUS, self.cus))
+
+    def join(self, gbp) -> None:
+        torch.cuda.current_stream().wait_stream(self.stream)
+        # one add per run of parameters whose gradients lie back to back in the flat buffer (their temporaries do: same
+        # order, same 16-byte rounding) -- feats_embed.weight / .bias and joint_embed.weight / .bias at C2: two launches
+        r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+        runs = []
+        for q in self.params:
+            real, tmp = gbp[id(q)], self.tmp[id(q)]
+            if runs and runs[-1][0] + 4 * runs[-1][2] == real.data_ptr() and runs[-1][1] + 4 * runs[-1][2] == tmp.data_ptr():
+                runs[-1][2] += r4(q.numel())
+                runs[-1][3] = q.numel() - r4(q.numel())
+            else:
+                runs.append([real.data_ptr(), tmp.data_ptr(), r4(q.numel()), q.numel() - r4(q.numel()), real, tmp])
+        for _, _, n, slack, real, tmp in runs:
+            n += slack  # (the last parameter's rounding is not part of its view)
+            if n == real.numel():
+                real.add_(tmp)
+            else:
+                real.reshape(-1).as_strided((n,), (1,)).add_(tmp.reshape(-1).as_strided((n,), (1,)))
+
+
 class _PackPlan:
     """Every transposed weight copy of a backward pass (ONE pack launch) and every head-padded gradient staging area
     (zeroed by the gradient buffer's fill, ONE unpack launch at the end)."""
@@ -350,10 +422,18 @@ class _CarcaFn(torch.autograd.Function):
         # (every id a scatter-add of this pass can touch: known for the embeddings with an item table)
         id_lists = [sg[0] for sg in st["segs"]] if hasattr(emb, "items_embed") and len(st["segs"]) <= 4 else None
         late = emb.late_grad_params(st["emb_saved"]) if hasattr(emb, "late_grad_params") else ()
-        grads, tail_buf, after_pass = _grad_buffers(model, params, plan.staging_floats(), id_lists, late)
+        want_side = (SPLIT_EMBED_BWD and st["is_ca"] and emb_wt_idx is not None and not ops.deterministic()
+                     and ops.early_event is None and hasattr(emb, "side_grad_params") and len(st["segs"]) >= 2)
+        r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+        extra = r4(plan.staging_floats()) + (_SideEmbed.floats(emb) if want_side else 0)
+        grads, tail_buf, after_pass = _grad_buffers(model, params, extra, id_lists, late)
         det = _det_pass(model) if ops.deterministic() else None
-        plan.build(dev, _Tail(tail_buf))
+        tail = _Tail(tail_buf)
+        plan.build(dev, tail)
         gbp = {id(p): g for p, g in zip(params, grads)}
+        side = _SideEmbed(emb, gbp, tail, dev) if want_side else None
+        if side is not None and not side.ok:
+            side = None
         ys = ctx.saved_tensors
         ngroups = st["ngroups"]
         if "Ns" in st:  # joint output: per-group views of the one score / gradient tensor
@@ -369,6 +449,23 @@ class _CarcaFn(torch.autograd.Function):
         wg = ops.WgradGroup()
         if st["is_ca"]:
             dx, des_t = _cross_decoder_backward(model, st, ys, dys, gbp, wg, cpk, plan.g.view(wpad_idx).view(-1))
+            if side is not None:  # d e of the target rows is final: their embedding backward starts on the second stream
+                segs_all, zq_all = st["segs"], st["emb_saved"]
+                rows0 = segs_all[0][0].numel()
+                side_segs, side_des, main_extra, zq_side = list(segs_all[1:]), list(des_t), None, rows0
+                nb_main = int(SPLIT_MAIN_TARGET_USERS * segs_all[1][0].shape[0])
+                if 0 < nb_main < segs_all[1][0].shape[0] and len(segs_all) + 1 <= ops._lib.MAX_SEGS:
+                    # balance: the FIRST users of the first target segment stay with the profile rows (their [z ; q] rows
+                    # follow the profile's in the saved buffer: one call, two segments)
+                    x, a, c, tg = segs_all[1]
+                    T = x.shape[1]
+                    head = lambda t: None if t is None else t[:nb_main]  # noqa: E731
+                    rest = lambda t: None if t is None else t[nb_main:]  # noqa: E731
+                    main_extra = ((head(x), head(a), head(c), tg), des_t[0][: nb_main * T])
+                    side_segs[0] = (rest(x), rest(a), rest(c), tg)
+                    side_des[0] = des_t[0][nb_main * T:]
+                    zq_side = rows0 + nb_main * T
+                side.launch(emb, side_des, side_segs, zq_all[zq_side:], L, dpi, plan.wT.view(emb_wt_idx))
         else:
             dp, des_t = dec.score_backward(dys, st["dsave"], B, L, d, dpi)
             # final LayerNorm (carca.py:421)
@@ -398,7 +495,24 @@ class _CarcaFn(torch.autograd.Function):
         if det is not None:  # (the staging areas are about to be READ: their accumulated sums out of the shadow first)
             det.flush_staging()
         plan.unpack(gbp)  # head-padded staging areas -> the real WQ / WK / WV / ffn gradients
-        if emb_wt_idx is not None:
+        if side is not None:
+            ops.set_tuning(10, side.main_cus())
+            try:
+                wj_t = plan.wT.view(emb_wt_idx)
+                # (d joint_embed over ALL rows here, in one launch: the second stream's segments ride along joint_only)
+                m_des, m_segs = [dx], list(st["segs"][:1])
+                if main_extra is not None:
+                    m_segs.append(main_extra[0])
+                    m_des.append(main_extra[1])
+                n_own = len(m_segs)
+                m_segs += side_segs
+                m_des += side_des
+                emb.embed_backward(m_des, m_segs, st["emb_saved"], gbp, L, dpi, wj_t=wj_t,
+                                   joint_only=[i >= n_own for i in range(len(m_segs))])
+            finally:
+                ops.set_tuning(10, 0)
+            side.join(gbp)
+        elif emb_wt_idx is not None:
             emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi, wj_t=plan.wT.view(emb_wt_idx))
         else:
             emb.embed_backward(des, st["segs"], st["emb_saved"], gbp, L, dpi)

@@ -297,42 +297,48 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
   size_t row0 = 0;
   float* ws = D->workspace;
   float* dzq[CARCA_MAX_SEGS];
+  const int32_t* sids[CARCA_MAX_SEGS];
+  int srows[CARCA_MAX_SEGS];
+  int nj = 0, nf = 0;  // segments of d joint_embed / of the three products behind it
   for (int s = 0; s < D->nseg; ++s) {
     const CarcaEmbedBwdSeg& sg = D->seg[s];
-    CARCA_CHECK_ARG(sg.rows >= 1 && sg.T >= 1 && sg.de && sg.ids && (sg.attrs || sg.attrs_table) &&
-                        (D->n_ctx == 0 || sg.ctx),
-                    "embed_bwd: segment %d malformed", s);
-    dzq[s] = ws;
+    CARCA_CHECK_ARG(sg.rows >= 1 && sg.T >= 1 && sg.de && sg.ids, "embed_bwd: segment %d malformed", s);
+    if (!D->skip_joint) {  // d joint_embed = (d e * mask)^T [z ; q]
+      CarcaWgradSeg& j = wj.seg[nj++];
+      j.dy = sg.de; j.x = D->zq + row0 * ldz; j.ids = sg.ids; j.rows = sg.rows; j.T = 1;
+    }
+    row0 += sg.rows;
+    if (sg.joint_only) continue;
+    CARCA_CHECK_ARG((sg.attrs || sg.attrs_table) && (D->n_ctx == 0 || sg.ctx), "embed_bwd: segment %d malformed", s);
+    dzq[nf] = ws;
     ws += (size_t)sg.rows * ldz;
-    // d joint_embed = (d e * mask)^T [z ; q]
-    wj.seg[s].dy = sg.de; wj.seg[s].x = D->zq + row0 * ldz; wj.seg[s].ids = sg.ids; wj.seg[s].rows = sg.rows; wj.seg[s].T = 1;
     // d [z ; q] = (d e * mask) W_j
-    gz.seg[s].a0 = sg.de; gz.seg[s].c = dzq[s]; gz.seg[s].ids = sg.ids; gz.seg[s].rows = sg.rows; gz.seg[s].T = 1;
+    gz.seg[nf].a0 = sg.de; gz.seg[nf].c = dzq[nf]; gz.seg[nf].ids = sg.ids; gz.seg[nf].rows = sg.rows; gz.seg[nf].T = 1;
     // d feats_embed = dq^T [attrs | ctx]: the ctx columns ride along as a second X source
-    CarcaWgradSeg& f = wf.seg[s];
-    f.dy = dzq[s] + d; f.rows = sg.rows; f.T = sg.T; f.ids = sg.ids;
+    CarcaWgradSeg& f = wf.seg[nf];
+    f.dy = dzq[nf] + d; f.rows = sg.rows; f.T = sg.T; f.ids = sg.ids;
     if (sg.attrs_table) {
       f.x = sg.attrs_table; f.x_gather = sg.attrs_table_rows > 1 ? sg.attrs_table_rows : 1;
     } else {
       f.x = sg.attrs; f.x_bstride = sg.attrs_bstride;
     }
     f.x1 = D->n_ctx ? sg.ctx : nullptr; f.x1_bstride = sg.ctx_bstride;
-    row0 += sg.rows;
+    sids[nf] = sg.ids; srows[nf] = sg.rows;
+    ++nf;
   }
-  wj.nseg = gz.nseg = wf.nseg = D->nseg;
-  wj.ld_dy = D->ld_de; wj.ld_x = ldz; wj.N = d; wj.K = ldz; wj.dw = D->g_joint_w; wj.ldw = ldz; wj.db = D->g_joint_b;
-  wj.mask_rows = 1;
-  if ((rc = carca_gemm_wgrad(&wj, stream))) return rc;
+  CARCA_CHECK_ARG(nf >= 1, "embed_bwd: every segment is joint_only");
+  wj.nseg = nj;
+  gz.nseg = wf.nseg = nf;
+  if (nj) {
+    wj.ld_dy = D->ld_de; wj.ld_x = ldz; wj.N = d; wj.K = ldz; wj.dw = D->g_joint_w; wj.ldw = ldz; wj.db = D->g_joint_b;
+    wj.mask_rows = 1;
+    if ((rc = carca_gemm_wgrad(&wj, stream))) return rc;
+  }
   gz.lda0 = D->ld_de; gz.K0 = d; gz.bt0 = D->joint_wt; gz.ldb0 = D->ld_joint_wt; gz.N = ldz; gz.ldc = ldz;
   gz.ncols_out = ldz; gz.gate_slope = 0.01f; gz.mask_rows = 1;
   if ((rc = carca_gemm_rows(&gz, stream))) return rc;
-  {  // nn.Embedding(padding_idx = 0): z = E[ids] * sqrt(d); every segment in one launch
-    const int32_t* sids[CARCA_MAX_SEGS];
-    int srows[CARCA_MAX_SEGS];
-    for (int s = 0; s < D->nseg; ++s) { sids[s] = D->seg[s].ids; srows[s] = D->seg[s].rows; }
-    if ((rc = carca_embed_scatter_segs(dzq, ldz, sids, srows, D->nseg, d, (float)sqrt((double)d), D->g_items, stream)))
-      return rc;
-  }
+  // nn.Embedding(padding_idx = 0): z = E[ids] * sqrt(d); every segment in one launch
+  if ((rc = carca_embed_scatter_segs(dzq, ldz, sids, srows, nf, d, (float)sqrt((double)d), D->g_items, stream))) return rc;
   wf.ld_dy = ldz; wf.ld_x = D->n_attrs; wf.ld_x1 = D->n_ctx; wf.N = g; wf.K = D->n_attrs; wf.K1 = D->n_ctx;
   wf.dw = D->g_feats_w; wf.ldw = D->n_attrs + D->n_ctx; wf.db = D->g_feats_b;
   if (D->ev_early && hipEventRecord((hipEvent_t)D->ev_early, (hipStream_t)stream) != hipSuccess) {

@@ -202,7 +202,7 @@ __device__ __forceinline__ void carca_gather_rows(const CarcaGatherArgs& ga, int
 // tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice.
 // Keys 3..5 are used by number (see include/carca_hip.h).
 enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_DETERMINISTIC = 8,
-       CARCA_TUNE_COUNT = 10 };
+       CARCA_TUNE_STAMPS = 9, CARCA_TUNE_CU_CAP = 10, CARCA_TUNE_COUNT = 12 };
 int carca_tuning(int key);
 int carca_num_cus();  // compute units of the current device (cached)
 // Timing events for this thread's NEXT row-GEMM launch (the roofline hooks of carca_forward): the launch binds them to

@@ -41,6 +41,7 @@ struct GemmDev {
   int sk_don;
   float* sk_part;
   int* sk_flag;
+  int* sk_err;  // host-visible word: a taker's bounded wait expired
 };
 
 template <int BM, int BN, int BK, int PF = 1, bool BUF = false>
@@ -803,7 +804,17 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
   }
   if constexpr (MODE == SK_TAKE) {
     if (tid == 0) {
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+      // (the giver is resident -- one round of workgroups -- and ends before its takers by the launcher's balance: the wait
+      // is a few us.  It is BOUNDED all the same, ~5 s: a taker that gives up says so in the library's host-visible error
+      // word and the next launch fails loudly (launch_gemm_rows_sk) instead of the GPU hanging)
+      unsigned spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins == (1u << 23)) {
+          if (args.sk_err) __hip_atomic_store(args.sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
       __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ready for the next launch)
     }
     __syncthreads();
@@ -876,26 +887,17 @@ __global__ __launch_bounds__(768) void gemm_rows_sk_kernel(const GemmDev args) {
   const int rb = wg / args.ncb, j = wg - rb * args.ncb;
   const int nfast = D.K0 / 32, nfull = args.ncb - 1;
   if (j == 0) {  // the row block's cheap workgroup (first of the block's five to be dispatched)
-    // (args.diag, tuning key 5, timing experiments with wrong results: 1 no partial tiles, 2 takers do not wait / add,
-    // 4 no cheap tile)
     // Its own tile FIRST, in step with the four owners: the five workgroups of a row block stream the same A rows through
     // their XCD's L2.  (Partials first -- the first version -- put this workgroup ~30 K steps behind the others and it
     // fetched the whole A row block from HBM again: PMC 482 -> 823 MB per launch.)  The owners then find their partial
     // between 0.79 and 0.95 of the kernel; the last one is what the launcher's choice of `don` leaves a margin for.
-    const int n_before = (args.diag & 8) ? nfull / 2 : 0;  // (diag 8: half of the partial tiles BEFORE the cheap tile)
-    for (int cb = 0; cb < n_before && !(args.diag & 1); ++cb)
-      cu_tile<3, 0, SK_GIVE>(args, As, Bs, rb, cb * 96, nfast - args.sk_don, nfast, false,
-                             args.sk_part + ((size_t)rb * nfull + cb) * (384 * 96), args.sk_flag + rb * nfull + cb);
-    if (!(args.diag & 4)) cu_tile<2, XC, SK_PLAIN>(args, As, Bs, rb, nfull * 96, 0, nfast, true, nullptr, nullptr);
-    for (int cb = n_before; cb < nfull && !(args.diag & 1); ++cb)
+    cu_tile<2, XC, SK_PLAIN>(args, As, Bs, rb, nfull * 96, 0, nfast, true, nullptr, nullptr);
+    for (int cb = 0; cb < nfull; ++cb)
       cu_tile<3, 0, SK_GIVE>(args, As, Bs, rb, cb * 96, nfast - args.sk_don, nfast, false,
                              args.sk_part + ((size_t)rb * nfull + cb) * (384 * 96), args.sk_flag + rb * nfull + cb);
   } else {
     const int cb = j - 1;
-    if (args.diag & 2)
-      cu_tile<3, 0, SK_PLAIN>(args, As, Bs, rb, cb * 96, 0, nfast - args.sk_don, true, nullptr, nullptr);
-    else
-      cu_tile<3, 0, SK_TAKE>(args, As, Bs, rb, cb * 96, 0, nfast - args.sk_don, true,
+    cu_tile<3, 0, SK_TAKE>(args, As, Bs, rb, cb * 96, 0, nfast - args.sk_don, true,
                            args.sk_part + ((size_t)rb * nfull + cb) * (384 * 96), args.sk_flag + rb * nfull + cb);
   }
 }
@@ -1417,6 +1419,8 @@ size_t g_sk_bytes[SK_RING] = {0};
 hipEvent_t g_sk_ev[SK_RING];
 bool g_sk_used[SK_RING] = {false}, g_sk_init = false;
 int g_sk_next = 0;
+int* g_sk_err_host = nullptr;  // mapped host memory: written by a taker whose wait expired, read here before every launch
+int* g_sk_err_dev = nullptr;
 
 static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, const CarcaGatherArgs* pas, int* rode) {
   const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
@@ -1451,13 +1455,24 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   if (carca_tuning(4) > 0) don = carca_tuning(4);
   if (don < 1 || don >= nfast) return 1;
   g.sk_don = don;
-  g.diag = carca_tuning(5);
   // The item-row gather does NOT ride in this launch (rode stays 0: the caller launches it, 8 us): the lone passenger
   // workgroup is a latency chain of ~100 rounds that takes ~455 us on an idle chip and ~540 us beside the tiles -- invisible
   // under gemm_rows_cu_kernel's 535 us, the long pole here (measured: 0.640 ms per forward with it, 0.614 without; more
   // rows or both 64-column pieces in flight made the compiler serialise the loads: 1.2 / 0.74 ms).
   (void)pas;
   (void)rode;
+  if (!g_sk_err_host) {
+    if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped) != hipSuccess) return 1;
+    *g_sk_err_host = 0;
+    if (hipHostGetDevicePointer((void**)&g_sk_err_dev, g_sk_err_host, 0) != hipSuccess) g_sk_err_dev = nullptr;
+  }
+  if (*(volatile int*)g_sk_err_host != 0) {
+    *(volatile int*)g_sk_err_host = 0;
+    carca_set_error("gemm_rows: an EARLIER stream-K launch gave up waiting for a partial tile (its output is wrong): "
+                    "were its workgroups not all resident?  carca_set_tuning(0, 15) selects the kernel without the hand-over");
+    return CARCA_ERR_UNSUPPORTED;
+  }
+  g.sk_err = g_sk_err_dev;
   const size_t n_part = (size_t)rb * nfull, flag_bytes = (n_part * sizeof(int) + 255) / 256 * 256;
   const size_t bytes = flag_bytes + n_part * 384 * 96 * sizeof(float);
   int slot = -1;

@@ -265,7 +265,7 @@ int carca_sa_ffn_chain_bwd(const float* dy, const float* h1, const float* r, con
   a.rows = rows; a.d = d; a.ld = dpi; a.mode = 0; a.residual = residual;
   a.a0 = dy; a.w0 = w2_t; a.w1 = w1_t; a.gate = h1; a.add = dy; a.x = r; a.ln_w = ln2_w;
   a.out1 = dh1pre; a.out = dr; a.g_ln_w = g_ln2_w; a.g_ln_b = g_ln2_b;
-  a.stamps = carca_tuning(5) == 1 ? carca_debug_buffer() : nullptr;
+  a.stamps = carca_tuning(CARCA_TUNE_STAMPS) == 1 ? carca_debug_buffer() : nullptr;
   switch (dpi) {
     case 64: return launch_row_chain<64, 0>(a, (hipStream_t)stream);
     case 96: return launch_row_chain<96, 0>(a, (hipStream_t)stream);
@@ -282,7 +282,7 @@ int carca_sa_input_chain_bwd(const float* dqh, const float* dkh, const float* dv
   a.rows = rows; a.d = d; a.ld = dpi; a.mode = 1; a.residual = residual;
   a.a0 = dqh; a.a1 = dkh; a.a2 = dvh; a.w0 = wq_t; a.w1 = wk_t; a.w2 = wv_t; a.add = dr; a.x = x_in; a.ln_w = ln1_w;
   a.out = dx; a.g_ln_w = g_ln1_w; a.g_ln_b = g_ln1_b;
-  a.stamps = carca_tuning(5) == 2 ? carca_debug_buffer() : nullptr;
+  a.stamps = carca_tuning(CARCA_TUNE_STAMPS) == 2 ? carca_debug_buffer() : nullptr;
   switch (dpi) {
     case 64: return launch_row_chain<64, 1>(a, (hipStream_t)stream);
     case 96: return launch_row_chain<96, 1>(a, (hipStream_t)stream);

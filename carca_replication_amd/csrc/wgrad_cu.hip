@@ -503,16 +503,19 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
     g_num_cus = prop.multiProcessorCount;
   }
+  // (tuning key 10: the caller's CU budget for this launch -- the other CUs belong to a concurrent stream)
+  int ncu = g_num_cus;
+  if (carca_tuning(CARCA_TUNE_CU_CAP) > 0 && carca_tuning(CARCA_TUNE_CU_CAP) < ncu) ncu = std::max(8, carca_tuning(CARCA_TUNE_CU_CAP) / 8 * 8);
   // worth it only when every CU gets a long run of chunks (pipeline fill + two flushes per block are overhead)
   const bool forced = carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 2 || carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 3;
   // (24 chunk-tiles per CU: the d x F product of the re-associated embedding backward, 26 per CU at C2, runs 2x faster
   // here than on the tile kernel; the joint-embedding dW, 5 per CU, does not)
-  if (!forced && (total < (long)g_num_cus * 24 || chunks < 8)) return 1;
+  if (!forced && (total < (long)ncu * 24 || chunks < 8)) return 1;
   // groups of nnb workgroups (see WgradCuDev): per XCD as many whole groups as fit, the left-over slots group across XCDs
   // (one n block: nothing to share -- consecutive workgroups take consecutive ranges, as before the groups; tuning variant 16
   // forces that numbering for any nnb: A/B switch)
-  g.nxcd = (g_num_cus % 8 == 0 && g.nnb <= g_num_cus / 8 && g.nnb > 1 && carca_tuning(CARCA_TUNE_GEMM_VARIANT) != 16) ? 8 : 1;
-  const int per_xcd = g_num_cus / g.nxcd;
+  g.nxcd = (ncu % 8 == 0 && g.nnb <= ncu / 8 && g.nnb > 1 && carca_tuning(CARCA_TUNE_GEMM_VARIANT) != 16) ? 8 : 1;
+  const int per_xcd = ncu / g.nxcd;
   g.gpx = per_xcd / g.nnb;
   g.ngroups = g.nxcd * g.gpx + (g.nxcd * (per_xcd - g.gpx * g.nnb)) / g.nnb;
   if (g.ngroups < 1) return 1;  // (more n blocks than CUs: the tile kernel)
@@ -523,7 +526,7 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   const long total_w = g.n_fast * 256 + n_slow * g.slow_w;
   g.per_w = (total_w + g.ngroups - 1) / g.ngroups;
   g.ngroups = (int)((total_w + g.per_w - 1) / g.per_w);  // (a short product: fewer groups than the chip could host)
-  const int grid = g_num_cus;
+  const int grid = ncu;
   g.V = chunks * WG_BR;
   {  // k blocks a group's range can touch: walk the groups' first and last units
     auto item_at = [&](long wt) -> long {

@@ -330,15 +330,22 @@ class AllEmbedding(Embedding):
         the others so that a sharded step can reduce everything else under that launch)."""
         return () if isinstance(saved, str) else (self.feats_embed.weight, self.feats_embed.bias)
 
+    def side_grad_params(self):
+        """The dense parameters embed_backward accumulates into with a read-modify-write at the end of a kernel: a second,
+        concurrent embed_backward call of the same pass (autograd._SideEmbed) needs buffers of its own for them.  (The
+        item table's rows are scatter-added with atomics: shared; d joint_embed stays in one call over all rows.)"""
+        return (self.feats_embed.weight, self.feats_embed.bias)
+
     def backward_pack_items(self, dpi: int):
         """The transposed weight copy embed_backward needs (Bt[n = input feature of joint_embed][k = output feature]): the
         backward pass packs it in ITS pack launch and hands the view back as embed_backward(..., wj_t=)."""
         return [ops.PackItem(self.joint_embed.weight, self.d + self.feats_embed.weight.shape[0], dpi, transposed=True)]
 
-    def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int, wj_t=None) -> None:
+    def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int, wj_t=None, joint_only=None, skip_joint=False) -> None:
         """Backward of embed_segments (carca.py:85-95): des[i] = d e of segment i, [rows, dpi], NOT yet masked;
         accumulates into the gradient buffers gbp[id(param)].  One host call (carca_embed_bwd): position-encoding
-        gradient, d joint_embed, d [z ; q], item-row scatter-add, d feats_embed."""
+        gradient, d joint_embed, d [z ; q], item-row scatter-add, d feats_embed.  joint_only / skip_joint: see
+        autograd._SideEmbed (the target rows' share on a second stream)."""
         if isinstance(zq, str):  # the forward took the re-associated path
             return self._embed_backward_folded(des, segs, gbp, L, dpi)
         d = self.d
@@ -360,7 +367,8 @@ class AllEmbedding(Embedding):
                            g_feats_b=gbp[id(self.feats_embed.bias)], g_joint_w=gbp[id(self.joint_embed.weight)],
                            g_joint_b=gbp[id(self.joint_embed.bias)]),
                       table, d, g_feats, n_attrs, n_ctx, L,
-                      gbp[id(enc_w)] if (enc_w is not None and not segs[0][3]) else None)  # (targets carry no position term)
+                      gbp[id(enc_w)] if (enc_w is not None and not segs[0][3]) else None,  # (targets carry no position term)
+                      joint_only=joint_only, skip_joint=skip_joint)
 
     def forward(self, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
         """`mask` must be get_mask(x) (it always is in the reference, carca.py:413-426); the kernel uses x != 0."""

@@ -761,9 +761,10 @@ early_event = None
 
 
 def embed_bwd(des, segs, zq: Tensor, joint_wt: Tensor, grads: dict, table: Optional[Tensor], d: int, g: int, n_attrs: int,
-              n_ctx: int, L: int, g_pos: Optional[Tensor]) -> None:
+              n_ctx: int, L: int, g_pos: Optional[Tensor], joint_only=None, skip_joint: bool = False) -> None:
     """Backward of AllEmbedding.forward over all segments as ONE host call (carca_embed_bwd).  des[i]: d e [rows, ld]
-    (unmasked); segs[i] = (ids, attrs or None, ctx, is_target); joint_wt: [d + g, ld] transposed joint weight."""
+    (unmasked); segs[i] = (ids, attrs or None, ctx, is_target); joint_wt: [d + g, ld] transposed joint weight.
+    joint_only[i] / skip_joint: a pass that runs the target rows' share on a second stream (include/carca_hip.h)."""
     lib = _lib.load()
     nseg = len(des)
     D = _lib.EmbedBwdDesc()
@@ -780,6 +781,11 @@ def embed_bwd(des, segs, zq: Tensor, joint_wt: Tensor, grads: dict, table: Optio
         S = D.seg[i]
         S.de, S.ids, S.rows, S.T = de.data_ptr(), ids32.data_ptr(), de.shape[0], x.shape[1]
         rows[i] = de.shape[0]
+        if joint_only is not None and joint_only[i]:
+            S.joint_only = 1
+            rows[i] = 0  # (no d [z ; q] workspace)
+            keep += [de, ids32]
+            continue
         if a is not None:
             a, a_bs = _btk_view(a)
             S.attrs, S.attrs_bstride = a.data_ptr(), a_bs
@@ -798,6 +804,7 @@ def embed_bwd(des, segs, zq: Tensor, joint_wt: Tensor, grads: dict, table: Optio
     D.g_pos = _ptr(g_pos)
     D.workspace = ws.data_ptr()
     D.ev_early = early_event.handle if early_event is not None else None
+    D.skip_joint = 1 if skip_joint else 0
     _lib.check(lib.carca_embed_bwd(C.byref(D), _stream()), "embed_bwd")
     del keep
 
@@ -1157,3 +1164,12 @@ def cross_attn_bwd(kh: Tensor, vh: Tensor, p_ids: Tensor, groups, ffn_w_pad_ptr:
                                         ffn_w_pad_ptr, dkh.data_ptr(), dvh.data_ptr(), d_ffn_w_pad.data_ptr(), B, L, d,
                                         H, int(bool(training)), drop_scale, _stream()), "cross_attn_bwd")
     return dqhs, dls, dkh, dvh
+
+
+def set_tuning(key: int, value: int) -> None:
+    """carca_set_tuning (include/carca_hip.h): kernel-variant knobs; 0 = the shipped choice."""
+    _lib.check(_lib.load().carca_set_tuning(int(key), int(value)), "set_tuning")
+
+
+def num_cus() -> int:
+    return torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CARCA_ABI_VERSION 1
+#define CARCA_ABI_VERSION 2
 #define CARCA_OK 0
 #define CARCA_ERR_UNSUPPORTED (-1) /* shape outside what the kernels were built for */
 #define CARCA_ERR_BADARG (-2)      /* null pointer, misaligned stride, ... */
@@ -55,7 +55,11 @@ int carca_abi_version(void);
  *          into a 64-bit fixed-point shadow buffer (carca_det_begin / carca_det_flush below), whose integer sums do not
  *          depend on the order in which workgroups arrive; HR / NDCG sums are added in a fixed order by one block.
  *          Same inputs => same bits, run to run.  Reference: none (torch's CUDA backward has the same nondeterminism:
- *          index_add / atomicAdd in embedding_dense_backward); it exists so that trajectory tests can be tight. */
+ *          index_add / atomicAdd in embedding_dense_backward); it exists so that trajectory tests can be tight.
+ *   key 9  in-kernel phase stamps of the row-chain kernels (1 FFN side, 2 input side; carca_set_debug_buffer)
+ *   key 10 CU budget of the one-workgroup-per-CU weight-gradient kernel (0 = every CU): a caller that runs two halves
+ *          of a backward pass on two streams gives each launch half the chip (autograd.py: the target rows' embedding
+ *          backward beside the profile rows' encoder backward) */
 int carca_set_tuning(int key, int value);
 /* Deterministic mode, per backward pass: register the pass's flat fp32 gradient buffer `flat` (n floats) and its shadow
  * (n uint64, ZERO on entry); kernels launched on `stream` afterwards accumulate gradients that land inside `flat` into
@@ -482,6 +486,8 @@ typedef struct CarcaEmbedBwdSeg {
   const float* attrs_table;  /* optional [n_items, n_attrs]: rows gathered by id instead of `attrs` */
   int64_t attrs_bstride, ctx_bstride;
   int32_t rows, T, attrs_table_rows;
+  int32_t joint_only;        /* 1: this segment only enters d joint_embed here -- its d [z ; q], scatter-add and d feats_embed
+                              * are another call's (the same pass's second stream, see skip_joint) */
 } CarcaEmbedBwdSeg;
 typedef struct CarcaEmbedBwdDesc {
   CarcaEmbedBwdSeg seg[CARCA_MAX_SEGS]; /* seg[0] = the profile (the only one with a position encoding) */
@@ -495,6 +501,9 @@ typedef struct CarcaEmbedBwdDesc {
   void* ev_early;         /* optional hipEvent_t recorded on `stream` right BEFORE the last launch (d feats_embed, as long as
                            * the whole forward GEMM): behind it every other gradient of the model is final, so a gradient
                            * all-reduce of everything but feats_embed.{weight,bias} can start under that kernel */
+  int32_t skip_joint;     /* 1: no d joint_embed in this call (a later call of the pass lists these segments joint_only):
+                           * a backward pass may hand the target rows' share to a second stream as soon as their d e is
+                           * final and keep the small d joint_embed product in ONE launch over all rows */
 } CarcaEmbedBwdDesc;
 size_t carca_embed_bwd_workspace(const int32_t* rows /*host [nseg]*/, int nseg, int d, int g);
 int carca_embed_bwd(const CarcaEmbedBwdDesc* desc /*host*/, void* stream);

@@ -230,6 +230,47 @@ def test_c2_full_batch_gradients_are_the_weighted_sum_of_its_halves():
         assert float((gf[k] - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-7, k
 
 
+@pytest.mark.parametrize("n_groups", [2, 3])
+def test_two_stream_embedding_backward_agrees_with_the_single_stream_pass(n_groups, monkeypatch):
+    """The backward pass hands the target rows' embedding backward to a second stream once the decoder's backward has
+    produced their d e (autograd._SideEmbed): same gradients as the single-stream pass (fp32 summation order aside), with
+    the balance slice (SPLIT_MAIN_TARGET_USERS) on and off, and at CARCA_MAX_SEGS segments (profile + 3 target groups:
+    no room for the slice).  The G2 / G7 fixtures above run the split as shipped against the reference's gradients."""
+    from carca_replication_amd import autograd, engine
+    from carca_replication_amd import modules as M
+    from carca_replication_amd.synth import eval_batch
+    from tests.model_util import build_model
+
+    B, L, d, g, H, n_items, n_attrs, n_ctx = 128, 50, 90, 450, 3, 12102, 512, 6
+    torch.manual_seed(0)
+    model = build_model(dict(d=d, H=H, n_blocks=2, encoding="learnable"), n_items, g, n_ctx, n_attrs, L).cuda().train()
+    profile, pos, _ = eval_batch(B, L, L, n_items, n_attrs, n_ctx, seed=78)
+    profile = tuple(t.cuda() for t in profile)
+    px = profile[0]
+    groups = [tuple(t.cuda() for t in (pos[0] * (px.cpu() != 0), pos[1], pos[2]))]
+    for k in range(1, n_groups):
+        groups.append(tuple(t.cuda() for t in (pos[0].roll(k, 0) * (px.cpu() != 0), pos[1].roll(k, 0), pos[2])))
+    y_true = torch.cat([(px != 0).int()] + [torch.zeros_like(px)] * (n_groups - 1), dim=1)
+
+    def run(split, frac):
+        monkeypatch.setattr(autograd, "SPLIT_EMBED_BWD", split)
+        monkeypatch.setattr(autograd, "SPLIT_MAIN_TARGET_USERS", frac)
+        model.zero_grad(set_to_none=True)
+        y = model(profile=profile, targets=groups)  # (the groups' scores: modules.JointScores)
+        loss = M.BinaryCrossEntropy()(y, y_true, M.get_mask(torch.cat([grp[0] for grp in groups], dim=1)))
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    l0, g0 = run(False, 0.0)
+    for frac in (0.0, 0.3):
+        l1, g1 = run(True, frac)
+        assert l1 == l0
+        for k in g0:
+            assert float((g1[k] - g0[k]).abs().max()) <= 2e-5 * float(g0[k].abs().max()) + 1e-7, (k, frac)
+    assert any(float(v.abs().max()) > 0 for k, v in g0.items() if "feats_embed" in k)
+
+
 @pytest.mark.parametrize("rows,d,ld,out_ld", [(6400, 90, 96, 96), (6401, 128, 128, 128), (333, 50, 64, 64),
                                               (77, 6, 8, 8), (129, 90, 91, 96), (64, 128, 256, 128)])
 def test_layernorm_backward_kernels_against_torch(rows, d, ld, out_ld):

@@ -35,7 +35,7 @@ def test_library_loaded_and_native():
     import carca_replication_amd as pkg
 
     lib = pkg.load()
-    assert lib.carca_abi_version() == 1
+    assert lib.carca_abi_version() == 2
 
 
 @pytest.mark.parametrize("name", G1_NAMES)

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.carca_abi_version() == 1
+    assert lib.carca_abi_version() == 2
 
 
 def test_padded_dims_host_logic():

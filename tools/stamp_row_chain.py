@@ -1,5 +1,5 @@
 """Phase stamps of the fused row chains of the SelfAttentionBlock backward (csrc/row_chain.hip) inside a real train step
-at C2: tuning key 5 = 1 stamps the FFN-side chain, 2 the input-side chain (the last launch of the step wins the buffer)."""
+at C2: tuning key 9 = 1 stamps the FFN-side chain, 2 the input-side chain (the last launch of the step wins the buffer)."""
 import os
 import sys
 
@@ -29,12 +29,12 @@ NAMES = ["tiles in LDS", "first product done", "its result in LDS", "barrier", "
 for mode, what in ((1, "FFN side"), (2, "input side")):
     nwg = (c["B"] * L + 63) // 64
     buf = torch.zeros(nwg * 8 + 64, dtype=torch.int64, device="cuda")
-    lib.carca_set_tuning(5, mode)
+    lib.carca_set_tuning(9, mode)
     lib.carca_set_debug_buffer(buf.data_ptr())
     engine.train_step(model, opt, batch)
     torch.cuda.synchronize()
     lib.carca_set_debug_buffer(None)
-    lib.carca_set_tuning(5, 0)
+    lib.carca_set_tuning(9, 0)
     st = buf[: nwg * 8].view(nwg, 8).double().cpu()
     rel = st - st[:, :1]
     print(what + ": cycles since the workgroup's start, median (max): " +
