@@ -255,7 +255,7 @@ bool carca_stream_capturing(hipStream_t stream) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   return hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
 }
-void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view) {
+void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view, size_t zero_bytes) {
   hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
   (void)hipThreadExchangeStreamCaptureMode(&mode);
   void* p = nullptr;
@@ -266,6 +266,14 @@ void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view) {
   } else {
     rc = hipMalloc(&p, bytes);
     if (device_view) *device_view = p;
+    // (state a kernel keeps clean itself -- the stream-K flags: every taker resets its own -- is cleared here, once, on the
+    // stream of the library's own, inside the relaxed-mode window)
+    if (rc == hipSuccess && zero_bytes) {
+      static hipStream_t zs = nullptr;  // (a stream of our own: the legacy stream may not wait for a capturing blocking stream)
+      if (!zs) rc = hipStreamCreateWithFlags(&zs, hipStreamNonBlocking);
+      if (rc == hipSuccess) rc = hipMemsetAsync(p, 0, zero_bytes, zs);
+      if (rc == hipSuccess) rc = hipStreamSynchronize(zs);
+    }
   }
   (void)hipThreadExchangeStreamCaptureMode(&mode);
   if (rc != hipSuccess) {

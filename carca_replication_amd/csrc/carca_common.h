@@ -214,7 +214,7 @@ int carca_num_cus();  // compute units of the current device (cached)
 bool carca_stream_capturing(hipStream_t stream);
 // hipMalloc / hipHostMalloc(mapped) that are legal inside a capture (thread capture mode relaxed around the call);
 // the memory lives as long as the process (a few hundred KB per captured step)
-void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view);
+void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view, size_t zero_bytes = 0);  // (zero_bytes: cleared once, now -- not a node of the graph)
 void carca_arm_launch_events(void* start, void* stop);
 bool carca_take_launch_events(hipEvent_t* start, hipEvent_t* stop);  // true (and disarms) when armed
 struct CarcaGemmDesc;

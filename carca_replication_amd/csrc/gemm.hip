@@ -1478,9 +1478,8 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   int slot = -1;
   char* buf;
   if (carca_stream_capturing(stream)) {
-    buf = (char*)carca_capture_alloc(bytes, false, nullptr);
+    buf = (char*)carca_capture_alloc(bytes, false, nullptr, flag_bytes);  // (flags zero from here on: every taker resets its own)
     if (!buf) return (int)hipErrorOutOfMemory;
-    (void)hipMemsetAsync(buf, 0, flag_bytes, stream);
   } else {
     if (!g_sk_init) {
       for (int i = 0; i < SK_RING; ++i) (void)hipEventCreateWithFlags(&g_sk_ev[i], hipEventDisableTiming);

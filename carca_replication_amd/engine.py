@@ -196,6 +196,8 @@ class GraphedTrainStep:
             self.foreign = torch.zeros(cdist.world_size() * per_rank, dtype=torch.int32, device=self.inputs[0].device)
             model.__dict__["_grad_foreign"] = self.foreign
         self.replays = torch.zeros(1, dtype=torch.int64, device=self.inputs[0].device)
+        # (a model without dropout draws no masks: no counter node in its graph -- 4.6 us per replay)
+        has_dropout = any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in model.modules())
         ops.set_dropout_seed_offset(self.replays)
         try:
             side = torch.cuda.Stream()
@@ -206,7 +208,8 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.replays.add_(1)
+                if has_dropout:
+                    self.replays.add_(1)
                 self.loss = _forward_backward(model, optim, self.inputs, self.denom)
         finally:
             ops.set_dropout_seed_offset(None)

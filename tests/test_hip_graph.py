@@ -57,7 +57,7 @@ def test_graphed_step_is_the_eager_step(p_drop, monkeypatch):
             # biases, after Adam has turned that noise into +-lr steps)
             for (n, a), (_, b) in zip(model_g.named_parameters(), model_e.named_parameters()):
                 assert torch.allclose(a.grad, b.grad, rtol=1e-3, atol=1e-6), n
-    assert int(step.replays.item()) == 3
+    assert int(step.replays.item()) == (3 if p_drop > 0 else 0)  # (the counter node exists only when masks are drawn)
     assert graphed == pytest.approx(eager, rel=1e-4)
     assert len(set(graphed)) == 3  # (the steps do move the loss: nothing is replaying a frozen state)
 
