@@ -151,7 +151,9 @@ class _Tail:
 # by the same fill) that are added at the join: the weight-gradient kernels end in a read-modify-write of dW.
 # Off: deterministic mode (its shadow buffer covers the real gradients), sharded steps (the early-gradients event sits
 # inside the one call), the re-associated embedding path, other embeddings / decoders.
-SPLIT_EMBED_BWD = True
+SPLIT_EMBED_BWD = "graph"  # "graph": while a hipGraph is being captured (engine.GraphedTrainStep) -- an eager step is bound by
+                           # its ~40 launches' host time (1.7 ms at C2), which the split's extra launches only add to (eager
+                           # steps measured 1.71-2.48 ms with it, 1.79 without); True: always; False: never
 SPLIT_SIDE_CUS = 128       # CU budget of the second stream's weight-gradient launch; the first stream's gets the rest
 SPLIT_MAIN_TARGET_USERS = 0.0  # share of the FIRST target segment's users left to the first stream (balance)
 _SIDE_STREAMS = {}
@@ -422,7 +424,8 @@ class _CarcaFn(torch.autograd.Function):
         # (every id a scatter-add of this pass can touch: known for the embeddings with an item table)
         id_lists = [sg[0] for sg in st["segs"]] if hasattr(emb, "items_embed") and len(st["segs"]) <= 4 else None
         late = emb.late_grad_params(st["emb_saved"]) if hasattr(emb, "late_grad_params") else ()
-        want_side = (SPLIT_EMBED_BWD and st["is_ca"] and emb_wt_idx is not None and not ops.deterministic()
+        split_on = torch.cuda.is_current_stream_capturing() if SPLIT_EMBED_BWD == "graph" else bool(SPLIT_EMBED_BWD)
+        want_side = (split_on and st["is_ca"] and emb_wt_idx is not None and not ops.deterministic()
                      and ops.early_event is None and hasattr(emb, "side_grad_params") and len(st["segs"]) >= 2)
         r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
         extra = r4(plan.staging_floats()) + (_SideEmbed.floats(emb) if want_side else 0)

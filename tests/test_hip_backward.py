@@ -73,6 +73,18 @@ def test_g2_gradients_match_reference(name, attn_variant):
     _check_grads(model, {k[len("grad/"):]: v for k, v in fx.outs.items() if k.startswith("grad/")})
 
 
+@pytest.mark.parametrize("name", G1_NAMES)
+def test_g2_gradients_match_reference_with_the_two_stream_backward(name, monkeypatch):
+    from carca_replication_amd import autograd
+
+    monkeypatch.setattr(autograd, "SPLIT_EMBED_BWD", True)
+    monkeypatch.setattr(autograd, "SPLIT_MAIN_TARGET_USERS", 0.5)
+    fx = load("g2_" + name)
+    model = model_from_fixture(fx)
+    _step(model, fx)
+    _check_grads(model, {k[len("grad/"):]: v for k, v in fx.outs.items() if k.startswith("grad/")})
+
+
 @pytest.mark.parametrize("name", G7_NAMES)
 def test_g7_variant_gradients(name):
     fx = load("g7_" + name)
@@ -235,7 +247,8 @@ def test_two_stream_embedding_backward_agrees_with_the_single_stream_pass(n_grou
     """The backward pass hands the target rows' embedding backward to a second stream once the decoder's backward has
     produced their d e (autograd._SideEmbed): same gradients as the single-stream pass (fp32 summation order aside), with
     the balance slice (SPLIT_MAIN_TARGET_USERS) on and off, and at CARCA_MAX_SEGS segments (profile + 3 target groups:
-    no room for the slice).  The G2 / G7 fixtures above run the split as shipped against the reference's gradients."""
+    no room for the slice).  As shipped the split is taken while a hipGraph is captured: tests/test_hip_graph.py replays
+    it against the eager single-stream step; the test below forces it on the reference's G2 gradients."""
     from carca_replication_amd import autograd, engine
     from carca_replication_amd import modules as M
     from carca_replication_amd.synth import eval_batch
