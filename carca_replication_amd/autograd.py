@@ -41,7 +41,11 @@ def _grad_buffers(model, params, extra: int, id_lists, late=()):
     previous gradient still lives in the cached buffer (accumulation without zero_grad(set_to_none=True))."""
     if not params:
         return [], None, (lambda: None)
-    big = [i for i, p in enumerate(params) if p.dim() == 2 and p.numel() * p.element_size() >= BIG_TABLE_BYTES]
+    # (only the ITEM table is row-sparse: its gradient rows are the batch's ids.  A dense weight of that size -- feats_embed
+    # over an attribute vocabulary of 40 k at g = 450 is 64 MB -- needs its whole gradient cleared every step like any other)
+    table = getattr(getattr(model, "embeds", model), "items_embed", None)
+    tw = table.weight if table is not None else None
+    big = [i for i, p in enumerate(params) if p is tw and p.numel() * p.element_size() >= BIG_TABLE_BYTES]
     late_i = [i for i, p in enumerate(params) if any(p is q for q in late) and i not in big]
     early_i = [i for i in range(len(params)) if i not in big and i not in late_i]
     r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
@@ -425,10 +429,14 @@ class _CarcaFn(torch.autograd.Function):
         id_lists = [sg[0] for sg in st["segs"]] if hasattr(emb, "items_embed") and len(st["segs"]) <= 4 else None
         late = emb.late_grad_params(st["emb_saved"]) if hasattr(emb, "late_grad_params") else ()
         split_on = torch.cuda.is_current_stream_capturing() if SPLIT_EMBED_BWD == "graph" else bool(SPLIT_EMBED_BWD)
-        want_side = (split_on and st["is_ca"] and emb_wt_idx is not None and not ops.deterministic()
-                     and ops.early_event is None and hasattr(emb, "side_grad_params") and len(st["segs"]) >= 2)
+        may_side = (bool(SPLIT_EMBED_BWD) and st["is_ca"] and emb_wt_idx is not None and not ops.deterministic()
+                    and ops.early_event is None and hasattr(emb, "side_grad_params") and len(st["segs"]) >= 2)
+        want_side = may_side and split_on
         r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
-        extra = r4(plan.staging_floats()) + (_SideEmbed.floats(emb) if want_side else 0)
+        # (the second stream's buffers are reserved whenever the split COULD be taken: the cached gradient buffer of a model
+        # with a big item table is keyed on this size, and the eager warm-up steps of GraphedTrainStep must leave the capture
+        # the buffer they used -- a fresh one inside the capture would be zero-filled as a whole by every replay)
+        extra = r4(plan.staging_floats()) + (_SideEmbed.floats(emb) if may_side else 0)
         grads, tail_buf, after_pass = _grad_buffers(model, params, extra, id_lists, late)
         det = _det_pass(model) if ops.deterministic() else None
         tail = _Tail(tail_buf)

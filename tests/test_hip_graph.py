@@ -98,3 +98,54 @@ def test_eager_step_between_replays_does_not_orphan_the_graphs_gradients():
         if n.endswith("WK.bias"):  # true gradient 0: Adam turns round-off into +-lr steps
             continue
         assert torch.allclose(a, b, rtol=1e-3, atol=2e-5), n
+
+
+@pytest.mark.parametrize("split", [False, "graph"], ids=["one-stream", "two-streams"])
+def test_graphed_step_with_a_big_item_table_captures_the_warm_up_gradient_cache(split, monkeypatch):
+    """A model whose item table counts as big (BASELINE config 4: 512 MB) keeps ONE gradient buffer across steps and clears
+    only the touched table rows (autograd._grad_buffers).  The captured pass -- which runs the backward on two streams and
+    needs room for the second stream's buffers -- must find the buffer of the eager warm-up steps: a buffer created inside
+    the capture would be zero-filled as a whole by every replay."""
+    from carca_replication_amd import autograd, engine
+
+    monkeypatch.setattr(autograd, "BIG_TABLE_BYTES", 1 << 10)
+    monkeypatch.setattr(autograd, "SPLIT_EMBED_BWD", split)
+    fresh, batch = _setup(0.0)
+    other = tuple(t.roll(1, 0) for t in batch)
+    model_g, opt_g = fresh()
+    engine.train_step(model_g, opt_g, batch)
+    flat0 = model_g.__dict__["_grad_cache"]["flat"]
+    step = engine.GraphedTrainStep(model_g, opt_g, batch)
+    assert model_g.__dict__["_grad_cache"]["flat"] is flat0
+    model_e, opt_e = fresh()
+    want = [float(engine.train_step(model_e, opt_e, b)) for b in (batch, other, batch)][1:]  # (the warm-up passes take no optimizer step)
+    got = [float(step(b)) for b in (other, batch)]
+    assert got == pytest.approx(want, rel=1e-4)
+    for (n, a), (_, b) in zip(model_g.named_parameters(), model_e.named_parameters()):
+        if n.endswith("WK.bias"):
+            continue
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-5), n
+
+
+def test_only_the_item_table_keeps_a_row_wise_cleared_gradient(monkeypatch):
+    """The gradient cache clears table ROWS by the previous step's ids: right for nn.Embedding(n_items, d), wrong for any other
+    matrix that happens to be large (feats_embed over a 40 k attribute vocabulary is 64 MB too).  With the threshold down at
+    1 KB every 2-D weight of the model is 'large': two steps must still give the gradients of the default path."""
+    from carca_replication_amd import autograd, engine
+
+    fresh, batch = _setup(0.0)
+    other = tuple(t.roll(1, 0) for t in batch)
+    (m1, o1), (m2, o2) = fresh(), fresh()
+    monkeypatch.setattr(autograd, "BIG_TABLE_BYTES", 1 << 10)
+    for b in (batch, other):
+        engine.train_step(m1, o1, b)
+    assert "_grad_cache" in m1.__dict__ and len(m1.__dict__["_flat_grad"]["big"]) == 1
+    monkeypatch.undo()
+    for b in (batch, other):
+        engine.train_step(m2, o2, b)
+    assert "_grad_cache" not in m2.__dict__
+    for (n, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        if n.endswith("WK.bias"):  # (true gradient 0)
+            continue
+        scale = float(b.grad.abs().max())
+        assert float((a.grad - b.grad).abs().max()) <= 1e-4 * scale + 1e-7, n
