@@ -200,8 +200,10 @@ def measure_train(c, model, rank, world, device, steps, fold=False, graphed=Fals
         what += ("; opt-in re-association of the linear embedding (one F->d GEMM forward, one F->d weight-gradient "
                  "product backward: ~5x fewer executed flops there, same gradients to ~1e-6)")
     if graphed:
-        what += ("; forward + backward replayed from ONE hipGraph (engine.GraphedTrainStep), the optimizer's launch issued "
-                 "behind it: ~40 launches cost 1.3-2.3 ms of host time per step when issued eagerly")
+        two = "" if fold else ("; the captured backward runs on two streams: the target rows' embedding backward beside the "
+                               "encoder's backward")
+        what += ("; forward + backward replayed from ONE hipGraph (engine.GraphedTrainStep" + two + "), the optimizer's launch "
+                 "issued behind it: ~40 launches cost 1.3-2.3 ms of host time per step when issued eagerly")
     out = {"users_per_s": world * c["B"] * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "what": what,
            "last_loss": float(loss)}
     if not fold:
