@@ -17,11 +17,13 @@ struct RowChainArgs {
   int rows, d, ld;        // every [rows, ld] activation buffer has row stride ld (= DPI); weights: Bt[n][k], row stride ld
   int mode;               // 0 = FFN side, 1 = input side
   int residual;
+  int diag;               // timing experiments of a stamped run (tuning key 9 = mode + 16 * diag): 1 drain vmcnt before the result
+                          // goes to LDS, 2 touch the later weight matrices at the kernel's start, 8 slot 7 = LDS writes retired (before the barrier)
   // FFN side: a0 = dy, w0 = w2_t, gate = h1, out1 = dh1pre, w1 = w1_t;  x = r;  out = dr
   // input side: a0 = dQ, w0 = wq_t (T2 = a0 w0 (+ add)), a1 = dK, w1 = wk_t, a2 = dV, w2 = wv_t (U = a1 w1 + a2 w2); x = x_in; out = dx
   const float *a0, *a1, *a2, *w0, *w1, *w2, *gate, *add, *x, *ln_w;
   float *out1, *out, *g_ln_w, *g_ln_b;
-  unsigned long long* stamps;  // diagnostic runs (carca_set_debug_buffer): 8 clocks per workgroup
+  unsigned long long* stamps;  // diagnostic runs (carca_set_debug_buffer): 8 clocks per wave, 16 wave slots per workgroup
 };
 
 template <int DPI, int MODE>
@@ -31,13 +33,14 @@ __global__ __launch_bounds__(DPI / 16 * 2 * 64) void row_chain_bwd_kernel(const 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float (*As)[BM * LS] = reinterpret_cast<float (*)[BM * LS]>(lds);                       // [3] operand tiles (FFN side: dy, then dh1pre)
   float (*Ex)[BM][8] = reinterpret_cast<float (*)[BM][8]>(lds + 3 * BM * LS);             // [2] per (row, column tile) partial sums of a round
-#define RC_STAMP(i)                                                                                  \
-  do {                                                                                               \
-    if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
-  } while (0)
-  RC_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (diagnostic runs: 8 clocks per WAVE -- [workgroup][16 waves][8])
+#define RC_STAMP(i)                                                                                                  \
+  do {                                                                                                               \
+    if (a.stamps && lane == 0) a.stamps[(blockIdx.x * 16 + wave) * 8 + (i)] = __builtin_readcyclecounter();          \
+  } while (0)
+  RC_STAMP(0);
   const int ln = lane & 15, mq = lane >> 4;
   const int ct = wave % NCT, rh = wave / NCT;
   const int row0 = blockIdx.x * BM;
@@ -92,6 +95,10 @@ __global__ __launch_bounds__(DPI / 16 * 2 * 64) void row_chain_bwd_kernel(const 
     for (int kg = 0; kg < NKG; ++kg) wf[kg] = gload4(bt, nn * ld + 16 * kg + 4 * mq);
   };
   f32x4 wfA[NKG], wfB[NKG];
+  if (a.diag & 2) {  // one dword of each later matrix per wave: translation + L2 line warm before they are needed
+    const float t1 = gload1(a.w1, nn * ld), t2 = gload1(a.w2 ? a.w2 : a.w1, nn * ld);
+    asm volatile("" ::"v"(t1), "v"(t2));
+  }
   load_w(a.w0, wfA);
   auto gemm = [&](int slot, const f32x4 (&wf)[NKG], f32x4 (&acc)[2]) {
     const float* a0p = &As[slot][(16 * (2 * rh) + ln) * LS + 4 * mq];
@@ -122,7 +129,12 @@ __global__ __launch_bounds__(DPI / 16 * 2 * 64) void row_chain_bwd_kernel(const 
         As[1][lrow * LS + n] = v;
         t1[i][r] = v;
       }
+    if (a.diag & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RC_STAMP(2);
+    if (a.diag & 8) {  // (slot 7 = LDS writes retired, before the barrier)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      RC_STAMP(7);
+    }
     __syncthreads();
     RC_STAMP(3);
     gemm(1, wfB, t2);
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(DPI / 16 * 2 * 64) void row_chain_bwd_kernel(const 
     grad_add(&a.g_ln_w[n], dg);
     grad_add(&a.g_ln_b[n], db);
   }
-  RC_STAMP(7);
+  if (!(a.diag & 8)) RC_STAMP(7);
 #undef RC_STAMP
 }
 
@@ -265,7 +277,8 @@ int carca_sa_ffn_chain_bwd(const float* dy, const float* h1, const float* r, con
   a.rows = rows; a.d = d; a.ld = dpi; a.mode = 0; a.residual = residual;
   a.a0 = dy; a.w0 = w2_t; a.w1 = w1_t; a.gate = h1; a.add = dy; a.x = r; a.ln_w = ln2_w;
   a.out1 = dh1pre; a.out = dr; a.g_ln_w = g_ln2_w; a.g_ln_b = g_ln2_b;
-  a.stamps = carca_tuning(CARCA_TUNE_STAMPS) == 1 ? carca_debug_buffer() : nullptr;
+  a.stamps = (carca_tuning(CARCA_TUNE_STAMPS) & 3) == 1 ? carca_debug_buffer() : nullptr;
+  a.diag = carca_tuning(CARCA_TUNE_STAMPS) >> 4;
   switch (dpi) {
     case 64: return launch_row_chain<64, 0>(a, (hipStream_t)stream);
     case 96: return launch_row_chain<96, 0>(a, (hipStream_t)stream);
@@ -282,7 +295,8 @@ int carca_sa_input_chain_bwd(const float* dqh, const float* dkh, const float* dv
   a.rows = rows; a.d = d; a.ld = dpi; a.mode = 1; a.residual = residual;
   a.a0 = dqh; a.a1 = dkh; a.a2 = dvh; a.w0 = wq_t; a.w1 = wk_t; a.w2 = wv_t; a.add = dr; a.x = x_in; a.ln_w = ln1_w;
   a.out = dx; a.g_ln_w = g_ln1_w; a.g_ln_b = g_ln1_b;
-  a.stamps = carca_tuning(CARCA_TUNE_STAMPS) == 2 ? carca_debug_buffer() : nullptr;
+  a.stamps = (carca_tuning(CARCA_TUNE_STAMPS) & 3) == 2 ? carca_debug_buffer() : nullptr;
+  a.diag = carca_tuning(CARCA_TUNE_STAMPS) >> 4;
   switch (dpi) {
     case 64: return launch_row_chain<64, 1>(a, (hipStream_t)stream);
     case 96: return launch_row_chain<96, 1>(a, (hipStream_t)stream);

@@ -26,16 +26,27 @@ lib = _lib.load()
 for _ in range(5):
     engine.train_step(model, opt, batch)
 NAMES = ["tiles in LDS", "first product done", "its result in LDS", "barrier", "products done", "LayerNorm rounds done", "outputs stored", "end"]
-for mode, what in ((1, "FFN side"), (2, "input side")):
+DIAGS = [int(v) for v in os.environ.get("DIAGS", "0").split(",")]
+for mode, what in [(m + 16 * dg, w + (f" [diag {dg}]" if dg else "")) for dg in DIAGS for m, w in ((1, "FFN side"), (2, "input side"))]:
     nwg = (c["B"] * L + 63) // 64
-    buf = torch.zeros(nwg * 8 + 64, dtype=torch.int64, device="cuda")
+    nw = 2 * (96 // 16)  # waves per workgroup at dpi = 96
+    buf = torch.zeros(nwg * 16 * 8 + 64, dtype=torch.int64, device="cuda")
     lib.carca_set_tuning(9, mode)
     lib.carca_set_debug_buffer(buf.data_ptr())
     engine.train_step(model, opt, batch)
     torch.cuda.synchronize()
     lib.carca_set_debug_buffer(None)
     lib.carca_set_tuning(9, 0)
-    st = buf[: nwg * 8].view(nwg, 8).double().cpu()
-    rel = st - st[:, :1]
-    print(what + ": cycles since the workgroup's start, median (max): " +
-          "  ".join(f"[{NAMES[i - 1]}] {rel[:, i][rel[:, i] > 0].median() if (rel[:, i] > 0).any() else 0:.0f} ({rel[:, i].max():.0f})" for i in range(1, 8)))
+    st = buf[: nwg * 16 * 8].view(nwg, 16, 8)[:, :nw].double().cpu()
+    t0 = st[:, :, 0].min(dim=1, keepdim=True).values  # the workgroup's first wave to start
+    rel = st - t0[:, :, None]
+    print(what + ": cycles since the workgroup's first wave started; per phase: median over workgroups of the FASTEST / median / SLOWEST wave")
+    for i in range(8):
+        col = rel[:, :, i]
+        if not (col > 0).any():
+            continue
+        print(f"   [{(['start'] + NAMES)[i]:24s}] {col.min(dim=1).values.median():8.0f} {col.median(dim=1).values.median():8.0f} {col.max(dim=1).values.median():8.0f}")
+    w0 = rel[0]
+    print("   workgroup 0, per wave (rows) x stamp (columns):")
+    for w in range(nw):
+        print("     wave %2d (SIMD %d): " % (w, w % 4) + " ".join(f"{w0[w, i]:7.0f}" for i in range(8)))
