@@ -436,25 +436,37 @@ __global__ __launch_bounds__(512) void sa_attn_bwd_kernel(const float* __restric
 
   // ---- load Q, K, dO rows (16 B per thread, coalesced) ----------------------------------------------
   constexpr int V4 = DPO / 4;
-  for (int i = tid; i < 16 * LT * V4; i += 512) {
-    const int r = i / V4, c4 = i - r * V4;
-    f32x4 q = zero4(), k = zero4(), o = zero4(), v = zero4();
-    if (r < L) {
+  // (every request goes out before the first is waited for: unconditional loads of clamped rows / columns -- under the
+  // `r < L` branch each of the three loop iterations was a round trip of its own)
+  constexpr int ST_IT = (ATT_LMAX * V4 + 511) / 512;
+  {
+    f32x4 qq[ST_IT], kk[ST_IT], oo[ST_IT], vv[ST_IT];
+#pragma unroll
+    for (int j = 0; j < ST_IT; ++j) {
+      const int i = tid + 512 * j, r = min(i / V4, L - 1), c4 = i % V4;
       const size_t off = (ubase + r) * DPO + 4 * c4;
-      q = glb4(qh + off);
-      k = glb4(kh + off);
-      if (V_LDS) v = glb4(vh + off);
+      qq[j] = glb4(qh + off);
+      kk[j] = glb4(kh + off);
+      vv[j] = V_LDS ? glb4(vh + off) : zero4();
       const float* dar = d_attn + (ubase + r) * ld_da;  // plain feature order -> head-padded order
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int j = unpad_feature(4 * c4 + e, dh, DHP);
-        o[e] = j >= 0 ? dar[j] : 0.f;
+        const int jf = unpad_feature(4 * c4 + e, dh, DHP);
+        const float dv = dar[jf >= 0 ? jf : 0];
+        oo[j][e] = jf >= 0 ? dv : 0.f;
       }
     }
-    *reinterpret_cast<f32x4*>(Qs + r * SO + 4 * c4) = q;
-    *reinterpret_cast<f32x4*>(Ks + r * SO + 4 * c4) = k;
-    *reinterpret_cast<f32x4*>(Os + r * SO + 4 * c4) = o;
-    if (V_LDS) *reinterpret_cast<f32x4*>(Vs + r * SO + 4 * c4) = v;
+#pragma unroll
+    for (int j = 0; j < ST_IT; ++j) {
+      const int i = tid + 512 * j, r = i / V4, c4 = i - r * V4;
+      if (i < 16 * LT * V4) {
+        const bool live = r < L;
+        *reinterpret_cast<f32x4*>(Qs + r * SO + 4 * c4) = live ? qq[j] : zero4();
+        *reinterpret_cast<f32x4*>(Ks + r * SO + 4 * c4) = live ? kk[j] : zero4();
+        *reinterpret_cast<f32x4*>(Os + r * SO + 4 * c4) = live ? oo[j] : zero4();
+        if (V_LDS) *reinterpret_cast<f32x4*>(Vs + r * SO + 4 * c4) = live ? vv[j] : zero4();
+      }
+    }
   }
   __syncthreads();
 
@@ -510,6 +522,12 @@ struct CrossBwdGroups {
 };
 
 template <int DPI, int DHP, int NH>
+constexpr int cross_bwd_head_slots() {
+  using G = AttGeom<DPI, DHP, NH>;
+  return sizeof(float) * (3 * ATT_LMAX * G::SO + 4 * ATT_LMAX * ATT_SP + 64 + (1 + 8) * G::DPO + 64) <= 160 * 1024 ? 2 : 1;
+}
+
+template <int DPI, int DHP, int NH>
 __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __restrict__ kh,
                                                              const float* __restrict__ vh,
                                                              const int32_t* __restrict__ p_ids,
@@ -524,13 +542,18 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
   float* Qs = lds;                       // [64][SO] one chunk of <= 64 targets
   float* Ks = Qs + ATT_LMAX * SO;        // [64][SO]
   float* Vs = Ks + ATT_LMAX * SO;        // [64][SO]
-  float* PT = Vs + ATT_LMAX * SO;        // [64][ATT_SP]
-  float* DST = PT + ATT_LMAX * ATT_SP;   // [64][ATT_SP]
-  float* dls = DST + ATT_LMAX * ATT_SP;  // [64] dlogit of the chunk
+  // Two heads of a workgroup in flight where LDS has room for a second P^T / dS^T pair (d <= 96): phase 1 of a chunk has
+  // QT <= 4 (tile, head) units per head -- with one head at a time half of the eight waves sat it out, and the workgroups
+  // that own two of the three heads set the kernel's length.
+  constexpr int HS = cross_bwd_head_slots<DPI, DHP, NH>();
+  constexpr int PSZ = 2 * ATT_LMAX * ATT_SP;  // one slot: P^T then dS^T
+  float* PT0 = Vs + ATT_LMAX * SO;       // [HS] x { [64][ATT_SP] P^T, [64][ATT_SP] dS^T }
+  float* dls = PT0 + HS * PSZ;           // [64] dlogit of the chunk
   float* wps = dls + 64;                 // [DPO] ffn weight, head-padded
   float* dwp = wps + DPO;                // [NW][DPO] its gradient, accumulated over the user's targets: one slot per
                                          // wave (the target tiles are dealt to the waves statically), summed in wave
                                          // order at the end -- an LDS atomic would add in the order the waves arrive
+  int* ids_s = reinterpret_cast<int*>(dwp + NW * DPO);  // [64] target ids of the chunk
 
   // heads shared by two workgroups when users <= CUs / 2 (see sa_attn_bwd_kernel); dlogit is written by the first
   const int u = blockIdx.x / nparts, part = blockIdx.x - u * nparts;
@@ -542,15 +565,25 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
   const size_t ubase = (size_t)u * L;
   constexpr int V4 = DPO / 4;
 
-  for (int i = tid; i < 16 * LT * V4; i += 512) {
-    const int r = i / V4, c4 = i - r * V4;
-    f32x4 k = zero4(), v = zero4();
-    if (r < L) {
-      k = glb4(kh + (ubase + r) * DPO + 4 * c4);
-      v = glb4(vh + (ubase + r) * DPO + 4 * c4);
+  // (every request of a staging pass goes out before the first is waited for: unconditional loads of clamped rows -- a load
+  // under a branch is waited for right there, i.e. one round trip per loop iteration)
+  constexpr int ST_IT = (ATT_LMAX * V4 + 511) / 512;  // 16-byte slots per thread of a [64][DPO] image
+  {
+    f32x4 kk[ST_IT], vv[ST_IT];
+#pragma unroll
+    for (int j = 0; j < ST_IT; ++j) {
+      const int i = tid + 512 * j, r = min(i / V4, L - 1), c4 = i % V4;
+      kk[j] = glb4(kh + (ubase + r) * DPO + 4 * c4);
+      vv[j] = glb4(vh + (ubase + r) * DPO + 4 * c4);
     }
-    *reinterpret_cast<f32x4*>(Ks + r * SO + 4 * c4) = k;
-    *reinterpret_cast<f32x4*>(Vs + r * SO + 4 * c4) = v;
+#pragma unroll
+    for (int j = 0; j < ST_IT; ++j) {
+      const int i = tid + 512 * j, r = i / V4, c4 = i - r * V4;
+      if (i < 16 * LT * V4) {
+        *reinterpret_cast<f32x4*>(Ks + r * SO + 4 * c4) = r < L ? kk[j] : zero4();
+        *reinterpret_cast<f32x4*>(Vs + r * SO + 4 * c4) = r < L ? vv[j] : zero4();
+      }
+    }
   }
   for (int i = tid; i < DPO; i += 512) wps[i] = ffn_w_pad[i];
   for (int i = tid; i < NW * DPO; i += 512) dwp[i] = 0.f;
@@ -565,29 +598,41 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
       const size_t gbase = (size_t)u * grp.N + n0;
       const size_t ybase = (size_t)u * (grp.ld_y ? grp.ld_y : grp.N) + n0;  // y and dy may be column blocks of [B, sum N]
       __syncthreads();  // previous chunk's phase 2 is done with Qs / dls
-      for (int i = tid; i < 16 * QT * V4; i += 512) {
-        const int r = i / V4, c4 = i - r * V4;
-        f32x4 q = zero4();
-        if (r < nq) q = glb4(grp.qh + (gbase + r) * DPO + 4 * c4);
-        *reinterpret_cast<f32x4*>(Qs + r * SO + 4 * c4) = q;
-      }
-      if (tid < 64) {
-        float dl = 0.f;
-        if (tid < nq) {
-          const float yv = grp.y[ybase + tid];
-          dl = grp.dy[ybase + tid] * yv * (1.0f - yv);  // d sigmoid
-          if (grp.dlogit && part == 0) grp.dlogit[gbase + tid] = dl;
+      {
+        f32x4 qq[ST_IT];
+        const int t64 = min(tid & 63, nq - 1);
+        const float yv = grp.y[ybase + t64], dyv = grp.dy[ybase + t64];
+        const int idv = grp.ids[gbase + t64];
+#pragma unroll
+        for (int j = 0; j < ST_IT; ++j) {
+          const int i = tid + 512 * j, r = min(i / V4, nq - 1), c4 = i % V4;
+          qq[j] = glb4(grp.qh + (gbase + r) * DPO + 4 * c4);
         }
-        dls[tid] = dl;
+#pragma unroll
+        for (int j = 0; j < ST_IT; ++j) {
+          const int i = tid + 512 * j, r = i / V4, c4 = i - r * V4;
+          if (i < 16 * QT * V4) *reinterpret_cast<f32x4*>(Qs + r * SO + 4 * c4) = r < nq ? qq[j] : zero4();
+        }
+        if (tid < 64) {
+          const float dl = tid < nq ? dyv * yv * (1.0f - yv) : 0.f;  // d sigmoid
+          if (tid < nq && grp.dlogit && part == 0) grp.dlogit[gbase + tid] = dl;
+          dls[tid] = dl;
+        } else if (tid < 128) {
+          ids_s[tid - 64] = tid - 64 < nq ? idv : 0;
+        }
       }
       __syncthreads();
 #pragma unroll 1
-      for (int h = h_lo; h < h_hi; ++h) {
-        for (int qt = wave; qt < QT; qt += NW) {
+      for (int h0 = h_lo; h0 < h_hi; h0 += HS) {
+        const int nh = min(HS, h_hi - h0);
+        for (int unit = wave; unit < nh * QT; unit += NW) {
+          const int hs = unit / QT, qt = unit - hs * QT, h = h0 + hs;
+          float* PT = PT0 + hs * PSZ;
+          float* DST = PT + ATT_LMAX * ATT_SP;
           const int qloc = 16 * qt + ln;      // row in the chunk
           const int nslot = n0 + qloc;        // target slot in the group
           const bool in_range = qloc < nq;
-          const bool q_ok = in_range && grp.ids[gbase + (in_range ? qloc : 0)] != 0;
+          const bool q_ok = in_range && ids_s[qloc] != 0;
           unsigned okbits = 0;
 #pragma unroll
           for (int kt = 0; kt < ATT_LT; ++kt)
@@ -625,12 +670,22 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
           }
         }
         __syncthreads();
-        const int njobs = 2 * LT * G::NFH;
+        const int per_head = 2 * LT * G::NFH, njobs = nh * per_head;
         for (int job = wave; job < njobs; job += NW) {
-          const int which = job / (LT * G::NFH);
-          const int jj = job - which * LT * G::NFH;
+          const int hs = job / per_head, j1 = job - hs * per_head, h = h0 + hs;
+          const float* PT = PT0 + hs * PSZ;
+          const float* DST = PT + ATT_LMAX * ATT_SP;
+          const int which = j1 / (LT * G::NFH);
+          const int jj = j1 - which * LT * G::NFH;
           const int kt = jj / G::NFH, ft = jj - kt * G::NFH;
           f32x4 acc;
+          // the same lane owns an output element in every chunk: plain read-modify-write, no race -- the old values are
+          // requested BEFORE the tile's MFMAs (clamped rows, unconditional) and added behind them
+          float* out = which == 0 ? dkh : dvh;
+          float* dst0 = out + ubase * DPO + h * DHP + 16 * ft + ln;
+          float oldv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oldv[r] = dst0[(size_t)min(16 * kt + 4 * mq + r, L - 1) * DPO];
           if (which == 0) {
             auto rfrag = [&](int qt, int s) { return Qs[(16 * qt + 4 * mq + s) * SO + h * DHP + 16 * ft + ln]; };
             acc = attn_bwd_phase2_tile(DST, kt, 0, QT, rfrag, lane);
@@ -639,15 +694,10 @@ __global__ __launch_bounds__(512) void cross_attn_bwd_kernel(const float* __rest
             auto rfrag = [&](int qt, int s) { return dls[16 * qt + 4 * mq + s] * wv; };
             acc = attn_bwd_phase2_tile(PT, kt, 0, QT, rfrag, lane);
           }
-          float* out = which == 0 ? dkh : dvh;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = 16 * kt + 4 * mq + r;
-            if (key < L) {
-              float* dst = out + (ubase + key) * DPO + h * DHP + 16 * ft + ln;
-              // the same lane owns this element in every chunk: plain read-modify-write, no race
-              *dst = first_pass ? acc[r] : *dst + acc[r];
-            }
+            if (key < L) dst0[(size_t)key * DPO] = first_pass ? acc[r] : oldv[r] + acc[r];
           }
         }
         __syncthreads();
@@ -691,7 +741,8 @@ int launch_cross_attn_bwd(const float* kh, const float* vh, const int32_t* p_ids
                           const float* ffn_w_pad, float* dkh, float* dvh, float* d_ffn_w_pad, int B, int L, int d,
                           int training, float dscale, hipStream_t stream) {
   using G = AttGeom<DPI, DHP, NH>;
-  const size_t lds_bytes = sizeof(float) * (3 * ATT_LMAX * G::SO + 2 * ATT_LMAX * ATT_SP + 64 + (1 + 8) * G::DPO);
+  const size_t lds_bytes = sizeof(float) * (3 * ATT_LMAX * G::SO + 2 * cross_bwd_head_slots<DPI, DHP, NH>() * ATT_LMAX * ATT_SP + 64 +
+                                            (1 + 8) * G::DPO + 64);
   auto kern = cross_attn_bwd_kernel<DPI, DHP, NH>;
   static bool attr_set = false;
   if (!attr_set) {
