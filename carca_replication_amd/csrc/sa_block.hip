@@ -72,19 +72,30 @@ __global__ __launch_bounds__(1024) void sa_block_kernel_w16(const float* __restr
   // ---- A0 ---------------------------------------------------------------------------------------------
   constexpr int V4 = DPI / 4;
   const bool vec_ok = (ldx % 4 == 0) && ldx >= DPI;  // internal buffers: padded rows with zeroed pad columns
-  for (int i = tid; i < 16 * LT * V4; i += 1024) {
-    const int r = i / V4, c4 = i - r * V4;
-    f32x4 v = zero4();
-    if (r < L) {
-      const float* xr = x + (ubase + r) * ldx + 4 * c4;
-      if (vec_ok) {
-        v = gload4(x, (int)((ubase + r) * ldx) + 4 * c4);
-      } else {
+  if (vec_ok) {  // (both passes' loads in flight before the first LDS write: clamped rows, no load under a branch)
+    constexpr int A0_IT = (ATT_LMAX * V4 + 1023) / 1024;
+    f32x4 xv[A0_IT];
+#pragma unroll
+    for (int j = 0; j < A0_IT; ++j) {
+      const int i = tid + 1024 * j, r = min(i / V4, L - 1), c4 = i % V4;
+      xv[j] = gload4(x, (int)((ubase + r) * ldx) + 4 * c4);
+    }
+#pragma unroll
+    for (int j = 0; j < A0_IT; ++j) {
+      const int i = tid + 1024 * j, r = i / V4, c4 = i - r * V4;
+      if (i < 16 * LT * V4) *reinterpret_cast<f32x4*>(Xs + r * G::SI + 4 * c4) = r < L ? xv[j] : zero4();
+    }
+  } else {
+    for (int i = tid; i < 16 * LT * V4; i += 1024) {
+      const int r = i / V4, c4 = i - r * V4;
+      f32x4 v = zero4();
+      if (r < L) {
+        const float* xr = x + (ubase + r) * ldx + 4 * c4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 4 * c4 + e < d ? xr[e] : 0.f;
       }
+      *reinterpret_cast<f32x4*>(Xs + r * G::SI + 4 * c4) = v;
     }
-    *reinterpret_cast<f32x4*>(Xs + r * G::SI + 4 * c4) = v;
   }
   __syncthreads();
   SA_STAMP(1);
