@@ -159,7 +159,9 @@ SPLIT_EMBED_BWD = "graph"  # "graph": while a hipGraph is being captured (engine
                            # its ~40 launches' host time (1.7 ms at C2), which the split's extra launches only add to (eager
                            # steps measured 1.71-2.48 ms with it, 1.79 without); True: always; False: never
 SPLIT_SIDE_CUS = 128       # CU budget of the second stream's weight-gradient launch; the first stream's gets the rest
-SPLIT_MAIN_TARGET_USERS = 0.0  # share of the FIRST target segment's users left to the first stream (balance)
+SPLIT_MAIN_TARGET_USERS = 0.04  # share of the FIRST target segment's users left to the first stream (balance; C2: 0 / 0.04 / 0.08
+                                # -> 1.654 / 1.642 / 1.655 ms per step)
+SPLIT_MIN_GFLOP = 20.0     # the split pays when d feats_embed is long against the launches it doubles (C2: 71 GFLOP per pass)
 _SIDE_STREAMS = {}
 
 
@@ -431,6 +433,10 @@ class _CarcaFn(torch.autograd.Function):
         split_on = torch.cuda.is_current_stream_capturing() if SPLIT_EMBED_BWD == "graph" else bool(SPLIT_EMBED_BWD)
         may_side = (bool(SPLIT_EMBED_BWD) and st["is_ca"] and emb_wt_idx is not None and not ops.deterministic()
                     and ops.early_event is None and hasattr(emb, "side_grad_params") and len(st["segs"]) >= 2)
+        if may_side:  # (worth it only for a long d feats_embed product: every latency-bound launch of the call runs twice)
+            wf = emb.feats_embed.weight
+            rows = sum(sg[0].numel() for sg in st["segs"])
+            may_side = 2.0 * rows * wf.shape[0] * wf.shape[1] >= SPLIT_MIN_GFLOP * 1e9
         want_side = may_side and split_on
         r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
         # (the second stream's buffers are reserved whenever the split COULD be taken: the cached gradient buffer of a model

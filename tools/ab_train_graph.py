@@ -28,13 +28,13 @@ lib = _lib.load()
 res = {s: [] for s in settings}
 for rnd in range(int(os.environ.get("ROUNDS", "4"))):
     for s in settings:
-        autograd.SPLIT_EMBED_BWD, autograd.SPLIT_SIDE_CUS, autograd.SPLIT_MAIN_TARGET_USERS = "graph", 128, 0.0
+        autograd.SPLIT_EMBED_BWD, autograd.SPLIT_SIDE_CUS, autograd.SPLIT_MAIN_TARGET_USERS = "graph", 128, 0.04
         for k in range(8):
             lib.carca_set_tuning(k, 0)
         for kv in filter(None, s.split(",")):
             k, v = kv.split("=")
             if k == "split":
-                autograd.SPLIT_EMBED_BWD = bool(int(v))
+                autograd.SPLIT_EMBED_BWD = "graph" if v == "graph" else bool(int(v))
             elif k == "side":
                 autograd.SPLIT_SIDE_CUS = int(v)
             elif k == "frac":
