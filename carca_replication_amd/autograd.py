@@ -436,7 +436,8 @@ class _CarcaFn(torch.autograd.Function):
         if may_side:  # (worth it only for a long d feats_embed product: every latency-bound launch of the call runs twice)
             wf = emb.feats_embed.weight
             rows = sum(sg[0].numel() for sg in st["segs"])
-            may_side = 2.0 * rows * wf.shape[0] * wf.shape[1] >= SPLIT_MIN_GFLOP * 1e9
+            # ... and while the encoder's backward leaves CUs idle: its kernels run one or two workgroups per user
+            may_side = (2.0 * rows * wf.shape[0] * wf.shape[1] >= SPLIT_MIN_GFLOP * 1e9 and 2 * B <= ops.num_cus())
         want_side = may_side and split_on
         r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
         # (the second stream's buffers are reserved whenever the split COULD be taken: the cached gradient buffer of a model
