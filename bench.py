@@ -320,6 +320,43 @@ def measure_epoch_pipeline(c, model, device, world, fence, n_batches=256):
                     "headline" % n_batches}
 
 
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv, script=None, python=None, env=None):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as a CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py argv`)
+    and relay rank 0's JSON line and the exit code.  The parent never touches the GPU (no HIP call, no re-exec of a process
+    that initialised one); the children read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun.
+    Returns (exit code, last stdout line that parses as JSON or None)."""
+    import subprocess
+
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script or os.path.abspath(__file__)] + list(argv)
+    child_env = dict(os.environ if env is None else env)
+    child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the host driver only supports dmabuf IPC: RCCL needs it)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=child_env, text=True)
+    line = None
+    for out in proc.stdout:  # (stderr passes through; stdout is relayed as it comes, the JSON line remembered)
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        s = out.strip()
+        if s.startswith("{") and s.endswith("}"):
+            try:
+                json.loads(s)
+                line = s
+            except ValueError:
+                pass
+    return proc.wait(), line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +369,14 @@ def main():
     ap.add_argument("--train-steps", type=int, default=24, help="extra, untimed-by-the-headline train-step measurement")
     ap.add_argument("--no-scoring-scaling", action="store_true", help="skip the scoring kernel's B = 1024 / 4096 side pass")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the plain invocation: launch the ranks ourselves, BEFORE anything of this process touches the GPU
+        rc, line = spawn_ranks(args.gpus, sys.argv[1:])
+        if rc == 0 and line is None:
+            print("bench.py: the ranks exited 0 but rank 0 printed no JSON line", file=sys.stderr)
+            rc = 1
+        raise SystemExit(rc)
 
     # The box exposes every host core but the cgroup grants only a share of them: torch's default intra-op pool
     # (one thread per visible core, spinning after each CPU op) burns the quota and gets the launching thread
@@ -350,8 +395,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # test hooks (a 1-GPU box cannot run RCCL across ranks): CARCA_BENCH_DEVICE pins every rank to one device and
     # CARCA_BENCH_BACKEND=gloo swaps the collective backend, so the N > 1 control flow can be rehearsed there
@@ -359,6 +402,7 @@ def main():
         local_rank = int(os.environ["CARCA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    collective = {"backend": None, "world_size": 1}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("CARCA_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
@@ -366,6 +410,9 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        # what the process group itself reports (not the environment): the line's n_gpus must be the ranks that ran
+        collective = {"backend": "rccl (torch 'nccl')" if backend == "nccl" else backend, "world_size": dist.get_world_size()}
+        assert collective["world_size"] == args.gpus
 
     from carca_replication_amd import ops
 
@@ -539,7 +586,8 @@ def main():
             "config": {"workload": "C2 synthetic Beauty-shape eval: per GPU B=%d users x (L=50 profile + 1+100 candidates), "
                                    "d=90 g=450 H=3 2 SA blocks + cross-attention decoder, n_attrs=4096 n_ctx=6 "
                                    "n_items=12102, random-init weights" % c["B"],
-                       "users_per_gpu_per_step": c["B"], "parallelism": f"users sharded x{world}, no data-path collective"},
+                       "users_per_gpu_per_step": c["B"], "parallelism": f"users sharded x{world}, no data-path collective",
+                       "collective": collective},
             "model_tflops": value * fl["total"] / 1e12,
             "preheat_ms": 1e3 * PREHEAT_S, "preheat_steps": n_heat,
             "timeline": {"gpu_span_ms": gpu_span_ms, "host_issue_ms": host_issue_ms,

@@ -236,6 +236,10 @@ SIGNATURES = {
     "carca_det_flush": (_i, [_fp, _fp, C.c_longlong, C.c_longlong, _fp]),
     "carca_set_debug_buffer": (_i, [_fp]),
     "carca_last_error": (C.c_char_p, []),
+    "carca_poll_errors": (_i, []),
+    "carca_capture_scope": (_i, [_fp, C.POINTER(C.c_ulonglong)]),
+    "carca_capture_bytes": (C.c_longlong, [C.c_ulonglong]),
+    "carca_capture_release": (_i, [C.c_ulonglong]),
     "carca_padded_dims": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "carca_pack_weights": (_i, [C.POINTER(PackDesc), _i, _fp]),
     "carca_embed_fwd": (_i, [C.POINTER(RowSeg), _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),

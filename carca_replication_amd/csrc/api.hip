@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <vector>
+
 #include "carca_common.h"
 #include "../../include/carca_hip.h"
 
@@ -255,7 +258,81 @@ bool carca_stream_capturing(hipStream_t stream) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   return hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
 }
-void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view, size_t zero_bytes) {
+// ---- memory the library owns on behalf of its kernels (carca_common.h) ------------------------------------------------
+namespace {
+std::mutex g_mem_mu;
+struct ScratchSlot {
+  int dev;
+  hipStream_t stream;
+  int tag;
+  void* p;
+  size_t bytes;
+};
+std::vector<ScratchSlot> g_scratch;
+struct Retired {
+  int dev;
+  hipStream_t stream;
+  void* p;
+};
+std::vector<Retired> g_retired;  // outgrown scratch: freed once its stream has drained (hipFree would block on it)
+struct CaptureBlock {
+  unsigned long long scope;
+  void* p;
+  size_t bytes;
+  bool host;
+};
+std::vector<CaptureBlock> g_capture_blocks;
+unsigned long long capture_id(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess || st != hipStreamCaptureStatusActive) return 0;
+  return id ? id : ~0ull;
+}
+}  // namespace
+
+void* carca_stream_scratch(hipStream_t stream, int tag, size_t bytes, size_t zero_bytes, bool* fresh) {
+  std::lock_guard<std::mutex> lock(g_mem_mu);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (fresh) *fresh = false;
+  for (size_t i = 0; i < g_retired.size();) {  // (outgrown buffers whose stream has nothing left in flight)
+    if (g_retired[i].dev == dev && !carca_stream_capturing(g_retired[i].stream) && hipStreamQuery(g_retired[i].stream) == hipSuccess) {
+      (void)hipFree(g_retired[i].p);
+      g_retired[i] = g_retired.back();
+      g_retired.pop_back();
+    } else {
+      ++i;
+    }
+  }
+  (void)hipGetLastError();  // (hipStreamQuery reports hipErrorNotReady through the sticky last-error too)
+  ScratchSlot* sl = nullptr;
+  for (auto& s : g_scratch)
+    if (s.dev == dev && s.stream == stream && s.tag == tag) sl = &s;
+  if (!sl) {
+    g_scratch.push_back(ScratchSlot{dev, stream, tag, nullptr, 0});
+    sl = &g_scratch.back();
+  }
+  if (bytes <= sl->bytes) return sl->p;
+  if (sl->p) g_retired.push_back(Retired{dev, stream, sl->p});  // launches already queued on `stream` may still use it
+  sl->p = nullptr;
+  sl->bytes = 0;
+  const size_t want = bytes + bytes / 8;
+  void* p = nullptr;
+  hipError_t rc = hipMalloc(&p, want);
+  if (rc == hipSuccess && zero_bytes) rc = hipMemsetAsync(p, 0, zero_bytes, stream);  // (stream-ordered: ahead of the first user)
+  if (rc != hipSuccess) {
+    if (p) (void)hipFree(p);
+    carca_set_error("stream scratch: cannot allocate %zu B: %s", want, hipGetErrorString(rc));
+    return nullptr;
+  }
+  sl->p = p;
+  sl->bytes = want;
+  if (fresh) *fresh = true;
+  return p;
+}
+
+void* carca_capture_alloc(hipStream_t stream, size_t bytes, bool host_mapped, void** device_view, size_t zero_bytes) {
+  const unsigned long long scope = capture_id(stream);
   hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
   (void)hipThreadExchangeStreamCaptureMode(&mode);
   void* p = nullptr;
@@ -266,7 +343,7 @@ void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view, si
   } else {
     rc = hipMalloc(&p, bytes);
     if (device_view) *device_view = p;
-    // (state a kernel keeps clean itself -- the stream-K flags: every taker resets its own -- is cleared here, once, on the
+    // (state a kernel keeps clean itself -- the stream-K flags: every taker resets its own -- is cleared here, once, on a
     // stream of the library's own, inside the relaxed-mode window)
     if (rc == hipSuccess && zero_bytes) {
       static hipStream_t zs = nullptr;  // (a stream of our own: the legacy stream may not wait for a capturing blocking stream)
@@ -280,7 +357,37 @@ void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view, si
     carca_set_error("allocation of %zu B during stream capture failed: %s", bytes, hipGetErrorString(rc));
     return nullptr;
   }
+  std::lock_guard<std::mutex> lock(g_mem_mu);
+  g_capture_blocks.push_back(CaptureBlock{scope, p, bytes, host_mapped});
   return p;
+}
+
+extern "C" int carca_capture_scope(void* stream, unsigned long long* id_out) {
+  CARCA_CHECK_ARG(id_out, "capture_scope: null");
+  *id_out = capture_id((hipStream_t)stream);
+  return CARCA_OK;
+}
+extern "C" long long carca_capture_bytes(unsigned long long id) {
+  std::lock_guard<std::mutex> lock(g_mem_mu);
+  long long n = 0;
+  for (const auto& b : g_capture_blocks)
+    if (b.scope == id) n += (long long)b.bytes;
+  return n;
+}
+extern "C" int carca_capture_release(unsigned long long id) {
+  CARCA_CHECK_ARG(id != 0, "capture_release: 0 is not a capture");
+  std::lock_guard<std::mutex> lock(g_mem_mu);
+  size_t kept = 0;
+  for (size_t i = 0; i < g_capture_blocks.size(); ++i) {
+    const CaptureBlock& b = g_capture_blocks[i];
+    if (b.scope == id) {
+      (void)(b.host ? hipHostFree(b.p) : hipFree(b.p));
+    } else {
+      g_capture_blocks[kept++] = b;
+    }
+  }
+  g_capture_blocks.resize(kept);
+  return CARCA_OK;
 }
 void carca_arm_launch_events(void* start, void* stop) {
   g_armed_start = (hipEvent_t)start;

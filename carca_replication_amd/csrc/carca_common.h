@@ -134,7 +134,9 @@ __device__ __forceinline__ void grad_add(float* p, float v) {
   if (__builtin_expect(c != nullptr, 0)) {
     float* const base = c->base;
     const long long off = p - base;
-    if (base && off >= 0 && off < c->n) {
+    // (a contribution the fixed-point format cannot hold -- NaN, +-Inf, |v| >= 2^27 -- takes the fp32 atomic below instead
+    // of saturating silently: a diverging run must show non-finite gradients here as it does on the default path)
+    if (base && off >= 0 && off < c->n && fabsf(v) < 134217728.f) {
       atomicAdd(c->shadow + off, (unsigned long long)__float2ll_rn(v * c->scale));
       return;
     }
@@ -199,22 +201,30 @@ __device__ __forceinline__ void carca_gather_rows(const CarcaGatherArgs& ga, int
   }
 }
 
-// tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice.
-// Keys 3..5 are used by number (see include/carca_hip.h).
+// tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice.  ONE meaning
+// per key (include/carca_hip.h lists them); keys 3..7 are used by number.
 enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_DETERMINISTIC = 8,
-       CARCA_TUNE_STAMPS = 9, CARCA_TUNE_CU_CAP = 10, CARCA_TUNE_COUNT = 12 };
+       CARCA_TUNE_STAMPS = 9, CARCA_TUNE_CU_CAP = 10, CARCA_TUNE_SK_DON = 11, CARCA_TUNE_SK_SPIN_LOG2 = 12,
+       CARCA_TUNE_SK_WITHHOLD = 13, CARCA_TUNE_XS_OPT = 14, CARCA_TUNE_DIAG = 15, CARCA_TUNE_SPLIT_GEMM = 16,
+       CARCA_TUNE_COUNT = 24 };
 int carca_tuning(int key);
 int carca_num_cus();  // compute units of the current device (cached)
 // Timing events for this thread's NEXT row-GEMM launch (the roofline hooks of carca_forward): the launch binds them to
 // its own dispatch packet (hipExtLaunchKernel), so elapsed(start, stop) is the kernel's duration and no barrier packet
 // is queued around it (an hipEventRecord is one: ~6 us of GPU time between two kernels each).
-// True while `stream` is being captured into a hipGraph.  Launch helpers that hand a kernel memory of the library's own
-// (descriptor rings, row tables) then give it storage that is never recycled instead of an event-guarded ring slot: a
-// replay runs without the host code that would refill the slot, and an event recorded during capture cannot be waited on.
+// True while `stream` is being captured into a hipGraph.
 bool carca_stream_capturing(hipStream_t stream);
-// hipMalloc / hipHostMalloc(mapped) that are legal inside a capture (thread capture mode relaxed around the call);
-// the memory lives as long as the process (a few hundred KB per captured step)
-void* carca_capture_alloc(size_t bytes, bool host_mapped, void** device_view, size_t zero_bytes = 0);  // (zero_bytes: cleared once, now -- not a node of the graph)
+// Memory the library hands its own kernels (partial-tile buffers, row tables, flags) -- two owners, no host wait in either:
+//  * eager launches: carca_stream_scratch, ONE buffer per (device, stream, tag), grown on demand.  Its users are ordered by
+//    the stream itself (a launch that reads the buffer has finished before the next launch on that stream starts), so
+//    there is no event and no ring; an outgrown buffer is freed once its stream has drained.  zero_bytes: cleared on
+//    `stream` when the buffer is (re)allocated (state the kernels keep clean themselves); *fresh tells that it was.
+//  * launches on a stream that is being CAPTURED: carca_capture_alloc, memory that belongs to the capture in progress
+//    (a replay runs without the host code that would pick a buffer, and captures may replay side by side).  It is
+//    accounted to the capture's id (carca_capture_scope) and freed by carca_capture_release once the graph is gone.
+void* carca_stream_scratch(hipStream_t stream, int tag, size_t bytes, size_t zero_bytes = 0, bool* fresh = nullptr);
+enum { CARCA_SCRATCH_SK = 1, CARCA_SCRATCH_WPART = 2, CARCA_SCRATCH_WTAB = 3 };
+void* carca_capture_alloc(hipStream_t stream, size_t bytes, bool host_mapped, void** device_view, size_t zero_bytes = 0);
 void carca_arm_launch_events(void* start, void* stop);
 bool carca_take_launch_events(hipEvent_t* start, hipEvent_t* stop);  // true (and disarms) when armed
 struct CarcaGemmDesc;

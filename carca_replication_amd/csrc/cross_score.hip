@@ -938,9 +938,9 @@ extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t*
     fa.cu = w->cu; fa.ffn_w = w->ffn_w; fa.ffn_b = w->ffn_b;
     fa.qscale = (float)(1.4426950408889634 / sqrt((double)(d / H)));
     fa.stamps = carca_debug_buffer();
-    fa.dbg = carca_tuning(5);
+    fa.dbg = carca_tuning(CARCA_TUNE_DIAG);
     fa.B = B;
-    fa.opt = carca_tuning(3);
+    fa.opt = carca_tuning(CARCA_TUNE_XS_OPT);
     // Persistent workgroups that pipeline their units of work (cross_stream.hip): every batch size where they are not
     // slower -- tuning key 7: 2 = never, 3 = at every batch size, 0 = above #CUs users.  It has no p_normed output and
     // no instantiation above d = 96: the per-user kernel below then runs.

@@ -24,6 +24,7 @@
 #include <hip/hip_ext.h>
 #include "carca_common.h"
 #include <type_traits>
+#include <vector>
 #include "../../include/carca_hip.h"
 
 namespace {
@@ -42,6 +43,8 @@ struct GemmDev {
   float* sk_part;
   int* sk_flag;
   int* sk_err;  // host-visible word: a taker's bounded wait expired
+  unsigned sk_spin;  // the bound: sleeps of ~0.4 us a taker spends on one flag before it gives up (launcher: 2^23, ~5 s)
+  int sk_withhold;   // TEST ONLY (tuning key 13): 1 + index of the one flag its giver does not raise; 0 = none
 };
 
 // The epilogue of the row GEMMs: D row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col = lane & 31 of each 32-column tile.
@@ -814,28 +817,37 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         __hip_atomic_store(&part[(tn * 16 + r) * NT + tid], acc[tn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the hand-over is MI355X_MICROARCH.md's "drained sc1" form: every byte of the partial leaves through an agent-scope
+    // (sc1, write-through) store, every storing wave drains its stores, the workgroup meets, THEN one lane raises the flag)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && (int)(flag - args.sk_flag) + 1 != args.sk_withhold)
+      __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   if constexpr (MODE == SK_TAKE) {
     if (tid == 0) {
       // (the giver is resident -- one round of workgroups -- and ends before its takers by the launcher's balance: the wait
-      // is a few us.  It is BOUNDED all the same, ~5 s: a taker that gives up says so in the library's host-visible error
-      // word and the next launch fails loudly (launch_gemm_rows_sk) instead of the GPU hanging)
+      // is a few us.  It is BOUNDED all the same, args.sk_spin sleeps (~5 s by default): a taker that gives up says so in
+      // the library's host-visible error word -- carca_poll_errors and the next launch fail loudly (launch_gemm_rows_sk)
+      // instead of the GPU hanging.  tests/test_hip_stream_k.py runs that path with a withheld flag and a short bound)
       unsigned spins = 0;
       while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         __builtin_amdgcn_s_sleep(16);
-        if (++spins == (1u << 23)) {
+        if (++spins >= args.sk_spin) {
           if (args.sk_err) __hip_atomic_store(args.sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
       }
       __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ready for the next launch)
+      // ONE relaxed poll -> ONE agent-scope acquire -> its completion -> the workgroup's barrier -> plain loads: the
+      // acquire (buffer_inv sc1) drops whatever this CU's L1 holds of the partial's lines -- the previous launch or the
+      // previous replay of a hipGraph read the same addresses -- and the giver's sc1 stores reached memory past its own
+      // XCD's L2 before the flag did.  ~1.7 us, once per taker, under the 12-wave epilogue that follows.
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    // (plain loads: this XCD has not touched these lines since the kernel began -- a launch starts with an invalidated L2)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -1428,16 +1440,23 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream, co
 }
 
 // gemm_rows_sk_kernel's launch (see the kernel): returns 1 when the product is not its shape -- the caller then launches
-// gemm_rows_cu_kernel<0, 3>.  The partial tiles and flags live in a two-slot ring of the library's own (a slot is reused
-// behind the event of its last launch; inside a hipGraph capture the graph gets storage of its own).
-constexpr int SK_RING = 2;
-float* g_sk_buf[SK_RING] = {nullptr};
-size_t g_sk_bytes[SK_RING] = {0};
-hipEvent_t g_sk_ev[SK_RING];
-bool g_sk_used[SK_RING] = {false}, g_sk_init = false;
-int g_sk_next = 0;
-int* g_sk_err_host = nullptr;  // mapped host memory: written by a taker whose wait expired, read here before every launch
-int* g_sk_err_dev = nullptr;
+// gemm_rows_cu_kernel<0, 3>.  The partial tiles and flags are stream scratch (carca_common.h: one buffer per stream, its
+// launches ordered by the stream -- no ring, no event, no host wait); inside a hipGraph capture they belong to the capture.
+int* g_sk_err_host = nullptr;  // mapped host memory: written by a taker whose wait expired; read before every launch and by
+int* g_sk_err_dev = nullptr;   // carca_poll_errors
+
+// A kernel's failure that no launch status can carry (today: a stream-K taker that gave up waiting): CARCA_OK, or
+// CARCA_ERR_UNSUPPORTED with the message set -- the word is cleared by the call that reports it.
+static int sk_check_error_word() {
+  if (g_sk_err_host && *(volatile int*)g_sk_err_host != 0) {
+    *(volatile int*)g_sk_err_host = 0;
+    carca_set_error("gemm_rows: an EARLIER stream-K launch gave up waiting for a partial tile (its output is wrong): "
+                    "were its workgroups not all resident?  carca_set_tuning(0, 15) selects the kernel without the hand-over");
+    return CARCA_ERR_UNSUPPORTED;
+  }
+  return CARCA_OK;
+}
+extern "C" int carca_poll_errors(void) { return sk_check_error_word(); }
 
 static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, const CarcaGatherArgs* pas, int* rode) {
   const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
@@ -1466,10 +1485,10 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   // balance: owner (nfast - don + ntail) steps of a full tile; giver its own (nfast + ntail) steps at c of a full step (two
   // MFMA column tiles of three + the VALU columns: 0.74 measured) + nfull x (don + p) of them, p = 1.5 steps of pipeline fill
   // per partial tile -- and it must END first (the last owner waits for its partial).  C2: 6 (tools/sk_sweep.py: 4 / 5 / 6 /
-  // 7 / 8 steps 526 / 522 / 520 / 532 / 548 us).  Tuning key 4 overrides don.
+  // 7 / 8 steps 526 / 522 / 520 / 532 / 548 us).  Tuning key 11 overrides don.
   const double c = (2.0 + 0.08 * xc) / 3.0;
   int don = (int)(((1.0 - c) * (nfast + ntail) - 1.5 * nfull) / ncb);
-  if (carca_tuning(4) > 0) don = carca_tuning(4);
+  if (carca_tuning(CARCA_TUNE_SK_DON) > 0) don = carca_tuning(CARCA_TUNE_SK_DON);
   if (don < 1 || don >= nfast) return 1;
   g.sk_don = don;
   // The item-row gather does NOT ride in this launch (rode stays 0: the caller launches it, 8 us): the lone passenger
@@ -1483,38 +1502,22 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
     *g_sk_err_host = 0;
     if (hipHostGetDevicePointer((void**)&g_sk_err_dev, g_sk_err_host, 0) != hipSuccess) g_sk_err_dev = nullptr;
   }
-  if (*(volatile int*)g_sk_err_host != 0) {
-    *(volatile int*)g_sk_err_host = 0;
-    carca_set_error("gemm_rows: an EARLIER stream-K launch gave up waiting for a partial tile (its output is wrong): "
-                    "were its workgroups not all resident?  carca_set_tuning(0, 15) selects the kernel without the hand-over");
-    return CARCA_ERR_UNSUPPORTED;
-  }
+  if (int rc = sk_check_error_word()) return rc;
   g.sk_err = g_sk_err_dev;
-  const size_t n_part = (size_t)rb * nfull, flag_bytes = (n_part * sizeof(int) + 255) / 256 * 256;
-  const size_t bytes = flag_bytes + n_part * 384 * 96 * sizeof(float);
-  int slot = -1;
-  char* buf;
-  if (carca_stream_capturing(stream)) {
-    buf = (char*)carca_capture_alloc(bytes, false, nullptr, flag_bytes);  // (flags zero from here on: every taker resets its own)
-    if (!buf) return (int)hipErrorOutOfMemory;
-  } else {
-    if (!g_sk_init) {
-      for (int i = 0; i < SK_RING; ++i) (void)hipEventCreateWithFlags(&g_sk_ev[i], hipEventDisableTiming);
-      g_sk_init = true;
-    }
-    slot = g_sk_next;
-    g_sk_next = (g_sk_next + 1) % SK_RING;
-    if (g_sk_used[slot]) (void)hipEventSynchronize(g_sk_ev[slot]);
-    if (bytes > g_sk_bytes[slot]) {
-      if (g_sk_buf[slot]) (void)hipFree(g_sk_buf[slot]);
-      g_sk_buf[slot] = nullptr;
-      g_sk_bytes[slot] = 0;
-      if (hipMalloc((void**)&g_sk_buf[slot], bytes) != hipSuccess) return 1;
-      g_sk_bytes[slot] = bytes;
-      (void)hipMemset(g_sk_buf[slot], 0, flag_bytes);  // (the flags: zero between launches from here on -- every taker resets its own)
-    }
-    buf = (char*)g_sk_buf[slot];
+  {
+    const int lg = carca_tuning(CARCA_TUNE_SK_SPIN_LOG2);
+    g.sk_spin = 1u << (lg > 0 && lg < 31 ? lg : 23);
+    g.sk_withhold = carca_tuning(CARCA_TUNE_SK_WITHHOLD);
   }
+  // (a FIXED flag area in front: one buffer serves every shape launched on its stream, and what was cleared when it was
+  // allocated must cover the flags of all of them -- one per partial tile, at most one workgroup per CU gives)
+  const size_t n_part = (size_t)rb * nfull, flag_bytes = 4096;
+  if (n_part * sizeof(int) > flag_bytes) return 1;
+  const size_t bytes = flag_bytes + n_part * 384 * 96 * sizeof(float);
+  // (the flags are cleared when the buffer is allocated and are zero between launches from then on: every taker resets its own)
+  char* buf = (char*)(carca_stream_capturing(stream) ? carca_capture_alloc(stream, bytes, false, nullptr, flag_bytes)
+                                                     : carca_stream_scratch(stream, CARCA_SCRATCH_SK, bytes, flag_bytes));
+  if (!buf) return (int)hipErrorOutOfMemory;
   g.sk_flag = (int*)buf;
   g.sk_part = (float*)(buf + flag_bytes);
   hipEvent_t e0, e1;
@@ -1525,10 +1528,6 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   } else {
     if (ev) hipExtLaunchKernelGGL((gemm_rows_sk_kernel<2>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
     else hipLaunchKernelGGL((gemm_rows_sk_kernel<2>), dim3(grid), dim3(768), 0, stream, g);
-  }
-  if (slot >= 0) {
-    (void)hipEventRecord(g_sk_ev[slot], stream);
-    g_sk_used[slot] = true;
   }
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
@@ -1546,7 +1545,7 @@ static int launch_gemm_rows_n96(const CarcaGemmDesc* desc, hipStream_t stream) {
   g.rb_start[desc->nseg] = rb;
   g.nrb = rb;
   g.ncb = 1;
-  g.diag = carca_tuning(5);
+  g.diag = carca_tuning(CARCA_TUNE_DIAG);
   constexpr size_t lds_bytes = sizeof(float) * 2 * (n96::A_BUF + n96::B_BUF);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1804,41 +1803,14 @@ static int wgrad_prepare(const CarcaWgradDesc* desc, WgradDev& g, bool* fits_out
   return tiles * g.nsplit;
 }
 
-// Partial tiles of the row splits (WgradDev.part): a four-slot ring of the library's own, a slot reused behind the event of
-// its last reduce launch; inside a hipGraph capture the graph gets storage of its own.  Tuning variant 19 = atomics (A/B).
+// Partial tiles of the row splits (WgradDev.part): stream scratch (carca_common.h) -- the product's kernel writes them, its
+// reduce launch reads them, the next product on the stream is ordered behind both; inside a hipGraph capture the capture
+// gets storage of its own.  Tuning variant 19 = atomics (A/B).
 namespace {
-constexpr int WPART_RING = 4;
-float* g_wpart[WPART_RING] = {nullptr};
-size_t g_wpart_floats[WPART_RING] = {0};
-hipEvent_t g_wpart_ev[WPART_RING];
-bool g_wpart_used[WPART_RING] = {false}, g_wpart_init = false;
-int g_wpart_next = 0;
-float* wpart_take(size_t floats, hipStream_t stream, int* slot) {
-  *slot = -1;
+float* wpart_take(size_t floats, hipStream_t stream) {
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 19 || carca_tuning(3) != 0) return nullptr;
-  if (carca_stream_capturing(stream)) return (float*)carca_capture_alloc(floats * sizeof(float), false, nullptr);
-  if (!g_wpart_init) {
-    for (int i = 0; i < WPART_RING; ++i) (void)hipEventCreateWithFlags(&g_wpart_ev[i], hipEventDisableTiming);
-    g_wpart_init = true;
-  }
-  const int s = g_wpart_next;
-  g_wpart_next = (g_wpart_next + 1) % WPART_RING;
-  if (g_wpart_used[s]) (void)hipEventSynchronize(g_wpart_ev[s]);
-  if (floats > g_wpart_floats[s]) {
-    if (g_wpart[s]) (void)hipFree(g_wpart[s]);
-    g_wpart[s] = nullptr;
-    g_wpart_floats[s] = 0;
-    if (hipMalloc((void**)&g_wpart[s], (floats + floats / 8) * sizeof(float)) != hipSuccess) return nullptr;
-    g_wpart_floats[s] = floats + floats / 8;
-  }
-  *slot = s;
-  return g_wpart[s];
-}
-void wpart_done(int slot, hipStream_t stream) {
-  if (slot >= 0) {
-    (void)hipEventRecord(g_wpart_ev[slot], stream);
-    g_wpart_used[slot] = true;
-  }
+  if (carca_stream_capturing(stream)) return (float*)carca_capture_alloc(stream, floats * sizeof(float), false, nullptr);
+  return (float*)carca_stream_scratch(stream, CARCA_SCRATCH_WPART, floats * sizeof(float));
 }
 }  // namespace
 
@@ -1855,32 +1827,44 @@ extern "C" int carca_gemm_wgrad(const CarcaWgradDesc* desc, void* stream_) {
   WgradDev g;
   bool fits = false;
   const int grid = wgrad_prepare(desc, g, &fits);
-  int pslot = -1;
   const int tiles = g.nnb * g.nkb;
-  if (g.nsplit > 1) g.part = wpart_take((size_t)g.nsplit * tiles * BNO * BKO, stream, &pslot);  // (one split: nothing to combine)
+  if (g.nsplit > 1) g.part = wpart_take((size_t)g.nsplit * tiles * BNO * BKO, stream);  // (one split: nothing to combine)
   if (fits)
     hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR, true>), dim3(grid), dim3(256), 0, stream, g);
   else
     hipLaunchKernelGGL((gemm_wgrad_kernel<BNO, BKO, BR>), dim3(grid), dim3(256), 0, stream, g);
-  if (g.part) {
-    hipLaunchKernelGGL(wgrad_part_reduce_kernel, dim3(tiles * 12), dim3(256), 0, stream, g);
-    wpart_done(pslot, stream);
-  }
+  if (g.part) hipLaunchKernelGGL(wgrad_part_reduce_kernel, dim3(tiles * 12), dim3(256), 0, stream, g);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
 
-// Grouped launch: the kernel reads its descriptors from a pinned, device-mapped host ring (one slot per launch, guarded
-// by an event); products that are big enough for the persistent kernel, or whose offsets do not fit the buffer-load
-// path, are issued one by one instead.
+// Grouped launch: the kernel reads its descriptors from pinned, device-mapped host memory that THIS thread writes, so a
+// slot may only be rewritten once the launch that reads it has finished: every slot carries an event recorded behind its
+// launch, and a launch takes the first slot whose event has completed (hipEventQuery -- the host never waits; while none
+// has, the pool grows: its size follows the number of launches in flight).  Products that are big enough for the
+// persistent kernel, or whose offsets do not fit the buffer-load path, are issued one by one instead.
 namespace {
-constexpr int GROUP_RING = 16;
-WgradDev* g_group_host = nullptr;  // [GROUP_RING][WGRAD_GROUP_MAX] pinned, mapped into the device's address space
-WgradDev* g_group_dev = nullptr;   // the device's view of the same memory (no copy command: a small async H2D copy
-                                   // turned out to stall the issuing thread until the stream had drained)
-hipEvent_t g_group_ev[GROUP_RING];
-bool g_group_used[GROUP_RING] = {false};
-int g_group_next = 0;
+struct GroupSlot {
+  WgradDev* host;  // [WGRAD_GROUP_MAX] pinned, mapped into the device's address space (no copy command: a small async H2D
+  WgradDev* dev;   // copy turned out to stall the issuing thread until the stream had drained)
+  hipEvent_t ev;
+  bool used;
+};
+std::vector<GroupSlot> g_group_slots;
+int group_slot_take() {
+  int found = -1;
+  for (size_t i = 0; i < g_group_slots.size() && found < 0; ++i)
+    if (!g_group_slots[i].used || hipEventQuery(g_group_slots[i].ev) == hipSuccess) found = (int)i;
+  (void)hipGetLastError();  // (a query of a pending event leaves hipErrorNotReady behind: not the next launch's error)
+  if (found >= 0) return found;
+  GroupSlot sl{};
+  if (hipHostMalloc((void**)&sl.host, sizeof(WgradDev) * WGRAD_GROUP_MAX, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&sl.dev, sl.host, 0) != hipSuccess ||
+      hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess)
+    return -1;
+  g_group_slots.push_back(sl);
+  return (int)g_group_slots.size() - 1;
+}
 }  // namespace
 
 extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* stream_) {
@@ -1888,15 +1872,6 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
   CARCA_CHECK_ARG(descs && n >= 1, "gemm_wgrad_group: no products");
   for (int i = 0; i < n; ++i)
     if (int rc = wgrad_check(&descs[i])) return rc;
-  if (!g_group_host) {
-    if (hipHostMalloc(&g_group_host, sizeof(WgradDev) * GROUP_RING * WGRAD_GROUP_MAX, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&g_group_dev, g_group_host, 0) != hipSuccess) {
-      g_group_host = nullptr;
-      carca_set_error("gemm_wgrad_group: cannot allocate the descriptor ring");
-      return CARCA_ERR_BADARG;
-    }
-    for (int i = 0; i < GROUP_RING; ++i) (void)hipEventCreateWithFlags(&g_group_ev[i], hipEventDisableTiming);
-  }
   constexpr int BNO = 96, BKO = 128, BR = 32;
   const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
   int done = 0;
@@ -1905,14 +1880,16 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
     int slot = -1;
     WgradDev *host, *dev;
     if (capturing) {
-      host = (WgradDev*)carca_capture_alloc(sizeof(WgradDev) * WGRAD_GROUP_MAX, true, (void**)&dev);
+      host = (WgradDev*)carca_capture_alloc(stream, sizeof(WgradDev) * WGRAD_GROUP_MAX, true, (void**)&dev);
       if (!host) return CARCA_ERR_BADARG;
     } else {
-      slot = g_group_next;
-      g_group_next = (g_group_next + 1) % GROUP_RING;
-      if (g_group_used[slot]) (void)hipEventSynchronize(g_group_ev[slot]);  // normally long complete
-      host = g_group_host + (size_t)slot * WGRAD_GROUP_MAX;
-      dev = g_group_dev + (size_t)slot * WGRAD_GROUP_MAX;
+      slot = group_slot_take();
+      if (slot < 0) {
+        carca_set_error("gemm_wgrad_group: cannot allocate a descriptor slot");
+        return CARCA_ERR_BADARG;
+      }
+      host = g_group_slots[slot].host;
+      dev = g_group_slots[slot].dev;
     }
     WgradGroupIndex idx{}, ridx{};
     int blocks = 0, rblocks = 0;
@@ -1948,8 +1925,7 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
     idx.block_start[idx.n] = blocks;
     ridx.n = idx.n;
     ridx.block_start[idx.n] = rblocks;
-    int pslot = -1;
-    float* part = wpart_take(part_floats, stream, &pslot);
+    float* part = wpart_take(part_floats, stream);
     if (part) {  // every product its own stretch of the slot
       size_t at = 0;
       for (int i = 0; i < idx.n; ++i) {
@@ -1958,13 +1934,10 @@ extern "C" int carca_gemm_wgrad_group(const CarcaWgradDesc* descs, int n, void* 
       }
     }
     hipLaunchKernelGGL((gemm_wgrad_group_kernel<BNO, BKO, BR>), dim3(blocks), dim3(256), 0, stream, dev, idx);
-    if (part) {
-      hipLaunchKernelGGL(wgrad_part_reduce_group_kernel, dim3(rblocks), dim3(256), 0, stream, dev, ridx);
-      wpart_done(pslot, stream);
-    }
+    if (part) hipLaunchKernelGGL(wgrad_part_reduce_group_kernel, dim3(rblocks), dim3(256), 0, stream, dev, ridx);
     if (slot >= 0) {
-      (void)hipEventRecord(g_group_ev[slot], stream);
-      g_group_used[slot] = true;
+      (void)hipEventRecord(g_group_slots[slot].ev, stream);
+      g_group_slots[slot].used = true;
     }
     CARCA_LAUNCH_CHECK();
   }

@@ -444,15 +444,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradCuDev args
   }
 }
 
-// Lazily grown device workspaces for the row tables: a small ring, one slot per launch, each guarded by an event
-// recorded behind its consumer -- consecutive launches never share a table, whatever streams they are issued on.
-constexpr int TAB_RING = 4;
-unsigned* g_tab[TAB_RING] = {nullptr};
-size_t g_tab_elems[TAB_RING] = {0};
-hipEvent_t g_tab_ev[TAB_RING];
-bool g_tab_used[TAB_RING] = {false};
-bool g_tab_init = false;
-int g_tab_next = 0;
+// The row table, the group ranges and the partial tiles of a launch are stream scratch (carca_common.h): written by this
+// launch's first kernel, read by its second and third, the next launch on the stream ordered behind all three.
 int g_num_cus = 0;
 
 }  // namespace
@@ -548,32 +541,10 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 14 || n_parts > 8 * n_tiles) g.slots_pg = 0;
   const size_t part_floats = (size_t)g.ngroups * g.slots_pg * g.nnb * WG_BN * WG_BK;
   const size_t cnt_ints = ((size_t)2 * (g.ngroups + 1) + 2 * g.nkb + 5) / 4 * 4;  // gbegin (8-byte entries) | klo
-  if (!g_tab_init) {
-    for (int i = 0; i < TAB_RING; ++i) (void)hipEventCreateWithFlags(&g_tab_ev[i], hipEventDisableTiming);
-    g_tab_init = true;
-  }
-  int slot = -1;
-  unsigned* tab;
-  if (carca_stream_capturing(stream)) {  // hipGraph capture: a table of the graph's own, no ring slot, no guard event
-    tab = (unsigned*)carca_capture_alloc(((size_t)3 * g.V + cnt_ints) * sizeof(unsigned) + part_floats * sizeof(float),
-                                         false, nullptr);
-    if (!tab) return 1;
-  } else {
-    slot = g_tab_next;
-    g_tab_next = (g_tab_next + 1) % TAB_RING;
-    if (g_tab_used[slot]) (void)hipEventSynchronize(g_tab_ev[slot]);  // its last consumer: normally long finished
-    const size_t need = (size_t)3 * g.V + cnt_ints + part_floats;  // row table | group ranges | partial tiles
-    if (need > g_tab_elems[slot]) {
-      if (g_tab[slot]) (void)hipFree(g_tab[slot]);
-      g_tab[slot] = nullptr;
-      g_tab_elems[slot] = need + need / 8;
-      if (hipMalloc(&g_tab[slot], g_tab_elems[slot] * sizeof(unsigned)) != hipSuccess) {
-        g_tab_elems[slot] = 0;
-        return 1;
-      }
-    }
-    tab = g_tab[slot];
-  }
+  const size_t tab_bytes = ((size_t)3 * g.V + cnt_ints) * sizeof(unsigned) + part_floats * sizeof(float);  // row table | group ranges | partial tiles
+  unsigned* tab = (unsigned*)(carca_stream_capturing(stream) ? carca_capture_alloc(stream, tab_bytes, false, nullptr)
+                                                              : carca_stream_scratch(stream, CARCA_SCRATCH_WTAB, tab_bytes));
+  if (!tab) return 1;
   g.tab = tab;
   {
     unsigned* aux = tab + (size_t)3 * g.V;  // (V is a multiple of 32 and the buffer comes from hipMalloc: 16-byte aligned)
@@ -590,10 +561,6 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_wgrad_cu_kernel<0>, dim3(grid), dim3(WG_NT), 0, stream, g);
   if (g.slots_pg > 0)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g.nkb * g.nnb, WG_BN * WG_BK / 1024), dim3(256), 0, stream, g);
-  if (slot >= 0) {
-    (void)hipEventRecord(g_tab_ev[slot], stream);
-    g_tab_used[slot] = true;
-  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     carca_set_error("HIP launch failed: %s", hipGetErrorString(e));

@@ -45,7 +45,13 @@ def _row_exchange_len(p_x, o_x, global_batch: Optional[int]) -> Optional[int]:
     if global_batch is None:
         return None
     world = max(cdist.world_size(), 1)
-    return -(-int(global_batch) // world) * (p_x.shape[1] + o_x.shape[1])
+    per_rank = -(-int(global_batch) // world)
+    if p_x.shape[0] > per_rank:
+        # (checked on the host BEFORE the step's first collective: a rank that found this out inside the row exchange
+        # would raise alone while the others wait in all_gather until the backend's timeout)
+        raise ValueError(f"this rank holds {p_x.shape[0]} users but global_batch={global_batch} over {world} ranks allows "
+                         f"at most {per_rank} per rank (dist.shard_range)")
+    return per_rank * (p_x.shape[1] + o_x.shape[1])
 
 
 def train_step(model, optim, batch, sharded: bool = False, global_batch: Optional[int] = None) -> torch.Tensor:
@@ -67,6 +73,7 @@ def train_step(model, optim, batch, sharded: bool = False, global_batch: Optiona
         # summed over ranks, in place in the backward's flat buffer -- the early range started under the backward's last
         # kernel: an event recorded right before that launch (CarcaEmbedBwdDesc.ev_early) gates a side stream, RCCL's
         # own stream queues behind the side stream, and the call returns to issue the late range behind the kernel.
+        _row_exchange_len(p_x, o_x, global_batch)  # (validates global_batch ahead of the step's first collective)
         denom = cdist.global_mask_count(o_x)
         # (deterministic mode: the early range's sums sit in the fixed-point shadow until the pass ends -- no early start)
         ev = _early_event() if p_x.is_cuda and not ops.deterministic() else None
@@ -207,10 +214,15 @@ class GraphedTrainStep:
                     _forward_backward(model, optim, self.inputs, self.denom)
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
+            self.scope = 0
             with torch.cuda.graph(self.graph):
+                # (what the library allocates for the captured kernels -- partial tiles, row tables, descriptor copies:
+                # ~170-200 MB at C2 -- belongs to this capture and is handed back by close())
+                self.scope = ops.capture_scope()
                 if has_dropout:
                     self.replays.add_(1)
                 self.loss = _forward_backward(model, optim, self.inputs, self.denom)
+            self.library_bytes = ops.capture_bytes(self.scope)
         finally:
             ops.set_dropout_seed_offset(None)
         # The replayed backward writes into the gradient tensors of the capture.  An eager step in between (train() sends
@@ -222,7 +234,23 @@ class GraphedTrainStep:
         # keep it alive even if an eager step of another shape replaces the model's current one)
         self._grad_cache = model.__dict__.get("_grad_cache")
 
+    def close(self) -> None:
+        """Destroys the graph and frees the library memory its kernels were given (idempotent).  Replays still in flight
+        are waited for first: the graph's kernels read that memory."""
+        if getattr(self, "graph", None) is not None:
+            torch.cuda.synchronize()
+            self.graph = None
+            ops.capture_release(self.scope)
+            self.scope = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def __call__(self, batch) -> torch.Tensor:
+        ops.poll_errors()  # (a kernel-side failure of an EARLIER replay that no launch status carries; one host read)
         for dst, src in zip(self.inputs, as_batch7(batch)):
             if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)

@@ -1173,3 +1173,39 @@ def set_tuning(key: int, value: int) -> None:
 
 def num_cus() -> int:
     return torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+
+
+def poll_errors() -> None:
+    """carca_poll_errors: raises CarcaHipError if a kernel of an earlier launch reported a failure that no launch status
+    could carry (a stream-K taker of the feature GEMM that gave up waiting for its partial tile).  One read of host
+    memory; meaningful wherever the host has synchronised with the device anyway."""
+    _lib.check(_lib.load().carca_poll_errors(), "poll_errors")
+
+
+def capture_scope() -> int:
+    """Id of the hipGraph capture in progress on the current stream (0 = not capturing); memory the library allocates for
+    captured kernels is accounted to it (capture_bytes) and freed by capture_release(id) once the graph is destroyed."""
+    out = C.c_ulonglong(0)
+    _lib.check(_lib.load().carca_capture_scope(_stream(), C.byref(out)), "capture_scope")
+    return int(out.value)
+
+
+def capture_bytes(scope: int) -> int:
+    return int(_lib.load().carca_capture_bytes(C.c_ulonglong(scope)))
+
+
+def capture_release(scope: int) -> None:
+    if scope:
+        _lib.check(_lib.load().carca_capture_release(C.c_ulonglong(scope)), "capture_release")
+
+
+# feature-GEMM precision (include/carca_hip.h, tuning key 16): opt-in split-precision products on the 16-bit MFMA pipe
+TUNE_SPLIT_GEMM = 16
+SPLIT_GEMM_MODES = {"fp32": 0, "bf16x3": 1, "fp16x2": 2}
+
+
+def set_feature_gemm_precision(mode: str) -> None:
+    """'fp32' (default): exact-fp32 MFMA.  'bf16x3': both operands split into three bf16 parts, six products, fp32
+    accumulation.  'fp16x2': two fp16 parts, three products (|operands| < 65504).  Applies to AllEmbedding.feats_embed
+    (carca.py:86) where the one-workgroup-per-CU kernel runs; every other product keeps the fp32 kernels."""
+    set_tuning(TUNE_SPLIT_GEMM, SPLIT_GEMM_MODES[mode])

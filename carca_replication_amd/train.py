@@ -96,24 +96,28 @@ def evaluate(model: Model, loader: DataLoader, device: str, k: int) -> Tuple[flo
             engine.eval_batch(model, to(*engine.as_batch7(batch), device=device), k=k, sums=sums)
             n_batches += 1
     hr, ndcg, _ties, loss_sum, users = (float(v) for v in sums.cpu())
+    if torch.device(device).type == "cuda":
+        ops.poll_errors()  # (the epoch's only host sync just happened: a kernel-side failure of any batch surfaces here)
     return hr / users, ndcg / users, loss_sum / max(n_batches, 1)
 
 
 def train(model: Model, train_loader: DataLoader, val_loader: DataLoader, test_loader: DataLoader, device: str,
           optim: Optimizer, epochs: int, top_k: int = 10, verbose: int = 1, early_stop: int = 10,
           datadir: str = "model", scheduler: Union[_LRScheduler, None] = None, graphed: bool = False,
-          resume: Union[str, None] = None) -> Model:
+          resume: Union[str, None] = None, resume_trusted: bool = False) -> Model:
     """src/train.py:56-152.  Extensions, off by default:
     graphed: batches of the first batch's shape replay their forward + backward from one hipGraph
       (engine.GraphedTrainStep); any other shape (a short last batch) takes the eager step;
     resume: path of a checkpoint written by an earlier run (save_checkpoint): model, optimizer and scheduler state are
-      restored and the epoch count continues after the stored one, with the stored best NDCG as the bar to beat."""
+      restored and the epoch count continues after the stored one, with the stored best NDCG as the bar to beat;
+    resume_trusted: the file named by `resume` may be a whole-module pickle as the reference writes them (train.py:124):
+      load_checkpoint(allow_pickle=True) -- unpickling executes code from the file, so only for files the caller trusts."""
     os.makedirs(datadir, exist_ok=True)
     model = model.train().to(device)
     best, stale, first_epoch = 0.0, 0, 1
     best_path = None  # the checkpoint holding the best weights so far: a resumed run starts with the one it resumes from
     if resume is not None:
-        meta = load_checkpoint(resume, model, optim, scheduler, device=device)
+        meta = load_checkpoint(resume, model, optim, scheduler, device=device, allow_pickle=resume_trusted)
         best, first_epoch = float(meta.get("NDCG", 0.0)), int(meta.get("epoch", 0)) + 1
         stale, best_path = int(meta.get("stale", 0)), resume
     t0 = datetime.now()

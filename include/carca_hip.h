@@ -11,9 +11,11 @@
  *  - every pointer is a DEVICE pointer to fp32 (ids: int32) unless it says "host";
  *  - tensors are row-major; `ld*` is a row stride in elements; activation strides must be
  *    multiples of 4 elements and bases 16-byte aligned (torch allocations are);
- *  - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, nothing
- *    synchronises, nothing is allocated, nothing is retained after the call returns
- *    (graph-capturable); callers own all memory;
+ *  - `stream` is a hipStream_t passed as void*; launches are asynchronous on it and the host never
+ *    waits for the device; callers own every tensor, nothing of theirs is retained after the call
+ *    returns (graph-capturable).  What a launch needs beyond its arguments (partial tiles of a split
+ *    product, row tables) is the library's own: one lazily grown scratch buffer per stream, reused
+ *    in stream order, or memory owned by the capture (carca_capture_scope below);
  *  - return 0 on success, a negative CARCA_ERR_* for a rejected call (message from
  *    carca_last_error()), a positive hipError_t for a failed launch.  Never aborts.
  */
@@ -47,9 +49,11 @@ int carca_abi_version(void);
  *          feature GEMM's launch
  *   key 1  attention kernels: 1 one workgroup per user, 2 always two, 3 one 8-wave workgroup per user (the variant
  *          for batches of more users than CUs, two workgroups resident per CU)
- *   key 2  weight gradient: row-split slot target      key 4  minimum 32-row chunks per split
+ *   key 2  weight gradient: row-split slot target      key 4  weight gradient: minimum 32-row chunks per split
  *   key 3  weight gradient: plain stores instead of atomics (timing diagnostic, wrong results)
  *   key 5  grouped weight gradient: row-split slot target per product
+ *   key 6  1: the round-1 paths (materialised V in the scoring kernel, per-op SelfAttentionBlock backward)
+ *   key 7  scoring kernel layout (1 one workgroup per user, 2 fold kernel, 3 persistent stream kernel)
  *   key 8  DETERMINISTIC MODE (1 = on): no fp32 atomics anywhere in the backward pass -- every accumulation into the
  *          pass's gradient buffer (weight gradients, LayerNorm gamma / beta, bias sums, the embedding scatter-add) goes
  *          into a 64-bit fixed-point shadow buffer (carca_det_begin / carca_det_flush below), whose integer sums do not
@@ -59,7 +63,18 @@ int carca_abi_version(void);
  *   key 9  in-kernel phase stamps of the row-chain kernels (1 FFN side, 2 input side; carca_set_debug_buffer)
  *   key 10 CU budget of the one-workgroup-per-CU weight-gradient kernel (0 = every CU): a caller that runs two halves
  *          of a backward pass on two streams gives each launch half the chip (autograd.py: the target rows' embedding
- *          backward beside the profile rows' encoder backward) */
+ *          backward beside the profile rows' encoder backward)
+ *   key 11 feature GEMM with the stream-K hand-over: K steps the cheap workgroup takes over per tile (0 = cost model)
+ *   key 12 ... log2 of the bound on a taker's wait for its partial tile, in ~0.4 us sleeps (0 = 23, about 5 s); on expiry
+ *          the launch's output is wrong, the library's error word is set and carca_poll_errors / the next such launch fail
+ *   key 13 ... TEST ONLY: 1 + index of the one partial tile whose giver withholds its flag (exercises key 12's expiry)
+ *   key 14 persistent scoring kernel: 1 = ticket dealing of a step's first jobs (A/B)
+ *   key 15 timing diagnostics of the 80 x 96 row GEMM and the scoring kernels (bit masks; WRONG results)
+ *   key 16 PRECISION OF THE FEATURE GEMM (AllEmbedding.feats_embed, carca.py:86), opt-in: 0 = exact-fp32 MFMA (default,
+ *          the path every parity figure is quoted on); 1 = operands split into three bf16 parts, six bf16-MFMA products,
+ *          fp32 accumulation (fp32-class accuracy on the 16x faster pipe); 2 = two fp16 parts (the second scaled by
+ *          2^11), three products, two fp32 accumulators -- |operands| < 65504 required.  Only where the one-workgroup-per-CU
+ *          kernel would run; anything else keeps the fp32 kernels. */
 int carca_set_tuning(int key, int value);
 /* Deterministic mode, per backward pass: register the pass's flat fp32 gradient buffer `flat` (n floats) and its shadow
  * (n uint64, ZERO on entry); kernels launched on `stream` afterwards accumulate gradients that land inside `flat` into
@@ -71,6 +86,17 @@ int carca_det_flush(float* flat, unsigned long long* shadow, long long lo, long 
  * s_memtime stamps at their phase boundaries; NULL (default) disables stamping. */
 int carca_set_debug_buffer(void* device_ptr);
 const char* carca_last_error(void); /* host string, thread-local, valid until the next call */
+/* Failures of a kernel that no launch status can carry (today: key 12's expiry).  CARCA_OK, or a negative code with the
+ * message set; the condition is cleared by the call that reports it.  Costs one read of host memory: call it wherever the
+ * host has synchronised anyway (end of an evaluation epoch, after a graph replay's loss was read). */
+int carca_poll_errors(void);
+/* Memory the library allocates for kernels that are CAPTURED into a hipGraph (partial-tile buffers, row tables, descriptor
+ * copies -- what an eager launch takes from a per-stream scratch buffer) belongs to the capture in progress:
+ * carca_capture_scope returns that capture's id while `stream` is capturing (0 otherwise), carca_capture_bytes what has
+ * been allocated under it, and carca_capture_release frees it -- call it once the graph built from the capture is gone. */
+int carca_capture_scope(void* stream, unsigned long long* id_out);
+long long carca_capture_bytes(unsigned long long id);
+int carca_capture_release(unsigned long long id);
 
 /* ------------------------------------------------------------------------------------------
  * Padded geometry shared by every entry point.  For model width d and H heads (dh = d/H):

@@ -17,7 +17,7 @@ lib = _lib.load()
 want = None
 for variant in [int(v) for v in os.environ.get("VARIANTS", "0,9,10,0").split(",")]:
     lib.carca_set_tuning(0, variant % 100)
-    lib.carca_set_tuning(5, variant // 100)  # (variant 100 * diag + v: timing experiments of the 80 x 96 kernel, wrong results)
+    lib.carca_set_tuning(15, variant // 100)  # (variant 100 * diag + v: timing experiments of the 80 x 96 kernel, wrong results)
     with torch.no_grad():
         for _ in range(30):
             y = model(profile=profile, targets=[target])
@@ -33,4 +33,4 @@ for variant in [int(v) for v in os.environ.get("VARIANTS", "0,9,10,0").split(","
     print(f"variant {variant}: joint GEMM avg {1e3 * sum(ms) / len(ms):.2f} us  median {1e3 * ms[len(ms) // 2]:.2f}  min {1e3 * ms[0]:.2f}"
           f"   max |dy| vs variant 0 {float((y - want).abs().max()):.2e}", flush=True)
 lib.carca_set_tuning(0, 0)
-lib.carca_set_tuning(5, 0)
+lib.carca_set_tuning(15, 0)

@@ -51,25 +51,25 @@ def inputs(B, L, Ns, d, dpi, lengths, seed=0):
 def run(x, p_ids, groups, cw, d, H, mode):
     lib.carca_set_tuning(7, {"stream": 3, "ticket": 3, "fold": 2, "mat": 2}[mode])
     lib.carca_set_tuning(6, 1 if mode == "mat" else 0)
-    lib.carca_set_tuning(3, 1 if mode == "ticket" else 0)
+    lib.carca_set_tuning(14, 1 if mode == "ticket" else 0)
     try:
         ys, _ = ops.cross_score_fwd(x, p_ids, groups, cw, d, H, True, False)
     finally:
         lib.carca_set_tuning(7, 0)
         lib.carca_set_tuning(6, 0)
-        lib.carca_set_tuning(3, 0)
+        lib.carca_set_tuning(14, 0)
     return [y.clone() for y in ys]
 
 
 def timed_mode(a, cw, d, H, mode, reps=40):
     """back-to-back launches between two events, the variant switches set once around the whole loop"""
     lib.carca_set_tuning(7, {"stream": 3, "ticket": 3, "fold": 2}[mode])
-    lib.carca_set_tuning(3, 1 if mode == "ticket" else 0)
+    lib.carca_set_tuning(14, 1 if mode == "ticket" else 0)
     try:
         t = timed(lambda: ops.cross_score_fwd(*a, cw, d, H, True, False), reps)
     finally:
         lib.carca_set_tuning(7, 0)
-        lib.carca_set_tuning(3, 0)
+        lib.carca_set_tuning(14, 0)
     return t
 
 
@@ -141,10 +141,10 @@ if os.environ.get("STAMPS"):  # per-wave clocks of one step (tuning key 5 = step
         nwg = min(256, B * (2 if 2 * B <= 256 else 1))
         buf = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
         lib.carca_set_debug_buffer(buf.data_ptr())
-        lib.carca_set_tuning(5, step)
+        lib.carca_set_tuning(15, step)
         run(*a, cw, d, H, "stream")
         torch.cuda.synchronize()
-        lib.carca_set_tuning(5, 0)
+        lib.carca_set_tuning(15, 0)
         lib.carca_set_debug_buffer(None)
         st = buf.view(256, 64)[:nwg].cpu().double()
         opened, arrive, mid = st[:, 0:16], st[:, 16:32], st[:, 32:48]

@@ -39,10 +39,10 @@ lib.carca_set_tuning(0, 15)
 print("plain kernel: median %.1f us, min %.1f" % tuple(1e3 * v for v in run()))
 lib.carca_set_tuning(0, 8)  # (8: the item-row gather in its own launch -- as a passenger workgroup it alone takes ~455 us)
 for don in [int(v) for v in os.environ.get("DONS", "1,2,3,4,5,6,7,8,10").split(",")]:
-    lib.carca_set_tuning(4, don)
+    lib.carca_set_tuning(11, don)
     print("don = %2d: median %.1f us, min %.1f" % ((don,) + tuple(1e3 * v for v in run())))
-lib.carca_set_tuning(4, 0)
+lib.carca_set_tuning(11, 0)
 # (the kernel's timing experiments -- cheap tile alone, takers alone, givers alone: TUNING.md -- were removed from the kernel
 # with their switch: a taker waiting for a partial nobody writes hangs the GPU)
-lib.carca_set_tuning(4, 0)
+lib.carca_set_tuning(11, 0)
 lib.carca_set_tuning(0, 0)
