@@ -279,6 +279,64 @@ def measure_scoring_scaling(c, model, device, batches=(1024, 4096), reps=30):
     return out
 
 
+def measure_split_path(c, model, profile, target, profile_cpu, target_cpu, fence, steps, warmup, world, fl):
+    """Opt-in split-precision feature GEMM (SURVEY 7 hard part 1; csrc/gemm_split.hip): the SAME eval forward with
+    AllEmbedding.feats_embed on the 16-bit MFMA pipe, both operands split into 16-bit parts -- 'bf16x3': three bf16 parts,
+    six products; 'fp16x2': two fp16 parts (the residual scaled by 2^11), three products.  Never the headline `value`.
+    Per scheme: users/s and ms per step by the headline's protocol, the kernel's own duration (events bound to its dispatch),
+    the largest score difference against the default exact-fp32 path on the bench batch, the error of both paths against the
+    CPU oracle run in fp64 on the first 8 users, whether every user's rank of the positive is unchanged, and a roofline entry
+    against the dense 16-bit MFMA peak divided by the products a scheme spends per fp32 product."""
+    import torch
+
+    from carca_replication_amd import ops
+    from oracle import carca_oracle as O
+
+    PEAK_16BIT_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 MFMA, dense
+    with torch.no_grad():
+        y32 = model(profile=profile, targets=[target]).clone()
+        n8 = min(8, c["B"])
+        P64 = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+        cfg = O.CarcaConfig(d=c["d"], H=c["H"], n_blocks=c["n_blocks"])
+        cut = lambda t: tuple(x[:n8].double() if x.is_floating_point() else x[:n8] for x in t)  # noqa: E731
+        y64 = O.carca_forward(P64, cfg, cut(profile_cpu), [cut(target_cpu)], training=False)
+        err32 = float((y32[:n8].cpu().double() - y64).abs().max())
+        out = {"fp32_path_max_abs_err_vs_fp64_oracle": err32, "oracle_users": n8,
+               "note": "opt-in (ops.set_feature_gemm_precision / carca_set_tuning(16, mode)); the headline `value` and every "
+                       "parity figure stay on the exact-fp32 MFMA path"}
+        for mode, passes in (("bf16x3", 6), ("fp16x2", 3)):
+            ops.set_feature_gemm_precision(mode)
+            try:
+                n0 = ops.split_launch_count()
+                y = model(profile=profile, targets=[target]).clone()
+                if ops.split_launch_count() == n0:
+                    out[mode] = {"error": "the launcher did not take the split kernel for this shape"}
+                    continue
+                dt = timed_loop(lambda: model(profile=profile, targets=[target]), steps, warmup, fence)
+                evs = [[ops.HipEvent() for _ in range(2)] for _ in range(24)]
+                for e in evs:
+                    ops.set_fused_events([e[0].handle, e[1].handle] + [None] * 6)
+                    model(profile=profile, targets=[target])
+                    ops.set_fused_events(None)
+                fence()
+                k_ms = sorted(e[0].elapsed_ms(e[1]) for e in evs)
+                k_avg = sum(k_ms) / len(k_ms)
+            finally:
+                ops.set_feature_gemm_precision("fp32")
+            tf = c["B"] * fl["feat"] / (k_avg * 1e-3) / 1e12
+            r32, r = ops.rank_metrics(y32, 10, want_rank=True)[1], ops.rank_metrics(y, 10, want_rank=True)[1]
+            out[mode] = {"passes": passes, "users_per_s": world * c["B"] * steps / dt, "ms_per_step": 1e3 * dt / steps,
+                         "kernel_avg_ms": k_avg, "kernel_min_ms": k_ms[0],
+                         "max_abs_diff_vs_fp32_path": float((y - y32).abs().max()),
+                         "max_abs_err_vs_fp64_oracle": float((y[:n8].cpu().double() - y64).abs().max()),
+                         "ranks_equal": bool(torch.equal(r, r32)),
+                         "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_16BIT_TFLOPS / passes, "unit": "TFLOP/s",
+                                      "frac": tf / (PEAK_16BIT_TFLOPS / passes),
+                                      "note": "algorithmic fp32 flops of the product / kernel time, against the dense 16-bit "
+                                              "MFMA peak (2500 TF) / %d products per fp32 product" % passes}}
+    return out
+
+
 def measure_epoch_pipeline(c, model, device, world, fence, n_batches=256):
     """END-TO-END evaluation epoch of the assembled fast loop: users/s INCLUDING batch construction
     and the metrics.  A synthetic interaction log lives in HBM (device_data.DeviceInteractions: per user a history whose
@@ -366,6 +424,7 @@ def main():
     ap.add_argument("--batch", type=int, default=C2["B"])
     ap.add_argument("--no-fold", action="store_true", help="skip the folded-embedding (composed weights) measurement")
     ap.add_argument("--no-table", action="store_true", help="skip the attribute-table (ids-only batch) measurement")
+    ap.add_argument("--no-split", action="store_true", help="skip the opt-in split-precision feature GEMM measurement")
     ap.add_argument("--train-steps", type=int, default=24, help="extra, untimed-by-the-headline train-step measurement")
     ap.add_argument("--no-scoring-scaling", action="store_true", help="skip the scoring kernel's B = 1024 / 4096 side pass")
     args = ap.parse_args()
@@ -489,6 +548,11 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+
+    split_info = None
+    if not args.no_split and rank == 0:
+        split_info = measure_split_path(c, model, profile, target, profile_cpu, target_cpu, fence if world == 1 else
+                                        torch.cuda.synchronize, args.steps, args.warmup, 1, fl)
 
     # extension path: attribute table resident in HBM, ids-only batches, gather fused into the GEMM
     table_info = epoch_info = None
@@ -644,6 +708,8 @@ def main():
             out["epoch_pipeline"] = epoch_info
         if fold_info is not None:
             out["folded_embedding_path"] = fold_info
+        if split_info is not None:
+            out["split_bf16_path"] = split_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, model, profile_cpu, target_cpu)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -18,8 +18,8 @@ _CSRC = os.path.join(_HERE, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libcarca_hip.so")
 _STAMP = LIB_PATH + ".srchash"
-SOURCES = ["api.hip", "gemm.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "sa_eval.hip", "cross_score.hip", "cross_stream.hip", "loss_metrics.hip", "backward.hip", "block_bwd.hip", "row_chain.hip", "optim.hip"]
-HEADERS = ["carca_common.h", "attn_common.h"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_split.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "sa_eval.hip", "cross_score.hip", "cross_stream.hip", "loss_metrics.hip", "backward.hip", "block_bwd.hip", "row_chain.hip", "optim.hip"]
+HEADERS = ["carca_common.h", "attn_common.h", "gemm_epilogue.h", "cross_fold.h"]
 
 MAX_SEGS = 4
 MAX_GROUPS = 3
@@ -244,6 +244,10 @@ SIGNATURES = {
     "carca_pack_weights": (_i, [C.POINTER(PackDesc), _i, _fp]),
     "carca_embed_fwd": (_i, [C.POINTER(RowSeg), _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     "carca_gemm_rows": (_i, [C.POINTER(GemmDesc), _fp]),
+    "carca_split_bytes": (C.c_longlong, [_i, _i, _i]),
+    "carca_split_pack": (_i, [_fp, _i, _i, _i, _i, _fp, _fp]),
+    "carca_split_bind": (_i, [_fp, _fp, _i, _i, _i]),
+    "carca_split_launch_count": (C.c_longlong, []),
     "carca_gemm_rows_group": (_i, [C.POINTER(GemmDesc), _i, _fp]),
     "carca_gemm_wgrad": (_i, [C.POINTER(WgradDesc), _fp]),
     "carca_gemm_wgrad_group": (_i, [C.POINTER(WgradDesc), _i, _fp]),

@@ -200,6 +200,7 @@ class AllEmbedding(Embedding):
         state = dict(super().__getstate__())
         state.pop("_attr_table", None)
         state.pop("_fold_cache", None)
+        state.pop("_split_cache", None)
         state.pop("_wj_t", None)
         state.pop("_fold_train", None)
         state.pop("_wf_t", None)
@@ -245,8 +246,24 @@ class AllEmbedding(Embedding):
     def _pos(self, T: int) -> Optional[Tensor]:
         return _position_table(self.enc, T)
 
+    def bind_split_weights(self, n_attrs: int) -> None:
+        """Opt-in split-precision feature GEMM (ops.set_feature_gemm_precision): hand the library the packed 16-bit planes
+        of feats_embed.weight[:, :n_attrs], prepared once per weight version (same key as every other packed copy)."""
+        mode = ops.feature_gemm_mode()
+        if mode == 0:
+            return
+        W = self.feats_embed.weight
+        key = (_WEIGHT_EPOCH[0], W.data_ptr(), W._version, mode, int(n_attrs))
+        cache = self.__dict__.get("_split_cache")
+        if cache is None or cache[0] != key:
+            cache = (key, ops.split_pack(W, n_attrs, mode))
+            self.__dict__["_split_cache"] = cache
+        ops.split_bind(W.detach(), cache[1], mode, n_attrs)
+
     def embed_segments(self, segs, ld_e: int):
         """segs: [(x, a, c, is_target)] -> ([e [B,T,ld_e]], zq).  One fused call for all segments."""
+        table = self.attr_table()
+        self.bind_split_weights(table.shape[1] if table is not None else segs[0][1].shape[-1])
         pos = _segs_pos(self.enc, segs)
         call = [(x, a, c, (not tgt) and pos is not None) for (x, a, c, tgt) in segs]
         return ops.embed_fwd(call, self.items_embed.weight, self.feats_embed.weight, self.feats_embed.bias,
@@ -733,7 +750,7 @@ class _PackedModule:
 
     def __getstate__(self):  # torch.save(model) pickles whole modules (train.py:124): drop the ctypes caches
         state = dict(super().__getstate__())
-        for k in ("_pack_cache", "_final_norm_params", "_plan", "_fold_cache", "_param_cache"):
+        for k in ("_pack_cache", "_final_norm_params", "_plan", "_fold_cache", "_param_cache", "_split_cache"):
             state.pop(k, None)
         return state
 
@@ -1029,6 +1046,7 @@ class CARCA(_PackedModule, Model):
         for t in prm:
             ops._need_cuda(t)
         D.items_w, D.feats_w, D.feats_b, D.joint_w, D.joint_b = [t.data_ptr() for t in prm]
+        emb.bind_split_weights(n_attrs)
         if pos is not None:
             pos = pos.detach().contiguous()
             keep.append(pos)

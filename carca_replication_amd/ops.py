@@ -1202,10 +1202,45 @@ def capture_release(scope: int) -> None:
 # feature-GEMM precision (include/carca_hip.h, tuning key 16): opt-in split-precision products on the 16-bit MFMA pipe
 TUNE_SPLIT_GEMM = 16
 SPLIT_GEMM_MODES = {"fp32": 0, "bf16x3": 1, "fp16x2": 2}
+_split_mode = 0
 
 
-def set_feature_gemm_precision(mode: str) -> None:
+def set_feature_gemm_precision(mode: str, force: bool = False) -> None:
     """'fp32' (default): exact-fp32 MFMA.  'bf16x3': both operands split into three bf16 parts, six products, fp32
     accumulation.  'fp16x2': two fp16 parts, three products (|operands| < 65504).  Applies to AllEmbedding.feats_embed
-    (carca.py:86) where the one-workgroup-per-CU kernel runs; every other product keeps the fp32 kernels."""
-    set_tuning(TUNE_SPLIT_GEMM, SPLIT_GEMM_MODES[mode])
+    (carca.py:86) where the one-workgroup-per-CU kernel runs and n_attrs is a multiple of 32; every other product keeps
+    the fp32 kernels.  force: take the split kernel wherever its own conditions hold, whatever the grid (parity tests at
+    fixture sizes)."""
+    global _split_mode
+    set_tuning(TUNE_SPLIT_GEMM, SPLIT_GEMM_MODES[mode] | (16 if force and SPLIT_GEMM_MODES[mode] else 0))
+    _split_mode = SPLIT_GEMM_MODES[mode]
+    if _split_mode == 0:
+        _lib.check(_lib.load().carca_split_bind(None, None, 0, 0, 0), "split_bind")
+
+
+def feature_gemm_mode() -> int:
+    return _split_mode
+
+
+def split_launch_count() -> int:
+    return int(_lib.load().carca_split_launch_count())
+
+
+def split_pack(w: Tensor, K0: int, mode: int) -> Tensor:
+    """Packed 16-bit planes of w[:, :K0] (carca_split_pack) for the split-precision row GEMM: prepare once per weight version."""
+    w = _f32(w.detach())
+    _need_cuda(w)
+    lib = _lib.load()
+    N = w.shape[0]
+    out = torch.empty(int(lib.carca_split_bytes(N, int(K0), int(mode))), dtype=torch.uint8, device=w.device)
+    _lib.check(lib.carca_split_pack(w.data_ptr(), w.stride(0), int(K0), N, int(mode), out.data_ptr(), _stream()), "split_pack")
+    return out
+
+
+def split_bind(w: Optional[Tensor], planes: Optional[Tensor], mode: int = 0, K0: int = 0) -> None:
+    """This thread's following launches use `planes` wherever a row GEMM's weight pointer is w's (carca_split_bind)."""
+    lib = _lib.load()
+    if w is None:
+        _lib.check(lib.carca_split_bind(None, None, 0, 0, 0), "split_bind")
+    else:
+        _lib.check(lib.carca_split_bind(w.data_ptr(), planes.data_ptr(), int(mode), w.shape[0], int(K0)), "split_bind")

@@ -74,7 +74,8 @@ int carca_abi_version(void);
  *          the path every parity figure is quoted on); 1 = operands split into three bf16 parts, six bf16-MFMA products,
  *          fp32 accumulation (fp32-class accuracy on the 16x faster pipe); 2 = two fp16 parts (the second scaled by
  *          2^11), three products, two fp32 accumulators -- |operands| < 65504 required.  Only where the one-workgroup-per-CU
- *          kernel would run; anything else keeps the fp32 kernels. */
+ *          kernel would run; anything else keeps the fp32 kernels.  + 16: wherever the kernel's own conditions hold
+ *          (K0 % 32 == 0, K1 <= 8, plain epilogue), whatever the grid -- for parity tests at fixture sizes. */
 int carca_set_tuning(int key, int value);
 /* Deterministic mode, per backward pass: register the pass's flat fp32 gradient buffer `flat` (n floats) and its shadow
  * (n uint64, ZERO on entry); kernels launched on `stream` afterwards accumulate gradients that land inside `flat` into
@@ -179,6 +180,18 @@ typedef struct CarcaGemmDesc {
   int32_t gate_zero_drops; /* 1: an exactly-zero saved activation was DROPPED -> gradient 0 (else LeakyReLU'(0) = slope) */
 } CarcaGemmDesc;
 int carca_gemm_rows(const CarcaGemmDesc* desc /*host*/, void* stream);
+/* Opt-in split-precision path of the product above (tuning key 16; csrc/gemm_split.hip): the weight matrix as packed
+ * 16-bit planes, prepared once per weight version.  It takes products whose k-source 0 is whole 32-wide K steps
+ * (K0 % 32 == 0; k-source 1, at most 8 columns, is added as exact fp32 multiply-adds) on 384 x 96 tiles.
+ * carca_split_bytes gives the size of the packed copy of the [N, K0] block of k-source 0 (mode 1 = bf16 x 3, 2 = fp16 x 2),
+ * carca_split_pack writes it (w = bt0, row stride ldw), and carca_split_bind tells this THREAD's following launches that
+ * `planes` is the packed copy of the matrix at `w`: a launch whose bt0, mode and shape match uses it, any other launch
+ * under key 16 splits its weights itself, into scratch, every time (correct, ~8 us at C2).  carca_split_bind(NULL, NULL,
+ * 0, 0, 0) unbinds.  The caller keeps `planes` alive and re-packs when the weights change. */
+long long carca_split_bytes(int N, int K0, int mode);
+int carca_split_pack(const float* w, int ldw, int K0, int N, int mode, void* out, void* stream);
+int carca_split_bind(const float* w, const void* planes, int mode, int N, int K0);
+long long carca_split_launch_count(void); /* launches of the split-precision kernel by this process so far */
 /* n INDEPENDENT products (host array): the narrow ones (d-wide input gradients of the backward pass) share launches,
  * so that two ~150-block products cost one launch instead of two back to back; same results as n single calls. */
 int carca_gemm_rows_group(const CarcaGemmDesc* descs /*host*/, int n, void* stream);
