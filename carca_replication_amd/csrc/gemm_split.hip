@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 // tiles of 32 x 32 in two accumulator sets (288 registers).  Every fragment it reads from LDS serves three tiles (0.33 KB of
 // LDS reads per MFMA), every A element is split exactly once per workgroup, and nothing but its own instruction stream has
 // to hide a wave's VALU work: 24 cycles of issue in the shadow of each 32-cycle MFMA.
-template <int MODE, int TM>
+// DIAG (tuning key 15, timing experiments with WRONG results; 0 in every shipped launch): 1 no global loads behind the
+// prologue, 2 no LDS writes behind the prologue, 4 no MFMAs, 8 no split arithmetic (the fragment's bits reinterpreted),
+// 16 no barriers in the K loop, 32 no B fragment reads (one set reused).
+template <int MODE, int TM, int DIAG = 0>
 __global__ __launch_bounds__(768 / TM) void gemm_rows_split_kernel(const SplitDev args) {
   using S = Split<MODE>;
   constexpr int NP = S::NP, TN = 3, C4 = SP_BK / 4, SP_NT = 768 / TM, RPI = SP_NT / 8;  // (RPI: A rows staged per slot index)
@@ -149,8 +152,8 @@ __global__ __launch_bounds__(768 / TM) void gemm_rows_split_kernel(const SplitDe
   const int row0 = (rb - args.rb_start[s]) * SP_BM;
   const int n0 = cb * SP_BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nfast = D.K0 / SP_BK;  // (the launcher admits K0 % 32 == 0 only; the few columns of k-source 1 join in the epilogue)
-  const int ntiles = nfast;
+  const int nfast = D.K0 / SP_BK;             // whole K steps: the pipelined loop
+  const int ntiles = (D.K0 + SP_BK - 1) / SP_BK;  // (+ one ragged step when K0 % 32 != 0; k-source 1 joins in the epilogue)
 
   // ---- staging slots (loop invariants): slot tid + SP_NT i = row (tid >> 3) + RPI i, 16-byte column tid & 7 -------------
   const int a_r = tid >> 3, a_c4 = tid & 7;
@@ -195,6 +198,16 @@ __global__ __launch_bounds__(768 / TM) void gemm_rows_split_kernel(const SplitDe
       rbv[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (unsigned)(min(tid + i * SP_NT, B_SLOTS - 1) * 16),
                                                      t * B_STEP_BYTES, 0);
   };
+  auto load_a_ragged = [&](int t) {
+    // the step that holds the end of K0 (a multiple of 4): a 16-byte group is all inside K0 or all outside; the ones outside
+    // re-read the row's last group -- finite data against the zeros the packed W holds there
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int kc = min(t * SP_BK + a_c4 * 4, D.K0 - 4);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_byte[i] + (unsigned)((kc - a_c4 * 4) * (int)sizeof(float)), 0, 0);
+      ra[i] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    }
+  };
   auto store_stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) *reinterpret_cast<f32x4*>(&As[buf * A_BUF + a_lds + i * RPI * SP_LSA]) = ra[i];
@@ -221,15 +234,31 @@ __global__ __launch_bounds__(768 / TM) void gemm_rows_split_kernel(const SplitDe
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int q = 0; q < NP; ++q)
-          bp[tn][q] = *reinterpret_cast<const typename S::vec*>(b_frag + buf * B_BUF + (q * SP_BN + tn * 32) * SP_LSB + kg * 16);
+          bp[tn][q] = *reinterpret_cast<const typename S::vec*>(
+              b_frag + buf * B_BUF + ((DIAG & 32) ? 0 : (q * SP_BN + tn * 32) * SP_LSB + kg * 16));
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(a_frag + buf * A_BUF + tm * 32 * SP_LSA + kg * 16);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(a_frag + buf * A_BUF + tm * 32 * SP_LSA + kg * 16 + 4);
         typename S::vec ap[NP];
-        S::split(x0, x1, ap);
+        if constexpr (DIAG & 8) {
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) S::products(ap, bp[tn], lead[tm][tn], corr[tm][tn]);
+          for (int q = 0; q < NP; ++q) ap[q] = __builtin_bit_cast(typename S::vec, q & 1 ? x1 : x0);
+        } else {
+          S::split(x0, x1, ap);
+        }
+        if constexpr (DIAG & 4) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+              const f32x4 u = __builtin_bit_cast(f32x4, ap[q]), w = __builtin_bit_cast(f32x4, bp[tn][q]);
+              lead[tm][tn][q] += u[0] * w[1] + u[2] * w[3];  // (keeps the operands alive)
+            }
+        } else {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) S::products(ap, bp[tn], lead[tm][tn], corr[tm][tn]);
+        }
       }
     }
   };
@@ -247,13 +276,23 @@ __global__ __launch_bounds__(768 / TM) void gemm_rows_split_kernel(const SplitDe
     for (int t = 0; t < nfast; ++t) {
       const int cur = t & 1;
       compute(cur);
-      if (t + 1 < nfast) store_stage(cur ^ 1);  // (last read in step t - 1, behind that step's barrier)
-      if (t + 2 < nfast) {
-        load_a_fast(t + 2);
-        load_b(t + 2);
-      }
-      __syncthreads();
+      if constexpr (!(DIAG & 2))
+        if (t + 1 < nfast) store_stage(cur ^ 1);  // (last read in step t - 1, behind that step's barrier)
+      if constexpr (!(DIAG & 1))
+        if (t + 2 < nfast) {
+          load_a_fast(t + 2);
+          load_b(t + 2);
+        }
+      if constexpr (!(DIAG & 16)) __syncthreads();
     }
+  }
+  for (int t = nfast; t < ntiles; ++t) {
+    load_a_ragged(t);
+    load_b(t);
+    __syncthreads();  // (every wave is done with both LDS buffers)
+    store_stage(0);
+    __syncthreads();
+    compute(0);
   }
 
   // ---- epilogue: the launcher admits the plain one only (alpha, bias, row mask -- what feats_embed needs) -----------------
@@ -348,8 +387,9 @@ extern "C" int carca_split_bind(const float* w, const void* planes, int mode, in
 int carca_gemm_rows_split_try(const CarcaGemmDesc* desc, hipStream_t stream) {
   const int mode = carca_tuning(CARCA_TUNE_SPLIT_GEMM) & 15;
   if (mode != 1 && mode != 2) return 1;
-  // whole 32-wide K steps of k-source 0 on the MFMA pipe; k-source 1 (a handful of context columns) as fp32 FMAs
-  if (desc->K0 % SP_BK != 0 || desc->K1 > 8) return 1;
+  // k-source 0 on the MFMA pipe in 32-wide K steps (16-byte groups: K0 a multiple of 4); k-source 1 (a handful of
+  // context columns) as fp32 FMAs
+  if (desc->K0 % 4 != 0 || desc->K0 < 4 || desc->K1 > 8) return 1;
   if (desc->colvec || desc->pos || desc->gate_scale != 0.f) return 1;  // (the plain epilogue only: alpha, bias, row mask)
   for (int s = 0; s < desc->nseg; ++s)
     if (desc->seg[s].add || desc->seg[s].gate || desc->seg[s].rowscale || desc->seg[s].add_pos) return 1;
@@ -381,13 +421,19 @@ int carca_gemm_rows_split_try(const CarcaGemmDesc* desc, hipStream_t stream) {
   const int grid = rb * g.ncb;
   hipEvent_t e0, e1;
   const bool ev = carca_take_launch_events(&e0, &e1);
-  if (mode == 1) {
-    if (ev) hipExtLaunchKernelGGL((gemm_rows_split_kernel<1, SPLIT_TM>), dim3(grid), dim3(768 / SPLIT_TM), 0, stream, e0, e1, 0, g);
-    else hipLaunchKernelGGL((gemm_rows_split_kernel<1, SPLIT_TM>), dim3(grid), dim3(768 / SPLIT_TM), 0, stream, g);
-  } else {
-    if (ev) hipExtLaunchKernelGGL((gemm_rows_split_kernel<2, SPLIT_TM>), dim3(grid), dim3(768 / SPLIT_TM), 0, stream, e0, e1, 0, g);
-    else hipLaunchKernelGGL((gemm_rows_split_kernel<2, SPLIT_TM>), dim3(grid), dim3(768 / SPLIT_TM), 0, stream, g);
+  auto launch = [&](auto kernel) {
+    if (ev) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(768 / SPLIT_TM), 0, stream, e0, e1, 0, g);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(768 / SPLIT_TM), 0, stream, g);
+  };
+  const int diag = carca_tuning(CARCA_TUNE_DIAG);
+#define SPLIT_CASE(D_) \
+  case D_: mode == 1 ? launch(gemm_rows_split_kernel<1, SPLIT_TM, D_>) : launch(gemm_rows_split_kernel<2, SPLIT_TM, D_>); break;
+  switch (diag) {
+    SPLIT_CASE(1) SPLIT_CASE(2) SPLIT_CASE(3) SPLIT_CASE(4) SPLIT_CASE(8) SPLIT_CASE(12) SPLIT_CASE(16) SPLIT_CASE(19) SPLIT_CASE(32)
+    SPLIT_CASE(7) SPLIT_CASE(15)
+    default: mode == 1 ? launch(gemm_rows_split_kernel<1, SPLIT_TM, 0>) : launch(gemm_rows_split_kernel<2, SPLIT_TM, 0>);
   }
+#undef SPLIT_CASE
   CARCA_LAUNCH_CHECK();
   ++g_split_launches;
   return CARCA_OK;

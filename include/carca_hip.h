@@ -75,7 +75,7 @@ int carca_abi_version(void);
  *          fp32 accumulation (fp32-class accuracy on the 16x faster pipe); 2 = two fp16 parts (the second scaled by
  *          2^11), three products, two fp32 accumulators -- |operands| < 65504 required.  Only where the one-workgroup-per-CU
  *          kernel would run; anything else keeps the fp32 kernels.  + 16: wherever the kernel's own conditions hold
- *          (K0 % 32 == 0, K1 <= 8, plain epilogue), whatever the grid -- for parity tests at fixture sizes. */
+ *          (K0 % 4 == 0, K1 <= 8, plain epilogue), whatever the grid -- for parity tests at fixture sizes. */
 int carca_set_tuning(int key, int value);
 /* Deterministic mode, per backward pass: register the pass's flat fp32 gradient buffer `flat` (n floats) and its shadow
  * (n uint64, ZERO on entry); kernels launched on `stream` afterwards accumulate gradients that land inside `flat` into
@@ -181,8 +181,8 @@ typedef struct CarcaGemmDesc {
 } CarcaGemmDesc;
 int carca_gemm_rows(const CarcaGemmDesc* desc /*host*/, void* stream);
 /* Opt-in split-precision path of the product above (tuning key 16; csrc/gemm_split.hip): the weight matrix as packed
- * 16-bit planes, prepared once per weight version.  It takes products whose k-source 0 is whole 32-wide K steps
- * (K0 % 32 == 0; k-source 1, at most 8 columns, is added as exact fp32 multiply-adds) on 384 x 96 tiles.
+ * 16-bit planes, prepared once per weight version.  It takes products with K0 % 4 == 0 (k-source 0 in 32-wide K steps;
+ * k-source 1, at most 8 columns, is added as exact fp32 multiply-adds) and the plain epilogue, on 384 x 96 tiles.
  * carca_split_bytes gives the size of the packed copy of the [N, K0] block of k-source 0 (mode 1 = bf16 x 3, 2 = fp16 x 2),
  * carca_split_pack writes it (w = bt0, row stride ldw), and carca_split_bind tells this THREAD's following launches that
  * `planes` is the packed copy of the matrix at `w`: a launch whose bt0, mode and shape match uses it, any other launch

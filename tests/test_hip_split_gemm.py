@@ -33,8 +33,12 @@ def split_forced(request):
 
 @pytest.mark.parametrize("name", G1_NAMES)
 def test_g1_eval_forward_matches_reference_on_the_split_path(split_forced, name):
+    from tests.golden_util import load
+
     F.test_g1_eval_forward_matches_reference(name)
-    assert split_forced() >= 1
+    # (n_attrs = 32 / 19 / 32 / 40: the kernel wants 16-byte groups -- n_attrs % 4 == 0 --, d90h2 keeps the fp32 kernels)
+    takes = int(load("g1_" + name).dim["n_attrs"]) % 4 == 0
+    assert split_forced() == (2 if takes else 0)  # (the forward and its traced twin)
 
 
 def test_g8_ranking_is_identical_on_the_split_path(split_forced):
@@ -131,11 +135,11 @@ def test_product_alone_at_c2_size_against_fp64(mode):
 
 @pytest.mark.parametrize("mode", MODES)
 def test_ragged_rows_segments_and_column_tail(mode):
-    """Two row segments that end inside a 384-row tile, N = 450 (66 columns in the last block), a [B, T, K] view as the
-    first operand: the forced kernel against the fp32 kernels."""
+    """Two row segments that end inside a 384-row tile, N = 450 (66 columns in the last block), K0 = 1000 (a ragged last K
+    step): the forced kernel against the fp32 kernels."""
     from carca_replication_amd import ops
 
-    K0, K1, N = 256, 6, 450
+    K0, K1, N = 1000, 6, 450
     a, c, w, b = _product_inputs(1000 + 333, K0, K1, N, seed=11)
     segs = [dict(a0=a[:1000], a1=c[:1000]), dict(a0=a[1000:], a1=c[1000:])]
 
