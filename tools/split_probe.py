@@ -1,7 +1,8 @@
 """Timing dissection of the split-precision feature GEMM (csrc/gemm_split.hip): python tools/split_probe.py
 The product alone at C2 size (19,328 x (4096 + 6) x 450) under each mode, events around back-to-back launches after a
 pre-heat, for the shipped kernel and for its DIAG variants (tuning key 15: timing experiments, wrong results):
-1 no global loads, 2 no LDS writes, 4 no MFMAs, 8 no split arithmetic, 16 no barriers, 32 no B fragment reads."""
+1 no global loads / DMA, 4 no MFMAs, 8 no split arithmetic, 16 no barriers, 32 no B fragment reads (sums combine);
+VARIANT=21 selects the register-staged kernel instead of the LDS-DMA one."""
 import os
 import sys
 
@@ -18,6 +19,8 @@ w = (torch.rand(N, K0 + K1, device="cuda", generator=g) * 2 - 1) * 0.036
 b = torch.zeros(N, device="cuda")
 out = torch.empty(rows, 452, device="cuda")
 planes = {}
+if os.environ.get("VARIANT"):
+    ops.set_tuning(0, int(os.environ["VARIANT"]))
 
 
 def run():
@@ -37,7 +40,7 @@ def timed(reps=40):
     return 1e3 * e0.elapsed_time(e1) / reps
 
 
-diags = [int(x) for x in os.environ.get("DIAGS", "0,1,2,3,4,8,12,16,32,7,15").split(",")]
+diags = [int(x) for x in os.environ.get("DIAGS", "0,64,128,192,1,4,68,5,8,13").split(",")]
 print("fp32 path: %.1f us" % timed())
 for mode_name, mode in (("bf16x3", 1), ("fp16x2", 2)):
     ops.set_feature_gemm_precision(mode_name)
