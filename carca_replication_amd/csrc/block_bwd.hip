@@ -341,6 +341,9 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
   if ((rc = carca_embed_scatter_segs(dzq, ldz, sids, srows, nf, d, (float)sqrt((double)d), D->g_items, stream))) return rc;
   wf.ld_dy = ldz; wf.ld_x = D->n_attrs; wf.ld_x1 = D->n_ctx; wf.N = g; wf.K = D->n_attrs; wf.K1 = D->n_ctx;
   wf.dw = D->g_feats_w; wf.ldw = D->n_attrs + D->n_ctx; wf.db = D->g_feats_b;
+  // (rows of pad items: their d q is zero already -- d [z ; q] above is masked -- but SAYING so lets the weight-gradient
+  // kernel leave them out of its row table instead of multiplying zeros: 47 % of a C2 training batch's rows)
+  wf.mask_rows = 1;
   if (D->ev_early && hipEventRecord((hipEvent_t)D->ev_early, (hipStream_t)stream) != hipSuccess) {
     carca_set_error("embed_bwd: cannot record the early-gradients event");
     return CARCA_ERR_BADARG;

@@ -31,9 +31,21 @@ constexpr int WG_XS = WG_BK + 32;                       // X tile row stride (fl
 constexpr int WG_YB = WG_BR * WG_BN, WG_XB = WG_BR * WG_XS;  // floats per LDS buffer
 constexpr unsigned WG_INV = 0x80000000u;                // row offset that reads as zeros (num_records <= 2^31)
 
+// What depends on HOW MANY rows take part is decided on the device: rows whose ids == 0 (mask_rows: the e * mask of
+// carca.py:94 seen from the backward side) contribute nothing, and the row-table kernel leaves them OUT of the table instead
+// of listing them as "reads as zeros" -- with left-padded profiles of U{3..50} items 47 % of a training
+// batch's rows are pads, and the chunks they filled were 47 % of this kernel's MFMA work.  The compacted chunk counts, and
+// with them the stream-K ranges, are written by that kernel into a WgPlan next to the table; the host sizes everything by
+// the uncompacted upper bounds.
+struct WgPlan {
+  int chunk_start[CARCA_MAX_SEGS + 1];  // compacted 32-row chunks per segment, prefix sums
+  int nchunks, ngroups, slow_w, pad;
+  long total, n_fast, per_w;
+};
+
 struct WgradCuDev {
   CarcaWgradDesc d;
-  int chunk_start[CARCA_MAX_SEGS + 1];
+  int chunk_start[CARCA_MAX_SEGS + 1];  // UPPER BOUNDS (every row kept): where a segment's entries start in the table
   unsigned y_bytes[CARCA_MAX_SEGS], x_bytes[CARCA_MAX_SEGS], x1_bytes[CARCA_MAX_SEGS];  // buffer extents
   const unsigned* tab;  // [3][V]: byte offsets of dY / X / X1 rows inside their segment, V = 32 * chunks
   int V, nnb, nkb;
@@ -65,6 +77,8 @@ struct WgradCuDev {
   int* klo;       // [nkb][2] first / last group with units in the k block     them instead of redoing 64-bit divisions)
   int src1_kb;  // k block that also carries the second k-source's columns, or -1
   unsigned long long* dbg;    // phase stamps of a diagnostic run (tuning variant 3)
+  WgPlan* plan;   // device: written by wgrad_rowtab_kernel, read by the two kernels behind it
+  int compact;    // 0: masked rows stay in the table as "reads as zeros" (tuning variant 22, A/B; the round-3 behaviour)
 };
 __device__ __forceinline__ unsigned long long* carca_debug_ptr(const WgradCuDev& a) { return a.dbg; }
 
@@ -86,45 +100,94 @@ struct WgRanges {
   }
 };
 
-__global__ void wgrad_rowtab_kernel(const WgradCuDev args, unsigned* tab) {
+// ONE 1024-thread block: per segment, a block-wide scan of the rows that take part, their three byte offsets written
+// back to back from the segment's first chunk on, the last chunk padded with "no row" entries; then the plan and the groups'
+// unit ranges.  (19,200 rows at C2: ~6 us, as long as the one-entry-per-thread kernel it replaces.)
+__global__ __launch_bounds__(1024) void wgrad_rowtab_kernel(const WgradCuDev args, unsigned* tab) {
+  __shared__ int wsum[16];
+  __shared__ int s_kept;
+  __shared__ WgPlan plan;
   const CarcaWgradDesc& D = args.d;
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  {
-    const int nchunks = args.chunk_start[D.nseg];
-    const WgRanges rg{(long)args.nkb * nchunks, args.n_fast, args.per_w, args.slow_w, args.ngroups};
-    if (v <= args.ngroups) args.gbegin[v] = rg.begin_of(v);
-    if (v < args.nkb) {
-      args.klo[2 * v] = rg.group_of((long)v * nchunks);
-      args.klo[2 * v + 1] = rg.group_of((long)(v + 1) * nchunks - 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int chunk0 = 0;
+  if (tid == 0) plan.chunk_start[0] = 0;
+  for (int s = 0; s < D.nseg; ++s) {
+    const CarcaWgradSeg sg = D.seg[s];
+    const int T = sg.T >= 1 ? sg.T : 1;
+    const int per = (sg.rows + 1023) / 1024;
+    const int r0 = min(tid * per, sg.rows), r1 = min(r0 + per, sg.rows);
+    auto masked = [&](int row) { return D.mask_rows && sg.ids && sg.ids[row] == 0; };
+    int cnt = 0;
+    for (int row = r0; row < r1; ++row) cnt += (args.compact && masked(row)) ? 0 : 1;
+    // exclusive scan of cnt over the block: inside the wave by shuffles, across the sixteen waves through LDS
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
     }
-  }
-  if (v >= args.V) return;
-  const int c = v >> 5;
-  int s = 0;
-  for (int i = 1; i < CARCA_MAX_SEGS; ++i)
-    if (i < D.nseg && c >= args.chunk_start[i]) s = i;
-  const CarcaWgradSeg sg = D.seg[s];
-  const int row = v - args.chunk_start[s] * WG_BR;
-  unsigned yo = WG_INV, xo = WG_INV, x1o = WG_INV;
-  if (row < sg.rows) {
-    const int id = sg.ids ? sg.ids[row] : 1;
-    if (!(D.mask_rows && id == 0)) {
-      yo = (unsigned)((size_t)row * D.ld_dy * sizeof(float));
-      const int T = sg.T >= 1 ? sg.T : 1;
-      const size_t xe = sg.x_gather ? (size_t)id * D.ld_x
-                        : sg.x_bstride ? (size_t)(row / T) * sg.x_bstride + (size_t)(row % T) * D.ld_x
-                                       : (size_t)row * D.ld_x;
-      xo = (unsigned)(xe * sizeof(float));
-      if (D.K1 > 0) {
-        const size_t x1e = sg.x1_bstride ? (size_t)(row / T) * sg.x1_bstride + (size_t)(row % T) * D.ld_x1
-                                         : (size_t)row * D.ld_x1;
-        x1o = (unsigned)(x1e * sizeof(float));
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (tid == 1023) s_kept = before + incl;
+    __syncthreads();
+    const int kept = s_kept;
+    int v = chunk0 * WG_BR + before + incl - cnt;
+    for (int row = r0; row < r1; ++row) {
+      const bool m = masked(row);
+      if (args.compact && m) continue;
+      unsigned yo = WG_INV, xo = WG_INV, x1o = WG_INV;
+      if (!m) {
+        const int id = sg.ids ? sg.ids[row] : 1;
+        yo = (unsigned)((size_t)row * D.ld_dy * sizeof(float));
+        const size_t xe = sg.x_gather ? (size_t)id * D.ld_x
+                          : sg.x_bstride ? (size_t)(row / T) * sg.x_bstride + (size_t)(row % T) * D.ld_x
+                                         : (size_t)row * D.ld_x;
+        xo = (unsigned)(xe * sizeof(float));
+        if (D.K1 > 0) {
+          const size_t x1e = sg.x1_bstride ? (size_t)(row / T) * sg.x1_bstride + (size_t)(row % T) * D.ld_x1
+                                           : (size_t)row * D.ld_x1;
+          x1o = (unsigned)(x1e * sizeof(float));
+        }
       }
+      tab[v] = yo;
+      tab[args.V + v] = xo;
+      tab[2 * args.V + v] = x1o;
+      ++v;
     }
+    const int chunks = (kept + WG_BR - 1) / WG_BR;
+    for (int p = chunk0 * WG_BR + kept + tid; p < (chunk0 + chunks) * WG_BR; p += 1024) {  // the last chunk's tail
+      tab[p] = WG_INV;
+      tab[args.V + p] = WG_INV;
+      tab[2 * args.V + p] = WG_INV;
+    }
+    chunk0 += chunks;
+    if (tid == 0) plan.chunk_start[s + 1] = chunk0;
+    __syncthreads();  // (wsum / s_kept are reused by the next segment)
   }
-  tab[v] = yo;
-  tab[args.V + v] = xo;
-  tab[2 * args.V + v] = x1o;
+  if (tid == 0) {
+    for (int s = D.nseg + 1; s <= CARCA_MAX_SEGS; ++s) plan.chunk_start[s] = chunk0;
+    const long total = (long)args.nkb * chunk0;
+    const long n_slow = (D.K1 > 0 && args.src1_kb >= 0 && args.src1_kb == args.nkb - 1) ? (long)chunk0 : 0;
+    plan.nchunks = chunk0;
+    plan.total = total;
+    plan.n_fast = total - n_slow;
+    plan.slow_w = args.slow_w;
+    const long total_w = plan.n_fast * 256 + n_slow * args.slow_w;
+    plan.per_w = max(1l, (total_w + args.ngroups - 1) / args.ngroups);  // (args.ngroups: the groups the chip can host)
+    plan.ngroups = (int)((total_w + plan.per_w - 1) / plan.per_w);      // (a short product: fewer groups)
+    plan.pad = 0;
+    *args.plan = plan;
+  }
+  __syncthreads();
+  const WgRanges rg{plan.total, plan.n_fast, plan.per_w, plan.slow_w, plan.ngroups};
+  for (int g = tid; g <= args.ngroups; g += 1024) args.gbegin[g] = rg.begin_of(g);
+  for (int kb = tid; kb < args.nkb; kb += 1024) {
+    const bool any = plan.ngroups > 0 && plan.nchunks > 0;
+    args.klo[2 * kb] = any ? rg.group_of((long)kb * plan.nchunks) : 0;
+    args.klo[2 * kb + 1] = any ? rg.group_of((long)(kb + 1) * plan.nchunks - 1) : -1;
+  }
 }
 
 __device__ __forceinline__ f32x4 as_f4(u32x4 v) {
@@ -143,9 +206,16 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int nchunks = args.chunk_start[D.nseg];
-  const long total = (long)args.nkb * nchunks;  // (k block, chunk) units of a group; its members take an n block each
-  const WgRanges rg{total, args.n_fast, args.per_w, args.slow_w, args.ngroups};
+  // the plan of the row-table kernel, once, into scalars (a scalar load inside the loops below would wait on lgkmcnt,
+  // i.e. on the LDS reads in flight)
+  const WgPlan P = *args.plan;
+  int cs[CARCA_MAX_SEGS + 1];
+#pragma unroll
+  for (int q = 0; q <= CARCA_MAX_SEGS; ++q) cs[q] = __builtin_amdgcn_readfirstlane(P.chunk_start[q]);
+  const int nchunks = __builtin_amdgcn_readfirstlane(P.nchunks);
+  const int ngroups = __builtin_amdgcn_readfirstlane(P.ngroups);
+  const long total = P.total;  // (k block, chunk) units of a group; its members take an n block each
+  const WgRanges rg{total, P.n_fast, P.per_w, P.slow_w, ngroups};
   int grp, nb;
   {
     const int per_xcd = (int)gridDim.x / args.nxcd, x = (int)blockIdx.x % args.nxcd, sl = (int)blockIdx.x / args.nxcd;
@@ -159,7 +229,7 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
       nb = l % args.nnb;
     }
   }
-  if (grp >= args.ngroups) return;
+  if (grp >= ngroups || nchunks == 0) return;
   const long w_begin = rg.begin_of(grp);
   const long w_end = rg.begin_of(grp + 1);
 
@@ -177,8 +247,8 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
     int seg = 0;
 #pragma unroll
     for (int q = 1; q < CARCA_MAX_SEGS; ++q)
-      if (q < D.nseg && c_begin >= args.chunk_start[q]) seg = q;
-    const int c_end = (int)min((long)args.chunk_start[seg + 1], c_begin + (w_end - w));
+      if (q < D.nseg && c_begin >= cs[q]) seg = q;
+    const int c_end = (int)min((long)cs[seg + 1], c_begin + (w_end - w));
     w += c_end - c_begin;
     const int n0 = nb * WG_BN, k0 = kb * WG_BK;
     const bool do_db = D.db != nullptr && kb == 0;
@@ -403,7 +473,7 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
 // same n, four consecutive k) -- one 16-byte load per partial.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradCuDev args) {
   const CarcaWgradDesc& D = args.d;
-  const int nchunks = args.chunk_start[D.nseg];
+  const int nchunks = args.plan->nchunks;
   const int kb = (int)blockIdx.x / args.nnb, nb = (int)blockIdx.x - kb * args.nnb;
   const int j4 = (int)blockIdx.y * 256 + threadIdx.x;  // float4 index inside the tile, 0 .. 9215
   const int e = (4 * j4) / WG_NT, tid = 4 * j4 - e * WG_NT;
@@ -512,35 +582,23 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   g.gpx = per_xcd / g.nnb;
   g.ngroups = g.nxcd * g.gpx + (g.nxcd * (per_xcd - g.gpx * g.nnb)) / g.nnb;
   if (g.ngroups < 1) return 1;  // (more n blocks than CUs: the tile kernel)
-  const long units = (long)g.nkb * chunks;
-  const long n_slow = (desc->K1 > 0 && g.src1_kb >= 0 && g.src1_kb == g.nkb - 1) ? (long)chunks : 0;
-  g.n_fast = units - n_slow;
+  // (g.ngroups stays the number of groups the chip can HOST; how many of them get units, and which, is the row-table
+  // kernel's decision once it has counted the rows that take part: WgPlan)
   g.slow_w = carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 13 ? 256 : 264;  // (variant 13: equal item counts -- A/B switch)
-  const long total_w = g.n_fast * 256 + n_slow * g.slow_w;
-  g.per_w = (total_w + g.ngroups - 1) / g.ngroups;
-  g.ngroups = (int)((total_w + g.per_w - 1) / g.per_w);  // (a short product: fewer groups than the chip could host)
+  g.compact = carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 22 ? 0 : 1;       // (variant 22: masked rows stay in the table -- A/B switch)
   const int grid = ncu;
   g.V = chunks * WG_BR;
-  {  // k blocks a group's range can touch: walk the groups' first and last units
-    auto item_at = [&](long wt) -> long {
-      const long fast_w = g.n_fast * 256;
-      return wt <= fast_w ? wt / 256 : g.n_fast + (wt - fast_w) / g.slow_w;
-    };
-    auto begin_of = [&](int gi) -> long { return gi >= g.ngroups ? units : std::min(units, item_at((long)gi * g.per_w)); };
-    int spg = 1;
-    for (int gi = 0; gi < g.ngroups; ++gi) {
-      const long b = begin_of(gi), e = begin_of(gi + 1);
-      if (e > b) spg = std::max(spg, (int)((e - 1) / chunks - b / chunks) + 1);
-    }
-    g.slots_pg = spg;
-  }
+  // k blocks a group's range can touch, for ANY number of chunks per k block c >= 1: a range holds at most
+  // ceil(nkb c / ngroups) + 1 units, which reach into at most floor(nkb / ngroups) + 2 k blocks
+  g.slots_pg = g.nkb / g.ngroups + 2;
   // Partials pay when a tile receives FEW of them: every partial is 147 KB written and read back (C2's feats_embed: 5.6 per
   // tile, 45 MB, ~14 us of reduce kernel against ~60 us of atomics).  A product of few tiles cut over all the groups (the
   // d x F product of the re-associated backward: 11 tiles, 23 partials each) keeps the atomics.
   const long n_tiles = (long)g.nkb * g.nnb, n_parts = (long)g.ngroups * g.nnb;
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 14 || n_parts > 8 * n_tiles) g.slots_pg = 0;
   const size_t part_floats = (size_t)g.ngroups * g.slots_pg * g.nnb * WG_BN * WG_BK;
-  const size_t cnt_ints = ((size_t)2 * (g.ngroups + 1) + 2 * g.nkb + 5) / 4 * 4;  // gbegin (8-byte entries) | klo
+  const size_t plan_ints = (sizeof(WgPlan) + 15) / 16 * 4;
+  const size_t cnt_ints = ((size_t)2 * (g.ngroups + 1) + 2 * g.nkb + 5) / 4 * 4 + plan_ints;  // gbegin (8-byte entries) | klo | plan
   const size_t tab_bytes = ((size_t)3 * g.V + cnt_ints) * sizeof(unsigned) + part_floats * sizeof(float);  // row table | group ranges | partial tiles
   unsigned* tab = (unsigned*)(carca_stream_capturing(stream) ? carca_capture_alloc(stream, tab_bytes, false, nullptr)
                                                               : carca_stream_scratch(stream, CARCA_SCRATCH_WTAB, tab_bytes));
@@ -550,10 +608,10 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
     unsigned* aux = tab + (size_t)3 * g.V;  // (V is a multiple of 32 and the buffer comes from hipMalloc: 16-byte aligned)
     g.gbegin = (long*)aux;
     g.klo = (int*)(aux + 2 * (size_t)(g.ngroups + 1));
+    g.plan = (WgPlan*)(aux + cnt_ints - plan_ints);  // (16-byte aligned: everything in front of it is whole 16-byte groups)
     g.part = (float*)(aux + cnt_ints);
   }
-  hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((std::max(g.V, std::max(g.ngroups + 1, g.nkb)) + 255) / 256), dim3(256), 0, stream,
-                     g, tab);
+  hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3(1), dim3(1024), 0, stream, g, tab);
   g.dbg = carca_debug_buffer();
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 3 && g.dbg)
     hipLaunchKernelGGL(gemm_wgrad_cu_kernel<1>, dim3(grid), dim3(WG_NT), 0, stream, g);
