@@ -290,6 +290,7 @@ SIGNATURES = {
     "carca_cross_score_bwd": (_i, [C.POINTER(CrossBwdDesc), C.POINTER(WgradDesc), C.POINTER(_i), _fp]),
     "carca_embed_bwd_workspace": (C.c_size_t, [C.POINTER(C.c_int32), _i, _i, _i]),
     "carca_embed_bwd": (_i, [C.POINTER(EmbedBwdDesc), _fp]),
+    "carca_early_event_recorded": (_i, []),
     "carca_adam_step": (_i, [C.POINTER(AdamTensor), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i,
                         _fp]),
     "carca_mark_rows": (_i, [_fp, C.c_int64, _fp, C.c_int64, _fp]),

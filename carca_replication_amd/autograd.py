@@ -158,7 +158,7 @@ class _Tail:
 SPLIT_EMBED_BWD = "graph"  # "graph": while a hipGraph is being captured (engine.GraphedTrainStep) -- an eager step is bound by
                            # its ~40 launches' host time (1.7 ms at C2), which the split's extra launches only add to (eager
                            # steps measured 1.71-2.48 ms with it, 1.79 without); True: always; False: never
-SPLIT_SIDE_CUS = 128       # CU budget of the second stream's weight-gradient launch; the first stream's gets the rest
+SPLIT_SIDE_CUS = 96        # CU budget of the second stream's weight-gradient launch; the first stream's gets the rest
 SPLIT_MAIN_TARGET_USERS = 0.04  # share of the FIRST target segment's users left to the first stream (balance; C2: 0 / 0.04 / 0.08
                                 # -> 1.654 / 1.642 / 1.655 ms per step)
 SPLIT_MIN_GFLOP = 20.0     # the split pays when d feats_embed is long against the launches it doubles (C2: 71 GFLOP per pass)

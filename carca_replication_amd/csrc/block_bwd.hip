@@ -275,6 +275,11 @@ extern "C" size_t carca_embed_bwd_workspace(const int32_t* rows, int nseg, int d
   return n;
 }
 
+namespace {
+int g_early_recorded = 0;  // did the last carca_embed_bwd with an ev_early record it?  (process-wide: autograd runs the backward on a thread of its own)
+}
+extern "C" int carca_early_event_recorded(void) { return g_early_recorded; }
+
 extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
   CARCA_CHECK_ARG(D && D->nseg >= 1 && D->nseg <= CARCA_MAX_SEGS, "embed_bwd: bad segment count");
   CARCA_CHECK_ARG(D->d >= 1 && D->g >= 1 && D->n_attrs >= 1 && D->n_ctx >= 0 && D->ld_de >= D->d && D->L >= 1,
@@ -344,9 +349,43 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
   // (rows of pad items: their d q is zero already -- d [z ; q] above is masked -- but SAYING so lets the weight-gradient
   // kernel leave them out of its row table instead of multiplying zeros: 47 % of a C2 training batch's rows)
   wf.mask_rows = 1;
-  if (D->ev_early && hipEventRecord((hipEvent_t)D->ev_early, (hipStream_t)stream) != hipSuccess) {
-    carca_set_error("embed_bwd: cannot record the early-gradients event");
-    return CARCA_ERR_BADARG;
+  if (D->ev_early) {
+    // While the stream is being captured the record must become an EXTERNAL event-record node of the graph: every replay
+    // then records the caller's event when it gets here, and a stream outside the graph -- the one that all-reduces the
+    // early gradients -- can wait on it (a plain record inside a capture is only an edge of the capture).  Two ways to say
+    // so; a runtime that takes neither leaves the event unrecorded and says so (carca_early_event_recorded): the caller
+    // then reduces the early range behind the replay.
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t ev = (hipEvent_t)D->ev_early;
+    g_early_recorded = 0;
+    if (!carca_stream_capturing(st)) {
+      if (hipEventRecord(ev, st) != hipSuccess) {
+        carca_set_error("embed_bwd: cannot record the early-gradients event");
+        return CARCA_ERR_BADARG;
+      }
+      g_early_recorded = 1;
+    } else if (hipError_t e1 = hipEventRecordWithFlags(ev, st, hipEventRecordExternal); e1 == hipSuccess) {
+      g_early_recorded = 1;
+    } else {
+      (void)hipGetLastError();
+      hipError_t e2 = hipSuccess, e3 = hipSuccess, e4 = hipSuccess;
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      unsigned long long id = 0;
+      hipGraph_t graph = nullptr;
+      const hipGraphNode_t* deps = nullptr;
+      size_t ndeps = 0;
+      hipGraphNode_t node = nullptr;
+      if ((e2 = hipStreamGetCaptureInfo_v2(st, &cs, &id, &graph, &deps, &ndeps)) == hipSuccess && cs == hipStreamCaptureStatusActive &&
+          graph && (e3 = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev)) == hipSuccess &&
+          (e4 = hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies)) == hipSuccess)
+        g_early_recorded = 1;
+      else {
+        (void)hipGetLastError();
+        carca_set_error("embed_bwd: no external event node in this capture (record-with-flags: %s; capture info: %s, graph %p, %zu deps; "
+                        "add node: %s; update dependencies: %s)", hipGetErrorString(e1), hipGetErrorString(e2), (void*)graph, ndeps,
+                        hipGetErrorString(e3), hipGetErrorString(e4));
+      }
+    }
   }
   return carca_gemm_wgrad(&wf, stream);
 }

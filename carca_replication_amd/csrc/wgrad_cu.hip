@@ -100,12 +100,15 @@ struct WgRanges {
   }
 };
 
-// ONE 1024-thread block: per segment, a block-wide scan of the rows that take part, their three byte offsets written
-// back to back from the segment's first chunk on, the last chunk padded with "no row" entries; then the plan and the groups'
-// unit ranges.  (19,200 rows at C2: ~6 us, as long as the one-entry-per-thread kernel it replaces.)
+// ONE 1024-thread block.  Per segment the rows go by in super-tiles of 8192 (row = base + 1024 j + tid, j < 8): all of a
+// thread's ids are requested at once, every (j, wave) counts its rows that take part with a ballot, ONE barrier later each
+// thread knows where its rows land -- the three byte offsets of a kept row are written back to back from the segment's
+// first chunk on, the last chunk is padded with "no row" entries; then the plan and the groups' unit ranges.
+// (19,200 rows at C2: three super-tiles, ~6 us; a first version with a contiguous run of rows per thread took 27 us: two
+// passes of dependent id loads.)
 __global__ __launch_bounds__(1024) void wgrad_rowtab_kernel(const WgradCuDev args, unsigned* tab) {
-  __shared__ int wsum[16];
-  __shared__ int s_kept;
+  constexpr int PER = 8;
+  __shared__ int wcnt[PER][16];
   __shared__ WgPlan plan;
   const CarcaWgradDesc& D = args.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,58 +117,71 @@ __global__ __launch_bounds__(1024) void wgrad_rowtab_kernel(const WgradCuDev arg
   for (int s = 0; s < D.nseg; ++s) {
     const CarcaWgradSeg sg = D.seg[s];
     const int T = sg.T >= 1 ? sg.T : 1;
-    const int per = (sg.rows + 1023) / 1024;
-    const int r0 = min(tid * per, sg.rows), r1 = min(r0 + per, sg.rows);
-    auto masked = [&](int row) { return D.mask_rows && sg.ids && sg.ids[row] == 0; };
-    int cnt = 0;
-    for (int row = r0; row < r1; ++row) cnt += (args.compact && masked(row)) ? 0 : 1;
-    // exclusive scan of cnt over the block: inside the wave by shuffles, across the sixteen waves through LDS
-    int incl = cnt;
+    int kept_seg = 0;  // rows of this segment placed so far (block-uniform)
+    for (int base = 0; base < sg.rows; base += 1024 * PER) {
+      int id[PER];
+      bool in[PER], keep[PER];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int before = 0;
-    for (int w = 0; w < wave; ++w) before += wsum[w];
-    if (tid == 1023) s_kept = before + incl;
-    __syncthreads();
-    const int kept = s_kept;
-    int v = chunk0 * WG_BR + before + incl - cnt;
-    for (int row = r0; row < r1; ++row) {
-      const bool m = masked(row);
-      if (args.compact && m) continue;
-      unsigned yo = WG_INV, xo = WG_INV, x1o = WG_INV;
-      if (!m) {
-        const int id = sg.ids ? sg.ids[row] : 1;
-        yo = (unsigned)((size_t)row * D.ld_dy * sizeof(float));
-        const size_t xe = sg.x_gather ? (size_t)id * D.ld_x
-                          : sg.x_bstride ? (size_t)(row / T) * sg.x_bstride + (size_t)(row % T) * D.ld_x
-                                         : (size_t)row * D.ld_x;
-        xo = (unsigned)(xe * sizeof(float));
-        if (D.K1 > 0) {
-          const size_t x1e = sg.x1_bstride ? (size_t)(row / T) * sg.x1_bstride + (size_t)(row % T) * D.ld_x1
-                                           : (size_t)row * D.ld_x1;
-          x1o = (unsigned)(x1e * sizeof(float));
-        }
+      for (int j = 0; j < PER; ++j) {
+        const int row = base + 1024 * j + tid;
+        in[j] = row < sg.rows;
+        id[j] = (in[j] && sg.ids) ? sg.ids[row] : 1;
       }
-      tab[v] = yo;
-      tab[args.V + v] = xo;
-      tab[2 * args.V + v] = x1o;
-      ++v;
+      unsigned long long bal[PER];
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const bool m = D.mask_rows && sg.ids && id[j] == 0;
+        keep[j] = in[j] && !(args.compact && m);
+        bal[j] = __ballot(keep[j]);
+        if (lane == 0) wcnt[j][wave] = __popcll(bal[j]);
+      }
+      __syncthreads();
+      int before = kept_seg, total = 0;  // rows placed ahead of (j, wave), rows of the whole super-tile
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        int upto = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+          const int c = wcnt[j][w];
+          upto += w < wave ? c : 0;
+          all += c;
+        }
+        if (keep[j]) {
+          const int row = base + 1024 * j + tid;
+          const int v = chunk0 * WG_BR + before + total + upto + __popcll(bal[j] & ((1ull << lane) - 1));
+          const bool m = D.mask_rows && sg.ids && id[j] == 0;
+          unsigned yo = WG_INV, xo = WG_INV, x1o = WG_INV;
+          if (!m) {
+            yo = (unsigned)((size_t)row * D.ld_dy * sizeof(float));
+            const size_t xe = sg.x_gather ? (size_t)id[j] * D.ld_x
+                              : sg.x_bstride ? (size_t)(row / T) * sg.x_bstride + (size_t)(row % T) * D.ld_x
+                                             : (size_t)row * D.ld_x;
+            xo = (unsigned)(xe * sizeof(float));
+            if (D.K1 > 0) {
+              const size_t x1e = sg.x1_bstride ? (size_t)(row / T) * sg.x1_bstride + (size_t)(row % T) * D.ld_x1
+                                               : (size_t)row * D.ld_x1;
+              x1o = (unsigned)(x1e * sizeof(float));
+            }
+          }
+          tab[v] = yo;
+          tab[args.V + v] = xo;
+          tab[2 * args.V + v] = x1o;
+        }
+        total += all;
+      }
+      kept_seg += total;
+      __syncthreads();  // (wcnt is rewritten by the next super-tile / segment)
     }
-    const int chunks = (kept + WG_BR - 1) / WG_BR;
-    for (int p = chunk0 * WG_BR + kept + tid; p < (chunk0 + chunks) * WG_BR; p += 1024) {  // the last chunk's tail
+    const int chunks = (kept_seg + WG_BR - 1) / WG_BR;
+    for (int p = chunk0 * WG_BR + kept_seg + tid; p < (chunk0 + chunks) * WG_BR; p += 1024) {  // the last chunk's tail
       tab[p] = WG_INV;
       tab[args.V + p] = WG_INV;
       tab[2 * args.V + p] = WG_INV;
     }
     chunk0 += chunks;
     if (tid == 0) plan.chunk_start[s + 1] = chunk0;
-    __syncthreads();  // (wsum / s_kept are reused by the next segment)
   }
+  __syncthreads();
   if (tid == 0) {
     for (int s = D.nseg + 1; s <= CARCA_MAX_SEGS; ++s) plan.chunk_start[s] = chunk0;
     const long total = (long)args.nkb * chunk0;

@@ -181,8 +181,11 @@ class GraphedTrainStep:
     them back skips the copy (dense C2 batches are 315 MB: ~0.1 ms of HBM time per step; ids-only batches over a registered
     attribute table are a few hundred KB).
     sharded=True (users sharded over ranks): the graph holds forward + backward normalised by a device scalar that every
-    call refills with the all-reduced mask count; the gradient all-reduce (in place, not overlapped here) and the
-    optimizer run behind each replay, outside the graph.
+    call refills with the all-reduced mask count; the gradient all-reduce (in place) and the optimizer run behind each
+    replay, outside the graph.  The EARLY range of the gradients (everything but feats_embed.{weight, bias}) is reduced
+    under the graph's last kernel, as in the eager sharded step: the capture holds an external event-record node right in
+    front of that kernel (CarcaEmbedBwdDesc.ev_early, hipEventRecordExternal), every replay records the event there, and
+    a side stream outside the graph waits on it and issues the all-reduce of the early range.
     Dropout: the seeds are launch arguments, which a replay repeats; the graph's first node increments a device counter
     that every dropout kernel adds to its seed (ops.set_dropout_seed_offset), so replay t draws the masks an eager step
     with seed + t would."""
@@ -202,10 +205,13 @@ class GraphedTrainStep:
                 (self.inputs[0].numel() + self.inputs[3].numel())
             self.foreign = torch.zeros(cdist.world_size() * per_rank, dtype=torch.int32, device=self.inputs[0].device)
             model.__dict__["_grad_foreign"] = self.foreign
+        # (the early-gradients event: not in deterministic mode, whose sums sit in the fixed-point shadow until the pass ends)
+        self.ev_early = ops.HipEvent() if (sharded and self.inputs[0].is_cuda and not ops.deterministic()) else None
         self.replays = torch.zeros(1, dtype=torch.int64, device=self.inputs[0].device)
         # (a model without dropout draws no masks: no counter node in its graph -- 4.6 us per replay)
         has_dropout = any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in model.modules())
         ops.set_dropout_seed_offset(self.replays)
+        ops.early_event = self.ev_early
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -223,8 +229,15 @@ class GraphedTrainStep:
                     self.replays.add_(1)
                 self.loss = _forward_backward(model, optim, self.inputs, self.denom)
             self.library_bytes = ops.capture_bytes(self.scope)
+            if self.ev_early is not None:
+                from . import _lib
+
+                if not _lib.load().carca_early_event_recorded():  # (this HIP runtime adds no external event node)
+                    self.ev_early = None
+                    self.ev_early_note = _lib.load().carca_last_error().decode(errors="replace")
         finally:
             ops.set_dropout_seed_offset(None)
+            ops.early_event = None
         # The replayed backward writes into the gradient tensors of the capture.  An eager step in between (train() sends
         # the short last batch of an epoch through train_step) rebinds every p.grad to fresh memory: remember the graph's
         # own tensors and hand them back to the parameters before each optimizer step.
@@ -262,9 +275,19 @@ class GraphedTrainStep:
                 p.grad = g
         gathered = None
         if self.sharded:
+            info = cdist.flat_layout(self.model, self.params)
+            early = None
+            if cdist._active() and info is not None and self.ev_early is not None and info["late"][1] > info["late"][0]:
+                # the replay just queued records ev_early in front of its last kernel: the early range goes out under it
+                side = _side_stream(self.inputs[0].device)
+                from . import _lib
+
+                _lib.check(_lib.load().carca_stream_wait_event(side.cuda_stream, self.ev_early.handle), "stream_wait_event")
+                with torch.cuda.stream(side):
+                    early = cdist.allreduce_range(info["flat"], *info["early"])
             gathered = cdist.allreduce_gradients(
                 self.params, sparse_rows=_sparse_tables(self.model, self.inputs[0], self.inputs[3]),
-                flat_info=cdist.flat_layout(self.model, self.params),
+                flat_info=info, early_work=early,
                 sparse_pad_to=_row_exchange_len(self.inputs[0], self.inputs[3], self.global_batch))
             if self.foreign is not None:
                 self.model.__dict__["_grad_foreign"] = self.foreign

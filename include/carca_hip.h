@@ -546,6 +546,10 @@ typedef struct CarcaEmbedBwdDesc {
 } CarcaEmbedBwdDesc;
 size_t carca_embed_bwd_workspace(const int32_t* rows /*host [nseg]*/, int nseg, int d, int g);
 int carca_embed_bwd(const CarcaEmbedBwdDesc* desc /*host*/, void* stream);
+/* 1 when this thread's last carca_embed_bwd call with an ev_early recorded it.  On a stream that is being captured the
+ * record is an EXTERNAL event-record node (every replay records the event in front of its last kernel); a HIP runtime that
+ * offers no way to add one leaves the event alone and this returns 0: reduce the early range behind the replay then. */
+int carca_early_event_recorded(void);
 
 /* ---- f3: the optimizer step of the train driver (training.py:174, train.py:96) -------------------------------
  * torch.optim.Adam's update (no amsgrad; weight_decay added to the gradient) for every tensor of the table in one

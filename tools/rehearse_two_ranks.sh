@@ -15,6 +15,7 @@ timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 
   tools/two_rank_check.py 2>&1 | grep -v "amdgpu.ids" | tee "$LOG"
 rc=${PIPESTATUS[0]}
 [ "$rc" -eq 0 ] || { echo "two-rank check FAILED (rc $rc)" | tee -a "$LOG"; exit "$rc"; }
-timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
-  bench.py --gpus 2 --steps 10 --warmup 3 --no-fold --no-table --train-steps 6 2>&1 | grep -v "amdgpu.ids" | tee -a "$LOG"
+# (the PLAIN invocation: no WORLD_SIZE in the environment -- bench.py starts torch.distributed.run itself, as a child process)
+echo "== python bench.py --gpus 2 (launches its own ranks) ==" | tee -a "$LOG"
+timeout -k 10 500 python bench.py --gpus 2 --steps 10 --warmup 3 --no-fold --no-table --no-split --train-steps 6 2>&1 | grep -v "amdgpu.ids" | tee -a "$LOG"
 exit "${PIPESTATUS[0]}"
