@@ -48,6 +48,54 @@ struct GemmDev {
   int sk_withhold;   // TEST ONLY (tuning key 13): 1 + index of the one flag its giver does not raise; 0 = none
 };
 
+// The item-row gather (carca.py:87-88) as the PASSENGER workgroup of gemm_rows_sk_kernel, through LDS-DMA.  carca_gather_rows
+// keeps its rows in registers and the compiler serialises them beyond ~16 in flight (a lone workgroup: ~455 us for C2's
+// 19 k rows, longer than the product it rides in).  Here a wave requests R rows -- each one or two buffer_load ... lds of 64
+// dwords, no destination registers, the row's table address in the scalar resource -- waits once, and copies them out of
+// LDS scaled; the ids of the next batch are requested right behind the rows of this one.  12 waves x 24 rows x 360 bytes in
+// flight: ~100 us of a CU that has nothing else to do, beside a 515 us product.
+template <int R, int RS>
+__device__ __forceinline__ void gather_rows_dma(const CarcaGatherArgs& ga, float* lds, const int wave, const int nwaves,
+                                                const int lane) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  float* my = lds + wave * (R * RS);
+  const int nb = (ga.total_rows + R - 1) / R;
+  auto id_of = [&](int b) -> int {
+    const int row = min(b * R + min(lane, R - 1), ga.total_rows - 1);
+    int s = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      if (j < ga.nseg && row >= ga.row_start[j]) s = j;
+    return ga.ids[s][row - ga.row_start[s]];
+  };
+  const unsigned v0 = (unsigned)min(lane, ga.d - 1) * 4u, v1 = (unsigned)min(64 + lane, ga.d - 1) * 4u;
+  const bool second = ga.d > 64 && lane < RS - 64;
+  int idv = id_of(wave);
+  for (int b = wave; b < nb; b += nwaves) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int id = __builtin_amdgcn_readlane(idv, i);
+      const __amdgpu_buffer_rsrc_t rs = carca_rsrc(ga.items_w + (size_t)id * ga.d);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(my + i * RS), 4, v0, 0, 0, 0);
+      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(my + i * RS + 64), 4, v1, 0, 0, 0);
+    }
+    // (the next batch's ids BEHIND the rows: the compiler drains every outstanding load before an LDS-DMA instruction)
+    const int idn = b + nwaves < nb ? id_of(b + nwaves) : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int row = b * R + i;
+      if (row < ga.total_rows) {
+        float* dst = ga.zq + (size_t)row * ga.ldz;
+        if (lane < ga.d) dst[lane] = my[i * RS + lane] * ga.scale;
+        if (RS > 64 && lane < RS - 64 && 64 + lane < ga.d) dst[64 + lane] = my[i * RS + 64 + lane] * ga.scale;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this batch has left LDS before the next one's rows are requested)
+    idv = idn;
+  }
+}
+
 template <int BM, int BN, int BK, int PF = 1, bool BUF = false>
 __device__ __forceinline__ void gemm_rows_body(const GemmDev& args, const int id) {
   constexpr int NW = BM / 32, NT = NW * 64, LS = BK + 4, TN = BN / 32;
@@ -840,7 +888,12 @@ __global__ __launch_bounds__(768) void gemm_rows_sk_kernel(const GemmDev args) {
   const CarcaGemmDesc& D = args.d;
   const int id = blockIdx.x, total = args.nrb * args.ncb;
   if (args.has_pas && id == total) {
-    carca_gather_rows<16>(args.pas, (int)threadIdx.x >> 6, 12, (int)threadIdx.x & 63);
+    static_assert(12 * 24 * 96 <= 2 * 384 * 36 && 12 * 18 * 128 <= 2 * 384 * 36, "the passenger's rows fit the A buffers");
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (args.pas.d <= 96)
+      gather_rows_dma<24, 96>(args.pas, As, wave, 12, (int)threadIdx.x & 63);
+    else
+      gather_rows_dma<18, 128>(args.pas, As, wave, 12, (int)threadIdx.x & 63);
     return;
   }
   const int xcd = id & 7, q8 = total >> 3, r8 = total & 7;
@@ -1423,12 +1476,15 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   if (carca_tuning(CARCA_TUNE_SK_DON) > 0) don = carca_tuning(CARCA_TUNE_SK_DON);
   if (don < 1 || don >= nfast) return 1;
   g.sk_don = don;
-  // The item-row gather does NOT ride in this launch (rode stays 0: the caller launches it, 8 us): the lone passenger
-  // workgroup is a latency chain of ~100 rounds that takes ~455 us on an idle chip and ~540 us beside the tiles -- invisible
-  // under gemm_rows_cu_kernel's 535 us, the long pole here (measured: 0.640 ms per forward with it, 0.614 without; more
-  // rows or both 64-column pieces in flight made the compiler serialise the loads: 1.2 / 0.74 ms).
-  (void)pas;
-  (void)rode;
+  // The item-row gather rides as workgroup `grid` on the CU the tiles leave idle (gather_rows_dma: ~100 us; the register
+  // version measured ~540 us beside the tiles and was the launch's long pole: 0.640 ms per forward against 0.614).
+  // Tuning variant 19: the gather keeps its own launch (A/B switch).
+  if (pas && grid < carca_num_cus() && pas->d <= 128 && variant != 19) {
+    g.has_pas = 1;
+    g.pas = *pas;
+    ++grid;
+    if (rode) *rode = 1;
+  }
   if (!g_sk_err_host) {
     if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped) != hipSuccess) return 1;
     *g_sk_err_host = 0;
