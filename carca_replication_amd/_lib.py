@@ -283,6 +283,10 @@ SIGNATURES = {
     "carca_mha_core": (_i, [_fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp]),
     "carca_mha_core_bwd": (_i, [_fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _fp,
                                 _fp]),
+    "carca_mha_core_drop": (_i, [_fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _i, _fp, C.POINTER(Dropout),
+                                 _fp, _fp]),
+    "carca_mha_core_bwd_drop": (_i, [_fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _fp,
+                                     _fp, C.c_float, _fp]),
     "carca_knn_score": (_i, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _i, _fp, _i, _i, _i, _i, _fp]),
     "carca_sa_block_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i]),
     "carca_sa_block_bwd": (_i, [C.POINTER(SaBwdDesc), C.POINTER(WgradDesc), C.POINTER(_i), _fp]),

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
                                                        const float* __restrict__ v, int ldk,
                                                        const int32_t* __restrict__ q_ids, const int32_t* __restrict__ k_ids,
                                                        int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
-                                                       float* __restrict__ out, int ldo, float* __restrict__ w_out) {
+                                                       float* __restrict__ out, int ldo, float* __restrict__ w_out,
+                                                       DropCfg drop, unsigned site, unsigned char* __restrict__ m_out) {
+  drop = drop_resolve(drop);
   const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wid >= (long)B * H * Tq) return;
@@ -230,7 +232,13 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
     const int j = lane + 64 * i;
     if (j < Tk) {
       sc[i] = ok[i] ? sc[i] / sum : 0.f;  // softmax, then "* attn_mask" (carca.py:256)
-      if (w_out) w_out[(((long)h * B + b) * Tq + t) * Tk + j] = sc[i];
+      if (w_out) w_out[(((long)h * B + b) * Tq + t) * Tk + j] = sc[i];  // (before dropout, carca.py:262-263)
+      if (drop.thresh) {  // nn.Dropout on the weights (carca.py:258): element (b, h, t, j) of the site
+        const long e = (((long)b * H + h) * Tq + t) * Tk + j;
+        const bool keep = drop_keep(drop, site, (unsigned)e);
+        if (m_out) m_out[e] = keep ? 1 : 0;
+        sc[i] = keep ? sc[i] * drop.scale : 0.f;
+      }
     }
   }
   // out[c] = sum_j W[j] v[j][c]: a lane owns the head's columns lane and lane + 64; the weights travel by shuffle, which
@@ -259,7 +267,8 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restri
                                                            int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
                                                            const float* __restrict__ d_out, int ldo,
                                                            const float* __restrict__ d_w, float* __restrict__ dq,
-                                                           float* __restrict__ dk, float* __restrict__ dv) {
+                                                           float* __restrict__ dk, float* __restrict__ dv,
+                                                           const unsigned char* __restrict__ keep, float keep_scale) {
   const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wid >= (long)B * H * Tq) return;
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restri
   const float* dor = d_out ? d_out + ((long)b * Tq + t) * ldo + h * dh : nullptr;
   const bool q_ok = q_ids[(long)b * Tq + t] != 0;
   const float sqrt_dh = sqrtf((float)dh);
-  float sc[MHA_KPL], dwj[MHA_KPL];
+  float sc[MHA_KPL], dwj[MHA_KPL], mj[MHA_KPL];  // mj: the dropout multiplier of weight j (keep / (1 - p), 1 without dropout)
   bool ok[MHA_KPL];
   float mx = -3.0e38f;
 #pragma unroll
@@ -279,6 +288,7 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restri
     const int j = lane + 64 * i;
     sc[i] = -3.0e38f;
     dwj[i] = 0.f;
+    mj[i] = 1.f;
     ok[i] = false;
     if (j < Tk) {
       const float* kr = k + ((long)b * Tk + j) * ldk + h * dh;
@@ -291,6 +301,10 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restri
       ok[i] = q_ok && k_ids[(long)b * Tk + j] != 0 && (!has_causal || j - t <= causal);
       sc[i] = ((ok[i] ? 0.0f : -4294967296.0f) + dot) / sqrt_dh;
       mx = fmaxf(mx, sc[i]);
+      if (keep) {
+        mj[i] = keep[(((long)b * H + h) * Tq + t) * Tk + j] ? keep_scale : 0.f;
+        dd *= mj[i];  // (out = (W * m) v: d out / d W_j carries the multiplier; the returned weights are pre-dropout)
+      }
       if (d_w) dd += d_w[(((long)h * B + b) * Tq + t) * Tk + j];
       dwj[i] = dd;
     }
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < MHA_KPL; ++i)
     for (int l = 0; l < 64 && l + 64 * i < Tk; ++l) {
-      const float dsj = __shfl(ds[i], l), wj = __shfl(sc[i], l);
+      const float dsj = __shfl(ds[i], l), wj = __shfl(sc[i] * mj[i], l);
       if (dsj == 0.f && wj == 0.f) continue;  // (uniform: the shuffled values are the same in every lane)
       const long krow = ((long)b * Tk + l + 64 * i) * ldk + h * dh;
       if (lane < dh) {
@@ -435,25 +449,35 @@ extern "C" int carca_add_positions(const float* x, int ldx, const float* pos, fl
   return CARCA_OK;
 }
 
-extern "C" int carca_mha_core(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
-                              const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
-                              float* out, int ldo, float* w_out, void* stream_) {
+extern "C" int carca_mha_core_drop(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
+                                   const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
+                                   float* out, int ldo, float* w_out, const CarcaDropout* drop, uint8_t* keep_out,
+                                   void* stream_) {
   CARCA_CHECK_ARG(q && k && v && q_ids && k_ids && out, "mha_core: null pointer");
   CARCA_CHECK_ARG(B >= 1 && Tq >= 1 && Tk >= 1 && d >= 1 && H >= 1 && d % H == 0 && ldq >= d && ldk >= d && ldo >= d,
                   "mha_core: bad dims");
   CARCA_CHECK_SUPPORTED(Tk <= 64 * MHA_KPL && d / H <= 128, "mha_core: Tk=%d > %d keys per query, or d/H=%d > 128", Tk,
                         64 * MHA_KPL, d / H);
+  CARCA_CHECK_ARG(!(drop && drop->p > 0.f) || (drop->p < 1.f), "mha_core: dropout p must be < 1");
   const long waves = (long)B * H * Tq;
   hipLaunchKernelGGL(mha_core_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, q, ldq, k, v, ldk,
-                     q_ids, k_ids, B, Tq, Tk, d, H, has_causal, causal, out, ldo, w_out);
+                     q_ids, k_ids, B, Tq, Tk, d, H, has_causal, causal, out, ldo, w_out, make_drop(drop),
+                     drop ? drop->site : 0u, keep_out);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
 
-extern "C" int carca_mha_core_bwd(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
-                                  const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
-                                  const float* d_out, int ldo, const float* d_w, float* dq, float* dk, float* dv,
-                                  void* stream_) {
+extern "C" int carca_mha_core(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
+                              const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
+                              float* out, int ldo, float* w_out, void* stream_) {
+  return carca_mha_core_drop(q, ldq, k, v, ldk, q_ids, k_ids, B, Tq, Tk, d, H, has_causal, causal, out, ldo, w_out, nullptr,
+                             nullptr, stream_);
+}
+
+extern "C" int carca_mha_core_bwd_drop(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
+                                       const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
+                                       const float* d_out, int ldo, const float* d_w, float* dq, float* dk, float* dv,
+                                       const uint8_t* keep, float keep_scale, void* stream_) {
   CARCA_CHECK_ARG(q && k && v && q_ids && k_ids && (d_out || d_w) && dq && dk && dv, "mha_core_bwd: null pointer");
   CARCA_CHECK_ARG(B >= 1 && Tq >= 1 && Tk >= 1 && d >= 1 && H >= 1 && d % H == 0 && ldq >= d && ldk >= d &&
                       (!d_out || ldo >= d),
@@ -462,7 +486,15 @@ extern "C" int carca_mha_core_bwd(const float* q, int ldq, const float* k, const
                         64 * MHA_KPL, d / H);
   const long waves = (long)B * H * Tq;
   hipLaunchKernelGGL(mha_core_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, q, ldq, k, v,
-                     ldk, q_ids, k_ids, B, Tq, Tk, d, H, has_causal, causal, d_out, ldo, d_w, dq, dk, dv);
+                     ldk, q_ids, k_ids, B, Tq, Tk, d, H, has_causal, causal, d_out, ldo, d_w, dq, dk, dv, keep, keep_scale);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
+}
+
+extern "C" int carca_mha_core_bwd(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
+                                  const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal,
+                                  const float* d_out, int ldo, const float* d_w, float* dq, float* dk, float* dv,
+                                  void* stream_) {
+  return carca_mha_core_bwd_drop(q, ldq, k, v, ldk, q_ids, k_ids, B, Tq, Tk, d, H, has_causal, causal, d_out, ldo, d_w, dq, dk,
+                                 dv, nullptr, 1.0f, stream_);
 }

@@ -810,6 +810,10 @@ class SelfAttentionBlock(_PackedModule, Encoder):
     def forward(self, x: Tensor, mask: Tensor) -> Tensor:
         """x [B, L, >=d], mask [B, L] (0 = pad) -> [B, L, d] (a view of a padded buffer)."""
         self._check_mode()
+        if x.shape[1] > _lib.MAX_L:
+            from . import long_profile
+
+            return long_profile.sa_block(self, x[..., : self.attn.d], mask != 0, ops.new_dropout_seed() if self.training else 0)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import sa_block_with_grad
 
@@ -878,6 +882,12 @@ class CrossAttentionBlock(_PackedModule, Decoder):
     def forward(self, o: Tensor, o_mask: Tensor, p: Tensor, p_mask: Tensor) -> Tensor:
         """Standalone decoder call: p is already final-normed (as in carca.py:421-428)."""
         self._check_mode()
+        if p.shape[1] > _lib.MAX_L:
+            from . import long_profile
+
+            d = self.attn.d
+            return long_profile.cross_block(self, o[..., :d], o_mask != 0, p[..., :d], p_mask != 0,
+                                            ops.new_dropout_seed() if self.training else 0).squeeze()
         if torch.is_grad_enabled() and (o.requires_grad or p.requires_grad or
                                         any(q.requires_grad for q in self.parameters())):
             from .autograd import cross_with_grad
@@ -946,7 +956,13 @@ class CARCA(_PackedModule, Model):
     def forward(self, profile: Tuple[Tensor, Tensor, Tensor], targets: List[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
         self._check_built()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in cached_parameters(self))
-        if needs_grad:
+        if profile[0].shape[1] > _lib.MAX_L or len(targets) > _lib.MAX_GROUPS:
+            # longer than the fused kernels' 64 profile slots (or more target groups than one fused call takes, carca.py:424):
+            # the same arithmetic from the row-level kernels
+            from . import long_profile
+
+            ys = long_profile.forward(self, profile, targets)
+        elif needs_grad:
             from .autograd import carca_forward_with_grad
 
             ys = carca_forward_with_grad(self, profile, targets)
@@ -1128,8 +1144,10 @@ class CARCA(_PackedModule, Model):
 
     def forward_nograd(self, profile, targets, trace: Optional[dict] = None) -> List[Tensor]:
         p_x, p_a, p_c = profile
-        if len(targets) > _lib.MAX_GROUPS:
-            raise CarcaHipError(f"at most {_lib.MAX_GROUPS} target groups per call")
+        if p_x.shape[1] > _lib.MAX_L or len(targets) > _lib.MAX_GROUPS:
+            from . import long_profile
+
+            return long_profile.forward(self, profile, targets, trace)
         if self._fused_ok(trace):
             return self._forward_fused(profile, targets, events=ops.fused_events())
         d = self.embeds.d

@@ -933,8 +933,10 @@ def add_positions(x: Tensor, pos: Tensor) -> Tensor:
 
 
 def mha_core(q: Tensor, k: Tensor, v: Tensor, q_ids: Tensor, k_ids: Tensor, H: int, causal: Optional[int],
-             want_w: bool):
-    """Attention core of MultiHeadAttention.forward (carca.py:242-260) on projected q [B, Tq, d], k / v [B, Tk, d]."""
+             want_w: bool, drop: Optional[Tuple[float, int, int]] = None):
+    """Attention core of MultiHeadAttention.forward (carca.py:242-260) on projected q [B, Tq, d], k / v [B, Tk, d].
+    drop = (p, seed, site): nn.Dropout on the weights (carca.py:258); then a third value is returned, the keep-mask
+    [B, H, Tq, Tk] (uint8) the backward and the tests replay."""
     _need_cuda(q, k, v, q_ids, k_ids)
     B, Tq, d = q.shape
     Tk = k.shape[1]
@@ -944,6 +946,14 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, q_ids: Tensor, k_ids: Tensor, H: i
     qi, ki = _ids32(q_ids.reshape(-1)), _ids32(k_ids.reshape(-1))
     out = torch.empty(B, Tq, d, dtype=torch.float32, device=q.device)
     w = torch.empty(H * B, Tq, Tk, dtype=torch.float32, device=q.device) if want_w else None
+    if drop is not None and drop[0] > 0:
+        keep = torch.empty(B, H, Tq, Tk, dtype=torch.uint8, device=q.device)
+        ds = _drop_struct(*drop)
+        _lib.check(_lib.load().carca_mha_core_drop(q2.data_ptr(), q2.stride(0), k2.data_ptr(), v2.data_ptr(), k2.stride(0),
+                                                   qi.data_ptr(), ki.data_ptr(), B, Tq, Tk, d, H, int(causal is not None),
+                                                   int(causal or 0), out.data_ptr(), d, _ptr(w), C.byref(ds),
+                                                   keep.data_ptr(), _stream()), "mha_core")
+        return out, w, keep
     _lib.check(_lib.load().carca_mha_core(q2.data_ptr(), q2.stride(0), k2.data_ptr(), v2.data_ptr(), k2.stride(0),
                                           qi.data_ptr(), ki.data_ptr(), B, Tq, Tk, d, H, int(causal is not None),
                                           int(causal or 0), out.data_ptr(), d, _ptr(w), _stream()), "mha_core")
@@ -951,8 +961,9 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, q_ids: Tensor, k_ids: Tensor, H: i
 
 
 def mha_core_bwd(q: Tensor, k: Tensor, v: Tensor, q_ids: Tensor, k_ids: Tensor, H: int, causal: Optional[int],
-                 d_out: Optional[Tensor], d_w: Optional[Tensor]):
-    """Backward of mha_core: (dq, dk, dv) for projected q [B, Tq, d], k / v [B, Tk, d]."""
+                 d_out: Optional[Tensor], d_w: Optional[Tensor], keep: Optional[Tensor] = None, p: float = 0.0):
+    """Backward of mha_core: (dq, dk, dv) for projected q [B, Tq, d], k / v [B, Tk, d]; keep / p: the forward's keep-mask
+    and dropout probability."""
     B, Tq, d = q.shape
     Tk = k.shape[1]
     q2, k2, v2 = (_f32(t).reshape(-1, d).contiguous() for t in (q, k, v))
@@ -962,9 +973,10 @@ def mha_core_bwd(q: Tensor, k: Tensor, v: Tensor, q_ids: Tensor, k_ids: Tensor, 
     dq = torch.empty(B * Tq, d, dtype=torch.float32, device=q.device)
     dk = torch.zeros(B * Tk, d, dtype=torch.float32, device=q.device)
     dv = torch.zeros(B * Tk, d, dtype=torch.float32, device=q.device)
-    _lib.check(_lib.load().carca_mha_core_bwd(q2.data_ptr(), d, k2.data_ptr(), v2.data_ptr(), d, qi.data_ptr(), ki.data_ptr(),
-                                              B, Tq, Tk, d, H, int(causal is not None), int(causal or 0), _ptr(do), d,
-                                              _ptr(dw), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _stream()),
+    _lib.check(_lib.load().carca_mha_core_bwd_drop(q2.data_ptr(), d, k2.data_ptr(), v2.data_ptr(), d, qi.data_ptr(),
+                                                   ki.data_ptr(), B, Tq, Tk, d, H, int(causal is not None), int(causal or 0),
+                                                   _ptr(do), d, _ptr(dw), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                                   _ptr(keep), 1.0 / (1.0 - p) if keep is not None else 1.0, _stream()),
                "mha_core_bwd")
     return dq.view(B, Tq, d), dk.view(B, Tk, d), dv.view(B, Tk, d)
 
