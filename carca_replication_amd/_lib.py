@@ -283,6 +283,7 @@ SIGNATURES = {
     "carca_mha_core": (_i, [_fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp]),
     "carca_mha_core_bwd": (_i, [_fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _fp,
                                 _fp]),
+    "carca_gemm_rows_log": (_i, [C.c_char_p, _i]),
     "carca_mha_core_drop": (_i, [_fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _i, _fp, C.POINTER(Dropout),
                                  _fp, _fp]),
     "carca_mha_core_bwd_drop": (_i, [_fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _fp,

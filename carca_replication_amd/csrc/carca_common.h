@@ -220,7 +220,8 @@ bool carca_stream_capturing(hipStream_t stream);
 //    (a replay runs without the host code that would pick a buffer, and captures may replay side by side).  It is
 //    accounted to the capture's id (carca_capture_scope) and freed by carca_capture_release once the graph is gone.
 void* carca_stream_scratch(hipStream_t stream, int tag, size_t bytes, size_t zero_bytes = 0, bool* fresh = nullptr);
-enum { CARCA_SCRATCH_SK = 1, CARCA_SCRATCH_WPART = 2, CARCA_SCRATCH_WTAB = 3, CARCA_SCRATCH_SPLITW = 4 };
+enum { CARCA_SCRATCH_SK = 1, CARCA_SCRATCH_WPART = 2, CARCA_SCRATCH_WTAB = 3, CARCA_SCRATCH_SPLITW = 4, CARCA_SCRATCH_SKC = 5,
+       CARCA_SCRATCH_SKC_PART = 6 };
 void* carca_capture_alloc(hipStream_t stream, size_t bytes, bool host_mapped, void** device_view, size_t zero_bytes = 0);
 // Timing events for this thread's NEXT row-GEMM launch (the roofline hooks of carca_forward): the launch binds them to
 // its own dispatch packet (hipExtLaunchKernel), so elapsed(start, stop) is the kernel's duration and no barrier packet
@@ -228,6 +229,8 @@ void* carca_capture_alloc(hipStream_t stream, size_t bytes, bool host_mapped, vo
 void carca_arm_launch_events(void* start, void* stop);
 bool carca_take_launch_events(hipEvent_t* start, hipEvent_t* stop);  // true (and disarms) when armed
 struct CarcaGemmDesc;
+// appends to the row-GEMM kernel log while carca_gemm_rows_log has it switched on (gemm.hip)
+void carca_rows_log(const char* kernel, const CarcaGemmDesc* d, int grid);
 // the opt-in split-precision feature GEMM (gemm_split.hip, tuning key 16): CARCA_OK = launched, 1 = not its product
 int carca_gemm_rows_split_try(const CarcaGemmDesc* desc, hipStream_t stream);
 // carca_gemm_rows with the item-row gather riding along where the kernel choice leaves a CU idle; *rode tells whether

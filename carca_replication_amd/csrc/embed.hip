@@ -79,6 +79,9 @@ extern "C" int carca_embed_fwd(const CarcaRowSeg* segs, int nseg, int n_attrs, i
   fa.bt0 = feats_w; fa.ldb0 = n_attrs + n_ctx;
   fa.bt1 = feats_w + n_attrs; fa.ldb1 = n_attrs + n_ctx;
   fa.N = g; fa.ldc = ldz; fa.ncols_out = g; fa.bias = feats_b;
+  // q of a padding slot (id 0) is never used -- e is masked (carca.py:92-94), the backward sees de = 0 there --, so the
+  // product may leave those rows out (gemm_rows_skc_kernel) and write zeros instead
+  fa.mask_rows = 1;
   if ((stages & CARCA_EMBED_GATHER) && (stages & CARCA_EMBED_FEAT)) {
     // both asked for in one call: the gather rides in the feature GEMM's launch when that leaves a CU idle
     int rode = 0;

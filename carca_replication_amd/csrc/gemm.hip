@@ -27,6 +27,32 @@
 #include <vector>
 #include "../../include/carca_hip.h"
 #include "gemm_epilogue.h"
+#include <cstring>
+#include <string>
+
+// Which kernel a row product took (tools/bench_configs.py names each configuration's dominant kernel with it): while
+// switched on, every row-GEMM launch of this thread appends "kernel rows=.. N=.. K=.. grid=..;".
+static thread_local std::string g_rows_log;
+static thread_local bool g_rows_log_on = false;
+void carca_rows_log(const char* kernel, const CarcaGemmDesc* d, int grid) {
+  if (!g_rows_log_on || g_rows_log.size() > 60000) return;
+  long rows = 0;
+  for (int s = 0; s < d->nseg; ++s) rows += d->seg[s].rows;
+  char buf[256];
+  snprintf(buf, sizeof(buf), "%s rows=%ld N=%d K=%d grid=%d;", kernel, rows, d->N, d->K0 + d->K1, grid);
+  g_rows_log += buf;
+}
+extern "C" int carca_gemm_rows_log(char* out, int cap) {
+  if (!out) {  // clear and switch on (cap = 0 switches off)
+    g_rows_log.clear();
+    g_rows_log_on = cap != 0;
+    return 0;
+  }
+  const int n = (int)std::min<size_t>(g_rows_log.size(), cap > 0 ? (size_t)cap - 1 : 0);
+  memcpy(out, g_rows_log.data(), n);
+  if (cap > 0) out[n] = 0;
+  return n;
+}
 
 namespace {
 
@@ -46,7 +72,9 @@ struct GemmDev {
   int* sk_err;  // host-visible word: a taker's bounded wait expired
   unsigned sk_spin;  // the bound: sleeps of ~0.4 us a taker spends on one flag before it gives up (launcher: 2^23, ~5 s)
   int sk_withhold;   // TEST ONLY (tuning key 13): 1 + index of the one flag its giver does not raise; 0 = none
+  int skc_cheap;     // (unused)
 };
+
 
 // The item-row gather (carca.py:87-88) as the PASSENGER workgroup of gemm_rows_sk_kernel, through LDS-DMA.  carca_gather_rows
 // keeps its rows in registers and the compiler serialises them beyond ~16 in flight (a lone workgroup: ~455 us for C2's
@@ -575,11 +603,20 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
 // and add the partial in their epilogue -- which is ~0.75 of the kernel later, so nobody ever waits (the flag is there
 // for correctness).  A giver waits for nobody, every workgroup is resident (one round, one workgroup per CU): no cycle.
 // cu_tile is gemm_rows_cu_kernel's body over a K-step range [t_lo, t_hi) with the three endings.
-enum { SK_PLAIN = 0, SK_GIVE = 1, SK_TAKE = 2 };
+enum { SK_PLAIN = 0, SK_GIVE = 1, SK_TAKE = 2, SK_DYN = 3 };
+// What a tile of gemm_rows_skc_kernel adds to cu_tile's arguments (MODE == SK_DYN): the ending as a value, the number of
+// partial tiles a taker adds (those of the workgroups behind it: part / flag of the first, one slot further each), and the
+// kept rows of the tile's segment.
+struct SkcTile {
+  int mode, ntake;
+  int seg, row0, live;
+  const int* rows;
+};
 template <int TN, int XC, int MODE>
 __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__ As, float* __restrict__ Bs, const int rb,
                                         const int n0, const int t_lo, const int t_hi, const bool with_tail,
-                                        float* __restrict__ part, int* flag) {
+                                        float* __restrict__ part, int* flag, const SkcTile dyn = SkcTile{}) {
+  constexpr bool IDX = MODE == SK_DYN;  // rows through the kept-row list
   constexpr int BM = 384, BNS = 32 * TN + XC, BK = 32, NW = 12, NT = 768, LS = BK + 4, C4 = BK / 4;
   constexpr int A_PER = BM * C4 / NT, B_PER = (BNS * C4 + NT - 1) / NT;
   constexpr int A_BUF = BM * LS, B_BUF = BNS * LS;
@@ -587,11 +624,16 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
   static_assert(B_PER == 1 && 2 * B_BUF + (NT - BNS * C4) * 4 <= 2 * 96 * LS + 1024, "B tile: one slot per thread, inside the kernel's Bs");
   const CarcaGemmDesc& D = args.d;
   int s = 0;
+  if constexpr (IDX) {
+    s = dyn.seg;
+  } else {
 #pragma unroll
-  for (int i = 1; i < CARCA_MAX_SEGS; ++i)
-    if (i < D.nseg && rb >= args.rb_start[i]) s = i;
+    for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+      if (i < D.nseg && rb >= args.rb_start[i]) s = i;
+  }
   const CarcaGemmSeg sg = D.seg[s];
-  const int row0 = (rb - args.rb_start[s]) * BM;
+  const int row0 = IDX ? dyn.row0 : (rb - args.rb_start[s]) * BM;
+  const int nrows = IDX ? dyn.live : sg.rows;  // rows of the segment this kernel multiplies
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt0 = (D.K0 + BK - 1) / BK, nt1 = (D.K1 + BK - 1) / BK;
   const int ntiles = nt0 + nt1;
@@ -602,7 +644,8 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int slot = tid + i * NT, r = slot / C4, c4 = slot - r * C4;
-    const int gr = min(row0 + r, sg.rows - 1);
+    int gr = min(row0 + r, nrows - 1);
+    if constexpr (IDX) gr = dyn.rows[gr];
     const int ub = gr / sg.T, ut = gr - ub * sg.T;
     aoff0[i] = sg.a0_gather ? (size_t)sg.ids[gr] * D.lda0
                : sg.a0_bstride ? (size_t)ub * sg.a0_bstride + (size_t)ut * D.lda0
@@ -789,7 +832,8 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
     }
   }
 
-  if constexpr (MODE == SK_GIVE) {
+  const int mode = MODE == SK_DYN ? dyn.mode : MODE;
+  if (mode == SK_GIVE) {
     // the partial tile in register order (256 contiguous bytes per wave store), written through the XCD's L2 (the taker
     // may sit on another XCD), then the flag
 #pragma unroll
@@ -797,6 +841,13 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         __hip_atomic_store(&part[(tn * 16 + r) * NT + tid], acc[tn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (XC > 0) {
+#pragma unroll
+      for (int c = 0; c < XC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          __hip_atomic_store(&part[(TN * 16 + c * 4 + e) * NT + tid], xacc[c][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // (the hand-over is MI355X_MICROARCH.md's "drained sc1" form: every byte of the partial leaves through an agent-scope
     // (sc1, write-through) store, every storing wave drains its stores, the workgroup meets, THEN one lane raises the flag)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -805,7 +856,9 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
       __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  if constexpr (MODE == SK_TAKE) {
+  const int ntake = MODE == SK_DYN ? (mode == SK_TAKE ? dyn.ntake : 0) : (MODE == SK_TAKE ? 1 : 0);
+  for (int tk = 0; tk < ntake; ++tk, part += 384 * 96, ++flag) {
+    if (tk > 0) __syncthreads();  // (everybody has read the previous flag's partial before lane 0 moves on)
     if (tid == 0) {
       // (the giver is resident -- one round of workgroups -- and ends before its takers by the launcher's balance: the wait
       // is a few us.  It is BOUNDED all the same, args.sk_spin sleeps (~5 s by default): a taker that gives up says so in
@@ -832,9 +885,21 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tn][r] += part[(tn * 16 + r) * NT + tid];
+    if constexpr (XC > 0) {
+#pragma unroll
+      for (int c = 0; c < XC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xacc[c][e] += part[(TN * 16 + c * 4 + e) * NT + tid];
+    }
   }
 
   // ---- epilogue (as gemm_rows_cu_kernel) ------------------------------------------------------------
+  int erow[16];  // the output row of accumulator register r (-1: past the segment's rows)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    erow[r] = row < nrows ? (IDX ? dyn.rows[row] : row) : -1;
+  }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + tn * 32 + lr;
@@ -844,8 +909,8 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
     const float cv = (n_ok && D.colvec) ? D.colvec[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row >= sg.rows) continue;
+      const int row = erow[r];
+      if (row < 0) continue;
       float v = 0.f;
       if (n_ok) {
         v = (D.alpha != 0.f ? D.alpha * acc[tn][r] : acc[tn][r]) + bias;
@@ -857,7 +922,7 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
           const float gs = D.gate_scale != 0.f ? D.gate_scale : 1.0f;
           v *= gv > 0.f ? gs : ((gv < 0.f || !D.gate_zero_drops) ? D.gate_slope * gs : 0.f);
         }
-        if (D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;
+        if (!IDX && D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;
       }
       sg.c[(size_t)row * D.ldc + n] = v;
     }
@@ -865,16 +930,18 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
   if constexpr (XC > 0) {
     // the VALU columns: lane (lr, lh) holds row wave * 32 + lr's sum over the k quads of its half; the launcher admits
     // this kernel only for the plain epilogue (alpha, bias, row mask)
-    const int row = row0 + wave * 32 + lr;
+    int row = row0 + wave * 32 + lr;
+    const bool row_ok = row < nrows;
+    if constexpr (IDX) row = dyn.rows[min(row, nrows - 1)];
 #pragma unroll
     for (int c = 0; c < XC; ++c) {
       const float mine = (xacc[c][0] + xacc[c][1]) + (xacc[c][2] + xacc[c][3]);
       auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine), __float_as_uint(mine), false, false);
       const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
       const int n = n0 + 32 * TN + c;
-      if (lh == 0 && row < sg.rows && n < D.N) {
+      if (lh == 0 && row_ok && n < D.N) {
         float v = (D.alpha != 0.f ? D.alpha * tot : tot) + (D.bias ? D.bias[n] : 0.f);
-        if (D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;
+        if (!IDX && D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;
         sg.c[(size_t)row * D.ldc + n] = v;
       }
     }
@@ -914,6 +981,303 @@ __global__ __launch_bounds__(768) void gemm_rows_sk_kernel(const GemmDev args) {
     cu_tile<3, 0, SK_TAKE>(args, As, Bs, rb, cb * 96, 0, nfast - args.sk_don, true,
                            args.sk_part + ((size_t)rb * nfull + cb) * (384 * 96), args.sk_flag + rb * nfull + cb);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_rows_skc_kernel: the feature product over the rows that COUNT.  AllEmbedding multiplies every slot of the padded id
+// matrices (carca.py:86) and the padding's rows are zeroed two lines later (carca.py:92-94: "* mask"); with BASELINE's
+// profile lengths U{3..50} that is 47 % of the profile rows, 16 % of an evaluation batch's rows and 47 % of a training
+// batch's.  Here the row blocks are 384 KEPT rows (id != 0), and they are shared by a FIXED grid of one workgroup per CU:
+//  * every workgroup counts the kept rows itself (the ids are 77 KB at C2: one pass of ballots over them, from L2 after
+//    the first workgroup, ~3 us -- a pre-kernel that wrote the plan cost a launch and ~20 us of a single block's latency
+//    chain in front of the product) and lists the rows of ITS row blocks in LDS;
+//  * TEAMS of ncb workgroups: workgroup c of team j multiplies column block c (the narrow last one as two MFMA column
+//    tiles + VALU columns, as in gemm_rows_sk_kernel) over the stretch [j, j + 1) * total / nteams of the row blocks' K
+//    steps laid end to end -- a team's workgroups stream the same A rows at the same time through their XCD's L2 (a first
+//    version dealt the TILES' steps out workgroup by workgroup: every tile fetched its own A rows, 3 TB/s of 128-byte
+//    pieces of 16 KB-strided rows, and the kernel turned memory-bound: 501 us against 480);
+//  * a stretch starts in the middle of a row block (its first piece: a partial tile handed to the block's owner team,
+//    computed FIRST), runs over whole row blocks, and ends in the head of one (the team owns it: computed LAST, the
+//    partial tiles of the teams behind it added).  Givers never wait, every workgroup is resident: no cycle; a taker
+//    finds partials written most of a kernel ago.
+// Left-out rows of the output are cleared (each workgroup its share).  Results: the same sums as gemm_rows_sk_kernel in
+// another grouping of the K range (1e-7 relative), the same bits from run to run.
+constexpr int SKC_RB = 6;       // row blocks one workgroup's stretch may touch (the launcher checks rows against it)
+constexpr int SKC_CH = 2304;    // 64-row chunks of all segments (+ one entry per segment)
+
+template <int XC>
+__global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) {
+  __shared__ __attribute__((aligned(16))) float As[2 * 384 * 36];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * 96 * 36 + 1024];
+  __shared__ int Rl[SKC_RB * 384];  // kept rows of this workgroup's row blocks
+  __shared__ int Cp[SKC_CH];        // kept rows before each 64-row chunk of its segment (+ the segment's total)
+  __shared__ int Pc[8 * SKC_RB + 4];  // this workgroup's pieces (step 5)
+  const CarcaGemmDesc& D = args.d;
+  const int id = blockIdx.x, nblk = gridDim.x - args.has_pas;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (args.has_pas && id == nblk) {
+    if (args.pas.d <= 96)
+      gather_rows_dma<24, 96>(args.pas, As, wave, 12, lane);
+    else
+      gather_rows_dma<18, 128>(args.pas, As, wave, 12, lane);
+    return;
+  }
+  // (tools/stamp_skc.py: wall-clock stamps of workgroup `id`, 100 MHz, behind the other kernels' 64 k entries -- start, after
+  // steps 1 / 2 / 4, around each piece)
+#define SKC_STAMP(k) do { if (args.dbg && tid == 0) args.dbg[65536 + id * 16 + (k)] = wall_clock64(); } while (0)
+  SKC_STAMP(0);
+  // ---- 1. kept rows per 64-row chunk ----------------------------------------------------------------------------
+  // (first chunk entry / first global row of segment s: running sums over at most four segments, recomputed where needed --
+  // arrays indexed by a run-time s would live in scratch)
+  auto seg_cbase = [&](int s) {
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < CARCA_MAX_SEGS; ++i)
+      if (i < s) v += (D.seg[i].rows + 63) / 64 + 1;
+    return v;
+  };
+  auto seg_roff = [&](int s) {
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < CARCA_MAX_SEGS; ++i)
+      if (i < s) v += D.seg[i].rows;
+    return v;
+  };
+  const unsigned long long below = (1ull << lane) - 1;
+#pragma unroll 1
+  for (int s = 0; s < D.nseg; ++s) {
+    const int rows = D.seg[s].rows, nch = (rows + 63) / 64, cb0 = seg_cbase(s);
+    const int32_t* __restrict__ ids = D.seg[s].ids;
+    // (32 chunks' ids requested together, in four groups of eight dealt round the waves: one chunk at a time is a dependent
+    // load per iteration, ~19 us at C2; the loop body stays small -- unrolled over segments with the clearing inside it was
+    // 100 KB of code run once, 13 us of instruction fetch)
+#pragma unroll 1
+    for (int r0 = 0; r0 < nch; r0 += 12 * 32) {
+      int idv[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const int row = (r0 + ((u >> 3) * 12 + wave) * 8 + (u & 7)) * 64 + lane;
+        idv[u] = row < rows ? ids[row] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const int c = r0 + ((u >> 3) * 12 + wave) * 8 + (u & 7);
+        const unsigned long long bal = __ballot(idv[u] != 0);
+        if (lane == 0 && c < nch) Cp[cb0 + c] = __popcll(bal);
+      }
+    }
+  }
+  __syncthreads();
+  SKC_STAMP(1);
+  // ---- 2. wave 0: the chunks' counts become running sums per segment; the others clear the left-out rows --------
+  if (wave == 0) {
+#pragma unroll 1
+    for (int s = 0; s < D.nseg; ++s) {
+      const int nch = (D.seg[s].rows + 63) / 64, per = (nch + 63) / 64, cb0 = seg_cbase(s);
+      int mine = 0;
+      for (int i = 0; i < per; ++i) {
+        const int c = lane * per + i;
+        mine += c < nch ? Cp[cb0 + c] : 0;
+      }
+      int incl = mine;  // inclusive sum over the lanes
+#pragma unroll
+      for (int sh = 1; sh < 64; sh <<= 1) {
+        const int o = __shfl_up(incl, sh);
+        if (lane >= sh) incl += o;
+      }
+      int run = incl - mine;
+      for (int i = 0; i < per; ++i) {
+        const int c = lane * per + i;
+        if (c < nch) {
+          const int v = Cp[cb0 + c];
+          Cp[cb0 + c] = run;
+          run += v;
+        }
+      }
+      if (lane == 63) Cp[cb0 + nch] = incl;  // the segment's kept rows
+    }
+  } else {
+    // this workgroup's share of the left-out rows: global rows id, id + nblk, ... -- a lane looks at one row's id, the wave
+    // then clears the rows it found one by one
+    const int R = seg_roff(D.nseg);
+#pragma unroll 1
+    for (int k0 = (wave - 1) * 64; id + (long)k0 * nblk < R; k0 += 11 * 64) {
+      const long g = id + (long)(k0 + lane) * nblk;
+      int sg = 0;
+#pragma unroll
+      for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+        if (i < D.nseg && g >= seg_roff(i)) sg = i;
+      const bool pad = g < R && D.seg[sg].ids[g - seg_roff(sg)] == 0;
+      unsigned long long bal = __ballot(pad);
+      while (bal) {
+        const int b = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const long gz = id + (long)(k0 + b) * nblk;
+        int sz = 0;
+#pragma unroll
+        for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+          if (i < D.nseg && gz >= seg_roff(i)) sz = i;
+        float* crow = D.seg[sz].c + (size_t)(gz - seg_roff(sz)) * D.ldc;
+        for (int cc = lane; cc < D.ncols_out; cc += 64) crow[cc] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  SKC_STAMP(2);
+  // ---- 3. the plan, the same in every workgroup ----------------------------------------------------------------
+  int live[CARCA_MAX_SEGS], rbs[CARCA_MAX_SEGS + 1];
+  rbs[0] = 0;
+#pragma unroll
+  for (int s = 0; s < CARCA_MAX_SEGS; ++s) {
+    live[s] = s < D.nseg ? Cp[seg_cbase(s) + (D.seg[s].rows + 63) / 64] : 0;
+    rbs[s + 1] = rbs[s] + (live[s] + 383) / 384;
+  }
+  const int nrb = rbs[CARCA_MAX_SEGS], ncb = args.ncb;
+  const int nfast = D.K0 / 32, nfull = ncb - 1;
+  const long total = (long)nfast * nrb;  // K steps of all row blocks
+  // Two kinds of workgroups: x TEAMS of nfull (column blocks 0 .. nfull - 1 of the team's stretch: they stream the same A
+  // rows together) and y LONE ones for the narrow last column block, whose K step costs skc_cheap / 100 of a full one --
+  // x nfull + y = the grid, both kinds done at the same time: x = grid / (nfull + cheap); at least 16 K steps per stretch.
+  const long cap = max(1l, total / 16);
+  int x = (int)max(1l, min(cap, (long)nblk * 100 / (nfull * 100 + args.skc_cheap)));
+  {
+    auto span = [&](int xx) {  // time of the slower kind with xx teams (in 1/100 K steps)
+      const long yy = max(1l, min(cap, (long)nblk - (long)xx * nfull));
+      return max(total * 100 / xx, total * args.skc_cheap / yy);
+    };
+    if ((x + 1) * nfull < nblk && x + 1 <= cap && span(x + 1) < span(x)) ++x;
+  }
+  const int y = (int)max(1l, min(cap, (long)nblk - (long)x * nfull));
+  const int xcd = id & 7, nw = x * nfull + y, q8 = nw >> 3, r8 = nw & 7;
+  const int cnt = xcd < r8 ? q8 + 1 : q8;
+  if (nrb == 0 || (id >> 3) >= cnt) return;
+  const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  const bool lone = w >= x * nfull;
+  const int nteams = lone ? y : x;                       // stretches of this workgroup's kind
+  const int tj = lone ? w - x * nfull : w / nfull;       // its stretch
+  const int cb = lone ? nfull : w - tj * nfull;          // its column block
+  const long lo = total * tj / nteams, hi = total * (tj + 1) / nteams;
+  const int rbA = (int)(lo / nfast), sA = (int)(lo - (long)rbA * nfast);
+  int rbB = (int)(hi / nfast), sB = (int)(hi - (long)rbB * nfast);
+  if (sB == 0) {  // (the stretch ends on a row block's boundary)
+    --rbB;
+    sB = nfast;
+  }
+  // ---- 4. the kept rows of row blocks rbA .. rbB, in row order ---------------------------------------------------
+  for (int rb = rbA; rb <= rbB && rb - rbA < SKC_RB; ++rb) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+      if (i < D.nseg && rb >= rbs[i]) s = i;
+    const CarcaGemmSeg sg = D.seg[s];
+    const int p0 = (rb - rbs[s]) * 384, p1 = min(p0 + 384, live[s]);
+    const int nch = (sg.rows + 63) / 64, cb0 = seg_cbase(s);
+    // the chunks that hold the block's rows: a contiguous run (the running sums are monotone); every wave finds its ends
+    // by itself (two searches over <= 2304 sums in LDS), then the run's chunks go round the waves, four requested together
+    int cl = 0, ch = nch;  // first chunk whose end is past p0; first chunk that starts at or after p1
+    {
+      int l = 0, h = nch;
+      while (l < h) {
+        const int m = (l + h) >> 1;
+        if (Cp[cb0 + m + 1] <= p0) l = m + 1; else h = m;
+      }
+      cl = l;
+      l = cl;
+      h = nch;
+      while (l < h) {
+        const int m = (l + h) >> 1;
+        if (Cp[cb0 + m] < p1) l = m + 1; else h = m;
+      }
+      ch = l;
+    }
+    for (int c0 = cl + wave * 4; c0 < ch; c0 += 12 * 4) {
+      int idv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = (c0 + u) * 64 + lane;
+        idv[u] = (c0 + u < ch && row < sg.rows) ? sg.ids[row] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u;
+        const bool keep = idv[u] != 0;
+        const unsigned long long bal = __ballot(keep);
+        if (c < ch) {
+          const int pos = Cp[cb0 + c] + __popcll(bal & below);
+          if (keep && pos >= p0 && pos < p1) Rl[(rb - rbA) * 384 + pos - p0] = c * 64 + lane;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  SKC_STAMP(3);
+  // ---- 5. the pieces, written down: the K loops below keep none of the plan's scalars alive (with them in registers the
+  // compiler re-read the buffer descriptors from the kernel arguments INSIDE the K loop, a scalar load whose wait also
+  // waits for the step's LDS reads: +5 % per step) -----------------------------------------------------------------
+  if (tid == 0) {
+    // partial tile / flag of this workgroup's first piece (consecutive over the stretches of a column block)
+    const int slot = (lone ? nfull * x : cb * x) + tj;
+    int np = 0;
+    for (int rb = rbA; rb <= rbB && np < SKC_RB; ++rb, ++np) {
+      const int s0 = rb == rbA ? sA : 0, s1 = rb == rbB ? sB : nfast;
+      int sg = 0;
+#pragma unroll
+      for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+        if (i < D.nseg && rb >= rbs[i]) sg = i;
+      int mode = s0 > 0 ? SK_GIVE : (s1 < nfast ? SK_TAKE : SK_PLAIN), ntake = 0;
+      if (mode == SK_TAKE) {
+        // the stretches behind this one that start inside the row block: tj + 1 .. the last j' with lo(j') < end
+        const long end = (long)(rb + 1) * nfast;
+        const long last = (end * nteams + total - 1) / total - 1;
+        ntake = (int)min(last, (long)nteams - 1) - tj;
+        if (ntake <= 0) mode = SK_PLAIN;  // (cannot happen with s1 < nfast; a taker must never wait for nobody)
+      }
+      int* pc = Pc + 8 * np;
+      pc[0] = rb;
+      pc[1] = s0;
+      pc[2] = s1;
+      pc[3] = sg;
+      pc[4] = min(384, live[sg] - (rb - rbs[sg]) * 384);
+      pc[5] = mode;
+      pc[6] = ntake;
+      pc[7] = mode == SK_GIVE ? slot : slot + 1;
+    }
+    Pc[8 * SKC_RB] = np;
+    Pc[8 * SKC_RB + 1] = cb;
+    Pc[8 * SKC_RB + 2] = (int)lone;
+  }
+  __syncthreads();
+  // ---- 6. the pieces, read back -------------------------------------------------------------------------------------
+  const int np = __builtin_amdgcn_readfirstlane(Pc[8 * SKC_RB]);
+  const int mycb = __builtin_amdgcn_readfirstlane(Pc[8 * SKC_RB + 1]);
+  const int nfull_ = args.ncb - 1;
+#pragma unroll 1
+  for (int p = 0; p < np; ++p) {
+    const int* pc = Pc + 8 * p;
+    const int rb = __builtin_amdgcn_readfirstlane(pc[0]), s0 = __builtin_amdgcn_readfirstlane(pc[1]);
+    const int s1 = __builtin_amdgcn_readfirstlane(pc[2]);
+    SkcTile dyn;
+    dyn.seg = __builtin_amdgcn_readfirstlane(pc[3]);
+    dyn.row0 = 0;
+    dyn.live = __builtin_amdgcn_readfirstlane(pc[4]);
+    dyn.rows = Rl + p * 384;
+    dyn.mode = __builtin_amdgcn_readfirstlane(pc[5]);
+    dyn.ntake = __builtin_amdgcn_readfirstlane(pc[6]);
+    const int slot = __builtin_amdgcn_readfirstlane(pc[7]);
+    SKC_STAMP(4 + 2 * p);
+    if (args.dbg && tid == 0 && p < 3)
+      args.dbg[65536 + id * 16 + 10 + p] = (unsigned long long)(s1 - s0) * 8 + (Pc[8 * SKC_RB + 2] ? 4 : 0) + dyn.mode;
+    const bool give = dyn.mode == SK_GIVE;
+    float* part = args.sk_part + (size_t)slot * (384 * 96);
+    int* flag = args.sk_flag + slot;
+    if (mycb < nfull_)
+      cu_tile<3, 0, SK_DYN>(args, As, Bs, rb, mycb * 96, s0, s1, !give, part, flag, dyn);
+    else
+      cu_tile<2, XC, SK_DYN>(args, As, Bs, rb, nfull_ * 96, s0, s1, !give, part, flag, dyn);
+    SKC_STAMP(5 + 2 * p);
+  }
+#undef SKC_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1379,6 +1743,11 @@ static int launch_gemm_rows(const CarcaGemmDesc* desc, hipStream_t stream) {
   g.nrb = rb;
   g.ncb = (desc->ncols_out + BN - 1) / BN;
   const int grid = rb * g.ncb;
+  if (g_rows_log_on) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "gemm_rows_kernel<%d,%d,%d,%d,%d>", BM, BN, BK, PF, (int)BUF);
+    carca_rows_log(nm, desc, grid);
+  }
   hipEvent_t e0, e1;
   if (carca_take_launch_events(&e0, &e1))
     hipExtLaunchKernelGGL((gemm_rows_kernel<BM, BN, BK, PF, BUF>), dim3(grid), dim3((BM / 32) * 64), 0, stream, e0, e1, 0, g);
@@ -1415,6 +1784,7 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream, co
     ++grid;
     if (rode) *rode = 1;
   }
+  if (g_rows_log_on) carca_rows_log(TN == 4 ? "gemm_rows_cu_kernel<0,4>" : "gemm_rows_cu_kernel<0,3>", desc, grid);
   hipEvent_t e0, e1;
   if (carca_take_launch_events(&e0, &e1))
     hipExtLaunchKernelGGL((gemm_rows_cu_kernel<DBG, TN>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
@@ -1479,7 +1849,8 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   // The item-row gather rides as workgroup `grid` on the CU the tiles leave idle (gather_rows_dma: ~100 us; the register
   // version measured ~540 us beside the tiles and was the launch's long pole: 0.640 ms per forward against 0.614).
   // Tuning variant 19: the gather keeps its own launch (A/B switch).
-  if (pas && grid < carca_num_cus() && pas->d <= 128 && variant != 19) {
+  if (pas && grid < carca_num_cus() && pas->d <= 128 && variant != 19 &&
+      4200.0 * (nfast - don + ntail) >= 1.5 * 12.0 * pas->total_rows) {  // (the tiles outlast the passenger with a margin)
     g.has_pas = 1;
     g.pas = *pas;
     ++grid;
@@ -1508,6 +1879,7 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   if (!buf) return (int)hipErrorOutOfMemory;
   g.sk_flag = (int*)buf;
   g.sk_part = (float*)(buf + flag_bytes);
+  if (g_rows_log_on) carca_rows_log(xc == 1 ? "gemm_rows_sk_kernel<1>" : "gemm_rows_sk_kernel<2>", desc, grid);
   hipEvent_t e0, e1;
   const bool ev = carca_take_launch_events(&e0, &e1);
   if (xc == 1) {
@@ -1516,6 +1888,74 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   } else {
     if (ev) hipExtLaunchKernelGGL((gemm_rows_sk_kernel<2>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
     else hipLaunchKernelGGL((gemm_rows_sk_kernel<2>), dim3(grid), dim3(768), 0, stream, g);
+  }
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}
+
+// gemm_rows_skc_kernel: the stream-K kernel over the rows with id != 0.  1 = not this product's kernel.
+static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, const CarcaGatherArgs* pas, int* rode) {
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
+  if (variant == 15 || variant == 158 || variant == 23) return 1;  // (23: gemm_rows_sk_kernel, every row -- A/B switch)
+  if (!desc->mask_rows) return 1;  // (rows with id 0 may be left out only where the product masks them)
+  const int ncb = (desc->ncols_out + 95) / 96, nfull = ncb - 1;
+  if (ncb < 2 || desc->ncols_out != desc->N) return 1;
+  const int rem = desc->N - 96 * nfull, xc = rem - 64;
+  if (xc < 1 || xc > 2) return 1;
+  if (desc->colvec || desc->pos || desc->gate_scale != 0.f) return 1;
+  long rows = 0;
+  GemmDev g{};
+  g.d = *desc;
+  for (int s = 0; s < desc->nseg; ++s) {
+    const CarcaGemmSeg& sg = desc->seg[s];
+    if (sg.add || sg.gate || sg.rowscale || sg.add_pos || !sg.ids) return 1;
+    if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
+    rows += sg.rows;
+  }
+  const int nfast = desc->K0 / 32;
+  const int ncu = carca_num_cus();
+  // (worth a persistent grid: at least most of a round of tiles if every row counted, and K long enough to share)
+  if (nfast < 64 || ((rows + 383) / 384) * ncb < ncu / 2 || ncu > 1024) return 1;
+  // (what the kernel's LDS lists hold: 64-row chunks of all segments, and SKC_RB row blocks per workgroup's stretch)
+  if (rows / 64 + 2 * desc->nseg > SKC_CH || ((rows + 383) / 384 + desc->nseg) > (SKC_RB - 2) * ((ncu - 1) / ncb)) return 1;
+  g.ncb = ncb;
+  g.skc_cheap = xc == 2 ? 74 : 71;  // (two MFMA column tiles of three + the VALU columns: 0.74 of a full step measured)
+  if (!g_sk_err_host) {
+    if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped) != hipSuccess) return 1;
+    *g_sk_err_host = 0;
+    if (hipHostGetDevicePointer((void**)&g_sk_err_dev, g_sk_err_host, 0) != hipSuccess) g_sk_err_dev = nullptr;
+  }
+  if (int rc = sk_check_error_word()) return rc;
+  g.sk_err = g_sk_err_dev;
+  {
+    const int lg = carca_tuning(CARCA_TUNE_SK_SPIN_LOG2);
+    g.sk_spin = 1u << (lg > 0 && lg < 31 ? lg : 23);
+    g.sk_withhold = carca_tuning(CARCA_TUNE_SK_WITHHOLD);
+  }
+  int grid = ncu;
+  if (pas && pas->d <= 128 && variant != 19 && 4200.0 * nfast * 0.5 >= 1.5 * 12.0 * pas->total_rows) {
+    g.has_pas = 1;  // (the gather takes the last workgroup's CU: gather_rows_dma)
+    g.pas = *pas;
+    if (rode) *rode = 1;
+  }
+  // partial tiles: one slot per workgroup
+  const bool cap = carca_stream_capturing(stream);
+  const size_t flag_bytes = 4096, part_bytes = flag_bytes + (size_t)grid * 384 * 96 * sizeof(float);
+  char* parts = (char*)(cap ? carca_capture_alloc(stream, part_bytes, false, nullptr, flag_bytes)
+                            : carca_stream_scratch(stream, CARCA_SCRATCH_SKC_PART, part_bytes, flag_bytes));
+  if (!parts) return (int)hipErrorOutOfMemory;
+  g.sk_flag = (int*)parts;
+  g.sk_part = (float*)(parts + flag_bytes);
+  g.dbg = carca_debug_buffer();
+  if (g_rows_log_on) carca_rows_log(xc == 1 ? "gemm_rows_skc_kernel<1>" : "gemm_rows_skc_kernel<2>", desc, grid);
+  hipEvent_t e0, e1;
+  const bool ev = carca_take_launch_events(&e0, &e1);
+  if (xc == 1) {
+    if (ev) hipExtLaunchKernelGGL((gemm_rows_skc_kernel<1>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
+    else hipLaunchKernelGGL((gemm_rows_skc_kernel<1>), dim3(grid), dim3(768), 0, stream, g);
+  } else {
+    if (ev) hipExtLaunchKernelGGL((gemm_rows_skc_kernel<2>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
+    else hipLaunchKernelGGL((gemm_rows_skc_kernel<2>), dim3(grid), dim3(768), 0, stream, g);
   }
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
@@ -1544,6 +1984,7 @@ static int launch_gemm_rows_n96(const CarcaGemmDesc* desc, hipStream_t stream) {
     }
     attr_set = true;
   }
+  if (g_rows_log_on) carca_rows_log("gemm_rows_n96_kernel", desc, rb);
   hipEvent_t e0, e1;
   if (carca_take_launch_events(&e0, &e1))
     hipExtLaunchKernelGGL(gemm_rows_n96_kernel, dim3(rb), dim3(768), lds_bytes, stream, e0, e1, 0, g);
@@ -1659,6 +2100,8 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
     case GEMM_CU: {
       int rc = carca_gemm_rows_split_try(desc, stream);  // (opt-in, tuning key 16; 1 = not asked for / not its product)
       if (rc != 1) return rc;
+      rc = launch_gemm_rows_skc(desc, stream, nullptr, nullptr);
+      if (rc != 1) return rc;
       rc = launch_gemm_rows_sk(desc, stream, nullptr, nullptr);
       return rc == 1 ? launch_gemm_rows_cu<0>(desc, stream) : rc;
     }
@@ -1680,6 +2123,8 @@ int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* 
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 8 || carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 158) ga = nullptr;  // (8: never let the gather ride -- A/B switch)
   if (c == GEMM_CU) {
     int rc = carca_gemm_rows_split_try(desc, stream);  // (the gather keeps its own launch beside this kernel: rode stays 0)
+    if (rc != 1) return rc;
+    rc = launch_gemm_rows_skc(desc, stream, ga, rode);
     if (rc != 1) return rc;
     rc = launch_gemm_rows_sk(desc, stream, ga, rode);
     return rc == 1 ? launch_gemm_rows_cu<0, 3>(desc, stream, ga, rode) : rc;

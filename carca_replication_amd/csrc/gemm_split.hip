@@ -681,6 +681,8 @@ int carca_gemm_rows_split_try(const CarcaGemmDesc* desc, hipStream_t stream) {
   bool dma = desc->K0 % SP_BK == 0 && desc->lda0 % 4 == 0 && carca_tuning(CARCA_TUNE_GEMM_VARIANT) != 21;
   for (int s = 0; s < desc->nseg && dma; ++s)
     dma = ((uintptr_t)desc->seg[s].a0 & 15) == 0 && desc->seg[s].a0_bstride % 4 == 0;
+  carca_rows_log(dma ? (mode == 1 ? "gemm_rows_split_dma_kernel<bf16x3>" : "gemm_rows_split_dma_kernel<fp16x2>")
+                     : (mode == 1 ? "gemm_rows_split_kernel<bf16x3>" : "gemm_rows_split_kernel<fp16x2>"), desc, grid);
   auto launch = [&](auto kernel) {
     if (ev) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(768), 0, stream, g);

@@ -1217,6 +1217,18 @@ SPLIT_GEMM_MODES = {"fp32": 0, "bf16x3": 1, "fp16x2": 2}
 _split_mode = 0
 
 
+def gemm_rows_log(on: Optional[bool] = None) -> str:
+    """on=True / False: clear the calling thread's log of row-GEMM launches and switch it on / off; None: the log so far
+    ("kernel rows=.. N=.. K=.. grid=..;" per launch)."""
+    lib = _lib.load()
+    if on is not None:
+        lib.carca_gemm_rows_log(None, int(bool(on)))
+        return ""
+    buf = C.create_string_buffer(65536)
+    lib.carca_gemm_rows_log(buf, len(buf))
+    return buf.value.decode()
+
+
 def set_feature_gemm_precision(mode: str, force: bool = False) -> None:
     """'fp32' (default): exact-fp32 MFMA.  'bf16x3': both operands split into three bf16 parts, six products, fp32
     accumulation.  'fp16x2': two fp16 parts, three products (|operands| < 65504).  Applies to AllEmbedding.feats_embed

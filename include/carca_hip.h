@@ -435,6 +435,11 @@ int carca_add_positions(const float* x, int ldx, const float* pos, float* out, i
 int carca_mha_core(const float* q, int ldq, const float* k, const float* v, int ldk, const int32_t* q_ids,
                    const int32_t* k_ids, int B, int Tq, int Tk, int d, int H, int has_causal, int causal, float* out,
                    int ldo, float* w_out /*or NULL*/, void* stream);
+/* Which kernel each row product took.  carca_gemm_rows_log(NULL, 1) clears the calling thread's log and switches it on
+ * ((NULL, 0): off); from then on every row-GEMM launch of that thread appends "kernel rows=.. N=.. K=.. grid=..;".
+ * carca_gemm_rows_log(buf, cap) copies the log (NUL-terminated) and returns its length.  tools/bench_configs.py names each
+ * configuration's dominant kernel with it. */
+int carca_gemm_rows_log(char* out /*or NULL*/, int cap);
 /* carca_mha_core with nn.Dropout on the weights (carca.py:258): W * keep / (1 - p) multiplies v, w_out stays pre-dropout
  * (carca.py:262-263); element (b, h, t, j) of site drop->site, keep-mask written to keep_out [B, H, Tq, Tk] (uint8,
  * or NULL).  drop NULL or p = 0: carca_mha_core.  The attention of profiles longer than the fused kernels' 64 slots

@@ -174,7 +174,7 @@ def test_a_taker_that_gives_up_is_reported_by_the_poll_and_by_the_next_launch(tu
         ops.poll_errors()  # clean
         for report in ("poll", "next launch"):
             tuning(12, 10)
-            tuning(13, 1)  # (flag 0: row block 0's partial for column block 0 -- profile rows of the first users)
+            tuning(13, 2)  # (flag 1: the partial tile workgroup 1 hands to workgroup 0 -- profile rows of the first users)
             got = model(profile=p, targets=[t])
             torch.cuda.synchronize()
             tuning(12, 0)

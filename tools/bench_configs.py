@@ -39,12 +39,49 @@ for name, c in CONFIGS.items():
             model(profile=profile, targets=[target])
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # per-stage kernel time of the same forward (HIP events bound to the launches: feature GEMM, scoring kernel, the FIRST
+    # SelfAttentionBlock's kernel, joint GEMM -- the hooks bench.py's roofline keys use) and which row kernels the products took
+    from carca_replication_amd import ops
+
+    evs = [[ops.HipEvent() for _ in range(8)] for _ in range(12)]
+    with torch.no_grad():
+        ops.gemm_rows_log(True)
+        model(profile=profile, targets=[target])
+        rows_log = ops.gemm_rows_log()
+        ops.gemm_rows_log(False)
+        for e in evs:
+            ops.set_fused_events([h.handle for h in e])
+            model(profile=profile, targets=[target])
+        ops.set_fused_events(None)
+        torch.cuda.synchronize()
+    med = lambda i: sorted(e[i].elapsed_ms(e[i + 1]) for e in evs)[len(evs) // 2]  # noqa: E731
+    B_, L_, N_, d_, g_, H_, nb_ = c["B"], c["L"], c["N"], c["d"], c["g"], c["H"], c["nb"]
     F = c["n_attrs"] + c["n_ctx"]
+    rows = B_ * (L_ + N_)
+    stages = {  # name: (ms per launch, launches per forward, algorithmic flop per launch)
+        "feature_gemm": (med(0), 1, 2.0 * rows * F * g_),
+        "cross_score": (med(2), 1, B_ * (4.0 * L_ * d_ * d_ + 2.0 * N_ * d_ * d_ + 4.0 * N_ * L_ * d_ + 2.0 * N_ * d_)),
+        "sa_block": (med(4), nb_, B_ * (10.0 * L_ * d_ * d_ + 4.0 * L_ * L_ * d_)),
+        "joint_gemm": (med(6), 1, 2.0 * rows * (d_ + g_) * d_),
+    }
+    dominant = max(stages, key=lambda k: stages[k][0] * stages[k][1])
+    feat_kernel = next((t for t in rows_log.split(";") if f"N={g_} " in t), "?")
+    joint_kernel = next((t for t in rows_log.split(";") if f"N={d_} K={d_ + g_} " in t), "?")
+    kname = {"feature_gemm": feat_kernel, "joint_gemm": joint_kernel, "cross_score": "cross_stream_kernel / cross_fold_kernel",
+             "sa_block": "sa_eval_kernel"}
+    stage_out = {k: dict(ms=v[0], launches=v[1], tflops=v[2] / v[0] / 1e9, frac_of_fp32_mfma_peak=v[2] / v[0] / 1e9 / 157.3)
+                 for k, v in stages.items()}
     flop = c["B"] * ((c["L"] + c["N"]) * (2 * F * c["g"] + 2 * (c["d"] + c["g"]) * c["d"]) + c["nb"] * (10 * c["L"] * c["d"] ** 2 + 4 * c["L"] ** 2 * c["d"])
                      + 2 * c["N"] * c["d"] ** 2 + 4 * c["L"] * c["d"] ** 2 + 4 * c["N"] * c["L"] * c["d"] + 2 * c["N"] * c["d"])
     results.append(dict(config=" ".join(name.split()), ms_per_batch=dt * 1e3, users_per_s=c["B"] / dt,
-                        algorithmic_tflops=flop / dt / 1e12, **c))
-    print(f"{name}: {dt*1e3:7.3f} ms/batch  {c['B']/dt:10.0f} users/s  {flop/dt/1e12:6.1f} TFLOP/s (algorithmic)", flush=True)
+                        algorithmic_tflops=flop / dt / 1e12, stages=stage_out,
+                        dominant=dict(stage=dominant, kernel=kname[dominant], share_of_step=stages[dominant][0] * stages[dominant][1] / (dt * 1e3),
+                                      roofline=dict(bound="mfma", peak=157.3, unit="TFLOP/s", achieved=stage_out[dominant]["tflops"],
+                                                    frac=stage_out[dominant]["frac_of_fp32_mfma_peak"])), **c))
+    print(f"{name}: {dt*1e3:7.3f} ms/batch  {c['B']/dt:10.0f} users/s  {flop/dt/1e12:6.1f} TFLOP/s (algorithmic); dominant: "
+          f"{dominant} [{kname[dominant]}] {stages[dominant][0]*1e3:.1f} us x{stages[dominant][1]} = "
+          f"{100*stage_out[dominant]['frac_of_fp32_mfma_peak']:.1f} % of the fp32 MFMA peak; "
+          + ", ".join(f"{k} {v[0]*1e3:.1f} us" for k, v in stages.items()), flush=True)
 
 if os.environ.get("JSON_OUT"):  # e.g. JSON_OUT=gpurun_out/r03_configs.json (copied to profiles/ by hand)
     import json

@@ -1,0 +1,60 @@
+"""Wall-clock stamps (100 MHz) inside gemm_rows_skc_kernel at C2 with BASELINE's profile lengths: per workgroup, the time of
+its prologue steps (chunk counts, running sums + clearing, row lists) and of each piece of its stretch."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from carca_replication_amd import _lib, ops  # noqa: E402
+from oracle.carca_oracle import synth_eval_batch  # noqa: E402
+from tests.model_util import build_model  # noqa: E402
+
+torch.manual_seed(0)
+model = build_model(dict(d=90, H=3, n_blocks=2), 12102, 450, 6, 4096, 50).cuda().eval()
+profile, target, _ = synth_eval_batch(128, 50, 101, 12102, 4096, 6, seed=1)
+profile, target = tuple(t.cuda() for t in profile), tuple(t.cuda() for t in target)
+lib = _lib.load()
+buf = torch.zeros(65536 + 256 * 16, dtype=torch.int64, device="cuda")
+with torch.no_grad():
+    for _ in range(30):
+        model(profile=profile, targets=[target])
+    torch.cuda.synchronize()
+    lib.carca_set_debug_buffer(buf.data_ptr())
+    model(profile=profile, targets=[target])
+    torch.cuda.synchronize()
+    lib.carca_set_debug_buffer(None)
+r = buf[65536:].view(256, 16).cpu().double()
+act = r[:, 3] > 0
+info = r[:, 10:13].clone().long()
+r = torch.where(r > 0, r - r[:, :1], torch.full_like(r, -1.0))  # per workgroup, since its own start (the XCDs' clocks differ)
+us = lambda x: x / 100.0  # noqa: E731
+print("workgroups with a stretch:", int(act.sum()))
+for k, name in ((0, "start"), (1, "after chunk counts"), (2, "after running sums / clearing"), (3, "after row lists")):
+    x = us(r[act, k])
+    print(f"{name:32s} mean {x.mean():7.2f} us   max {x.max():7.2f}")
+for piece in range(3):
+    a, b = r[:, 4 + 2 * piece], r[:, 5 + 2 * piece]
+    m = act & (b >= 0)
+    if m.any():
+        print(f"piece {piece}: workgroups {int(m.sum()):3d}  starts mean {us(a[m]).mean():7.2f}  ends mean {us(b[m]).mean():7.2f} max {us(b[m]).max():7.2f}  "
+              f"length mean {((b[m] - a[m]) / 100).mean():7.2f} max {((b[m] - a[m]) / 100).max():7.2f}")
+last = torch.stack([r[:, 5], r[:, 7], r[:, 9]]).max(dim=0).values
+print("last piece ends: mean %.2f  min %.2f  max %.2f us" % (us(last[act]).mean(), us(last[act]).min(), us(last[act]).max()))
+for w in (0, 1, 2, 3, 4, 5, 128, 250, 254):
+    print(w, [round(float(us(v)), 1) if v >= 0 else None for v in r[w, :10]])
+
+# us per K step by kind of piece: whole row blocks / given (first) pieces / taken (last) pieces, teams and lone workgroups
+import collections
+acc = collections.defaultdict(list)
+raw = buf[65536:].view(256, 16).cpu().double()
+for wg in range(256):
+    for pc in range(3):
+        v = int(info[wg, pc])
+        a, b = raw[wg, 4 + 2 * pc], raw[wg, 5 + 2 * pc]
+        if v > 0 and b > a > 0:
+            steps, kind = v >> 3, v & 7
+            acc[("lone " if kind & 4 else "team ") + {0: "whole", 1: "given", 2: "taken"}[kind & 3]].append((float(b - a) / 100.0, steps))
+for k, v in sorted(acc.items()):
+    us_, st = sum(x for x, _ in v), sum(s_ for _, s_ in v)
+    print(f"{k}: {len(v):3d} pieces, {st / len(v):6.1f} steps each, {us_ / st:.3f} us per step (ends included)")
