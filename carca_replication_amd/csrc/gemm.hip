@@ -1030,42 +1030,76 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
   // ---- 1. kept rows per 64-row chunk ----------------------------------------------------------------------------
   // (first chunk entry / first global row of segment s: running sums over at most four segments, recomputed where needed --
   // arrays indexed by a run-time s would live in scratch)
+  // (the segments' row counts and id pointers read UNCONDITIONALLY, all at once -- unused segments are zero-filled by the
+  // launcher: under `i < nseg` every one of them was a dependent scalar load, ~4 us of round trips when the kernel starts)
+  int nrows_[CARCA_MAX_SEGS];
+  const int32_t* ids_[CARCA_MAX_SEGS];
+#pragma unroll
+  for (int i = 0; i < CARCA_MAX_SEGS; ++i) {
+    nrows_[i] = D.seg[i].rows;
+    ids_[i] = D.seg[i].ids;
+  }
   auto seg_cbase = [&](int s) {
     int v = 0;
 #pragma unroll
-    for (int i = 0; i + 1 < CARCA_MAX_SEGS; ++i)
-      if (i < s) v += (D.seg[i].rows + 63) / 64 + 1;
+    for (int i = 0; i + 1 < CARCA_MAX_SEGS; ++i) v += i < s ? (nrows_[i] + 63) / 64 + 1 : 0;
     return v;
   };
   auto seg_roff = [&](int s) {
     int v = 0;
 #pragma unroll
-    for (int i = 0; i + 1 < CARCA_MAX_SEGS; ++i)
-      if (i < s) v += D.seg[i].rows;
+    for (int i = 0; i + 1 < CARCA_MAX_SEGS; ++i) v += i < s ? nrows_[i] : 0;
     return v;
   };
   const unsigned long long below = (1ull << lane) - 1;
-#pragma unroll 1
-  for (int s = 0; s < D.nseg; ++s) {
-    const int rows = D.seg[s].rows, nch = (rows + 63) / 64, cb0 = seg_cbase(s);
-    const int32_t* __restrict__ ids = D.seg[s].ids;
-    // (32 chunks' ids requested together, in four groups of eight dealt round the waves: one chunk at a time is a dependent
-    // load per iteration, ~19 us at C2; the loop body stays small -- unrolled over segments with the clearing inside it was
-    // 100 KB of code run once, 13 us of instruction fetch)
-#pragma unroll 1
-    for (int r0 = 0; r0 < nch; r0 += 12 * 32) {
-      int idv[32];
+  // All segments' chunks as one run 0 .. G - 1; 32 chunks' ids per wave requested together (four groups of eight dealt
+  // round the waves): one chunk at a time is a dependent load per iteration (~19 us at C2), one segment at a time a round
+  // trip per segment.  The loop body stays small: unrolled over segments with the clearing inside, it was 100 KB of code
+  // run once.
+  const int G = seg_cbase(D.nseg) - D.nseg;
+  // (every load UNCONDITIONAL, from a clamped row of a segment picked by compares: a load under a branch gets its own wait
+  // at the join -- the first version ran its 32 loads one after the other, 12 us)
+  int seg_rows[CARCA_MAX_SEGS], seg_g0[CARCA_MAX_SEGS];
+  const int32_t* seg_ids[CARCA_MAX_SEGS];
+  {
+    int gb = 0;
 #pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        const int row = (r0 + ((u >> 3) * 12 + wave) * 8 + (u & 7)) * 64 + lane;
-        idv[u] = row < rows ? ids[row] : 0;
-      }
+    for (int i = 0; i < CARCA_MAX_SEGS; ++i) {
+      const bool on = nrows_[i] > 0;
+      seg_rows[i] = on ? nrows_[i] : 1;
+      seg_ids[i] = on ? ids_[i] : ids_[0];
+      seg_g0[i] = on ? gb : 0x7fffffff;
+      gb += (nrows_[i] + 63) / 64;
+    }
+  }
+#pragma unroll 1
+  for (int g0 = 0; g0 < G; g0 += 12 * 32) {
+    int idv[32];
 #pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        const int c = r0 + ((u >> 3) * 12 + wave) * 8 + (u & 7);
-        const unsigned long long bal = __ballot(idv[u] != 0);
-        if (lane == 0 && c < nch) Cp[cb0 + c] = __popcll(bal);
-      }
+    for (int u = 0; u < 32; ++u) {
+      const int g = min(g0 + ((u >> 3) * 12 + wave) * 8 + (u & 7), G - 1);  // (wave-uniform)
+      int rows = seg_rows[0], gb = 0;
+      const int32_t* ip = seg_ids[0];
+#pragma unroll
+      for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+        if (g >= seg_g0[i]) {
+          rows = seg_rows[i];
+          gb = seg_g0[i];
+          ip = seg_ids[i];
+        }
+      const int row = (g - gb) * 64 + lane;
+      const int v = ip[min(row, rows - 1)];
+      idv[u] = row < rows ? v : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int g = g0 + ((u >> 3) * 12 + wave) * 8 + (u & 7);
+      int sgi = 0;
+#pragma unroll
+      for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+        if (g >= seg_g0[i]) sgi = i;
+      const unsigned long long bal = __ballot(idv[u] != 0);
+      if (lane == 0 && g < G) Cp[g + sgi] = __popcll(bal);  // (entry of chunk g: one spare entry behind each segment)
     }
   }
   __syncthreads();
@@ -1108,7 +1142,8 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
 #pragma unroll
       for (int i = 1; i < CARCA_MAX_SEGS; ++i)
         if (i < D.nseg && g >= seg_roff(i)) sg = i;
-      const bool pad = g < R && D.seg[sg].ids[g - seg_roff(sg)] == 0;
+      const int pv = D.seg[sg].ids[min(g, (long)R - 1) - seg_roff(sg)];
+      const bool pad = g < R && pv == 0;
       unsigned long long bal = __ballot(pad);
       while (bal) {
         const int b = __ffsll((long long)bal) - 1;
@@ -1165,7 +1200,11 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
     sB = nfast;
   }
   // ---- 4. the kept rows of row blocks rbA .. rbB, in row order ---------------------------------------------------
-  for (int rb = rbA; rb <= rbB && rb - rbA < SKC_RB; ++rb) {
+  // (the row blocks go round the waves: wave % npc takes block rbA + wave % npc with the waves that share it)
+  const int npc = min(rbB - rbA + 1, SKC_RB);
+  {
+    const int pi = wave % npc, sub = wave / npc, nsub = (12 - pi + npc - 1) / npc;
+    const int rb = rbA + pi;
     int s = 0;
 #pragma unroll
     for (int i = 1; i < CARCA_MAX_SEGS; ++i)
@@ -1191,12 +1230,13 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
       }
       ch = l;
     }
-    for (int c0 = cl + wave * 4; c0 < ch; c0 += 12 * 4) {
+    for (int c0 = cl + sub * 4; c0 < ch; c0 += nsub * 4) {
       int idv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int row = (c0 + u) * 64 + lane;
-        idv[u] = (c0 + u < ch && row < sg.rows) ? sg.ids[row] : 0;
+        const int v = sg.ids[min(row, sg.rows - 1)];
+        idv[u] = (c0 + u < ch && row < sg.rows) ? v : 0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1912,6 +1952,7 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
     if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
     rows += sg.rows;
   }
+  for (int s = desc->nseg; s < CARCA_MAX_SEGS; ++s) g.d.seg[s] = CarcaGemmSeg{};  // (the kernel reads all four: rows = 0)
   const int nfast = desc->K0 / 32;
   const int ncu = carca_num_cus();
   // (worth a persistent grid: at least most of a round of tiles if every row counted, and K long enough to share)
