@@ -211,13 +211,16 @@ def measure_train(c, model, rank, world, device, steps, fold=False, graphed=Fals
         ach = c["B"] * tf["total"] / (dt / steps) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "needed_gflop_per_step": c["B"] * tf["total"] / 1e9,
-                           "dominant_kernels": "gemm_wgrad_cu_kernel (dW of feats_embed, %.1f GFLOP) and gemm_rows_cu_kernel "
+                           "dominant_kernels": "gemm_wgrad_cu_kernel (dW of feats_embed, %.1f GFLOP) and gemm_rows_skc_kernel "
                                                "(its forward product, the same flops): %.0f %% of the step's needed flops"
                                                % (c["B"] * tf["feat_dw"] / 1e9, 200.0 * tf["feat_fwd"] / tf["total"]),
                            "note": "WHOLE step (fwd + bwd + Adam) against the fp32 MFMA peak on NEEDED flops: forward + "
                                    "weight gradient for the two products whose inputs are data (feats_embed: 2x its forward, "
                                    "not 3x), forward + both gradients for everything else; per-kernel durations of the same "
-                                   "step: profiles/*_train_kernel_stats.csv"}
+                                   "step: profiles/*_train_kernel_stats.csv.  Both feats_embed products leave the padding's rows "
+                                   "out (ids == 0: ~47 %% of a training batch's rows with BASELINE's profile lengths), so the "
+                                   "flops EXECUTED are about half the needed figure: frac says how fast the step delivers the "
+                                   "reference's arithmetic, not how busy the MFMA pipe is"}
     return out
 
 
@@ -638,6 +641,8 @@ def main():
         users = world * c["B"] * args.steps
         value = users / elapsed
         feat_tflops = c["B"] * fl["feat"] / (feat_avg * 1e-3) / 1e12
+        n_rows = profile[0].numel() + target[0].numel()
+        kept_share = float((profile[0] != 0).sum() + (target[0] != 0).sum()) / n_rows  # rows the feature GEMM multiplies
         ca_tflops = c["B"] * fl["ca"] / (ca_avg * 1e-3) / 1e12
         sa_avg, joint_avg = sum(sa_ms) / len(sa_ms), sum(joint_ms) / len(joint_ms)
         sa_tflops = c["B"] * (fl["sa"] / c["n_blocks"]) / (sa_avg * 1e-3) / 1e12
@@ -657,9 +662,20 @@ def main():
             "timeline": {"gpu_span_ms": gpu_span_ms, "host_issue_ms": host_issue_ms,
                          "note": "GPU time between the first and last launch of the timed region, and host time to "
                                  "issue them; wall >> gpu_span means the host, not the GPU, set the pace"},
-            "roofline": {"kernel": "gemm_rows_sk_kernel (384x96 tiles, one workgroup per CU; the last column block's workgroup trades its padding for K steps of its neighbours), feature GEMM launch (AllEmbedding feats_embed, carca.py:86)",
+            "roofline": {"kernel": "gemm_rows_skc_kernel (feature GEMM launch, AllEmbedding feats_embed, carca.py:86: 384-row x 96-column "
+                                   "tiles over the rows whose id is not 0 -- the padding's rows are masked two lines later, "
+                                   "carca.py:92-94 --, one workgroup per CU; teams of workgroups share the K steps of all row "
+                                   "blocks as stretches and hand partial tiles to their neighbours)",
                          "bound": "mfma", "achieved": feat_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS,
+                         "rows_multiplied_share": kept_share,
+                         "achieved_on_rows_multiplied": feat_tflops * kept_share,
+                         "frac_on_rows_multiplied": feat_tflops * kept_share / PEAK_F32_MFMA_TFLOPS,
+                         "flops_note": "achieved / frac: ALGORITHMIC flops of the product (every slot of the padded id matrices, "
+                                       "SURVEY 8d) / kernel time; *_on_rows_multiplied: the flops the kernel executes (rows with "
+                                       "id != 0: BASELINE's profile lengths U{3..50} leave %.1f %% of this batch's rows out) -- "
+                                       "the share of the MFMA peak the kernel really reaches" % (100 * (1 - kept_share)),
+                         "traffic": traffic,
                          "traffic_note": traffic_note,
                          "avg_ms": feat_avg, "min_ms": feat_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["feat"] / 1e9,
                          "launches_timed": len(feat_ms),

@@ -81,7 +81,7 @@ struct GemmDev {
 // 19 k rows, longer than the product it rides in).  Here a wave requests R rows -- each one or two buffer_load ... lds of 64
 // dwords, no destination registers, the row's table address in the scalar resource -- waits once, and copies them out of
 // LDS scaled; the ids of the next batch are requested right behind the rows of this one.  12 waves x 24 rows x 360 bytes in
-// flight: ~100 us of a CU that has nothing else to do, beside a 515 us product.
+// flight: ~390 us for C2's 19 k rows beside the tiles (20 ns per row; the register version: 540 us).
 template <int R, int RS>
 __device__ __forceinline__ void gather_rows_dma(const CarcaGatherArgs& ga, float* lds, const int wave, const int nwaves,
                                                 const int lane) {
@@ -1017,10 +1017,13 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (args.has_pas && id == nblk) {
+    if (args.dbg && tid == 0) args.dbg[65536 + id * 16] = wall_clock64();
     if (args.pas.d <= 96)
       gather_rows_dma<24, 96>(args.pas, As, wave, 12, lane);
     else
       gather_rows_dma<18, 128>(args.pas, As, wave, 12, lane);
+    __syncthreads();
+    if (args.dbg && tid == 0) args.dbg[65536 + id * 16 + 1] = wall_clock64();
     return;
   }
   // (tools/stamp_skc.py: wall-clock stamps of workgroup `id`, 100 MHz, behind the other kernels' 64 k entries -- start, after
@@ -1890,7 +1893,7 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   // version measured ~540 us beside the tiles and was the launch's long pole: 0.640 ms per forward against 0.614).
   // Tuning variant 19: the gather keeps its own launch (A/B switch).
   if (pas && grid < carca_num_cus() && pas->d <= 128 && variant != 19 &&
-      4200.0 * (nfast - don + ntail) >= 1.5 * 12.0 * pas->total_rows) {  // (the tiles outlast the passenger with a margin)
+      4200.0 * (nfast - don + ntail) >= 1.25 * 20.0 * pas->total_rows) {  // (the tiles outlast the passenger, 20 ns per row, with a margin)
     g.has_pas = 1;
     g.pas = *pas;
     ++grid;
@@ -1974,8 +1977,11 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
     g.sk_withhold = carca_tuning(CARCA_TUNE_SK_WITHHOLD);
   }
   int grid = ncu;
-  if (pas && pas->d <= 128 && variant != 19 && 4200.0 * nfast * 0.5 >= 1.5 * 12.0 * pas->total_rows) {
-    g.has_pas = 1;  // (the gather takes the last workgroup's CU: gather_rows_dma)
+  // The gather rides (last workgroup: gather_rows_dma, ~20 ns per row measured beside the tiles: 392 us for C2's 19 k rows)
+  // only under a product that lasts well beyond it even with half of its rows left out -- not at C2 (the kernel is ~480 us in
+  // evaluation, ~330 us in training; riding measured 0.5653 ms per forward against 0.5637 with the gather's own 7 us launch).
+  if (pas && pas->d <= 128 && variant != 19 && 4200.0 * nfast * 0.5 >= 1.5 * 20.0 * pas->total_rows) {
+    g.has_pas = 1;
     g.pas = *pas;
     if (rode) *rode = 1;
   }

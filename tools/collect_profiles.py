@@ -29,7 +29,7 @@ def put(path, name):
         print("profiles/%s_%s" % (a.tag, name))
 
 
-def filtered(path, name, key="gemm_rows_sk_kernel"):
+def filtered(path, name, key="gemm_rows_sk"):
     if not path:
         return
     rows = list(csv.reader(open(path)))

@@ -21,11 +21,11 @@ out = sys.argv[1]
 def one(pat):
     f = glob.glob(os.path.join(out, pat), recursive=True)
     return f[0] if f else None
-WANT = {"table": ["gemm_rows_sk_kernel"], "train": ["gemm_wgrad_cu_kernel", "gemm_rows_sk_kernel"], "knn": ["knn_score_kernel"]}
+WANT = {"table": ["gemm_rows_sk"], "train": ["gemm_wgrad_cu_kernel", "gemm_rows_sk"], "knn": ["knn_score_kernel"]}
 ALG = {  # algorithmic HBM bytes per launch
-    ("table", "gemm_rows_sk_kernel"): "attribute rows gathered from the table: 19328 rows x 4096 x 4 B = 316.7 MB (+ ctx 0.5 MB, W_f 7.4 MB, q out 34.8 MB) = 359 MB",
+    ("table", "gemm_rows_sk"): "attribute rows gathered from the table: 19328 rows x 4096 x 4 B = 316.7 MB (+ ctx 0.5 MB, W_f 7.4 MB, q out 34.8 MB) = 359 MB",
     ("train", "gemm_wgrad_cu_kernel"): "dy = dq [19200 x 450] 34.6 MB + x = [attrs | ctx] 315 MB + dW out 7.4 MB = 357 MB",
-    ("train", "gemm_rows_sk_kernel"): "forward feature GEMM of the train step: 19200 rows, 357 MB",
+    ("train", "gemm_rows_sk"): "forward feature GEMM of the train step: 19200 rows, 357 MB",
     ("knn", "knn_score_kernel"): "B T F 4 + B F 4 + B T 4 = 214 MB",
 }
 res = []

@@ -42,13 +42,13 @@ def pmc(pat, name):
     f = one(pat)
     vals = []
     for r in csv.DictReader(open(f)):
-        if ("gemm_rows_sk_kernel" in r["Kernel_Name"] or "gemm_rows_cu_kernel<0, 3>" in r["Kernel_Name"]) and r["Counter_Name"] == name:
+        if ("gemm_rows_skc_kernel" in r["Kernel_Name"] or "gemm_rows_sk_kernel" in r["Kernel_Name"] or "gemm_rows_cu_kernel<0, 3>" in r["Kernel_Name"]) and r["Counter_Name"] == name:
             vals.append(float(r["Counter_Value"]))
     return vals
 fe, wr = pmc("fetch/**/*counter_collection.csv", "FETCH_SIZE"), pmc("write/**/*counter_collection.csv", "WRITE_SIZE")
 B, L, N, K, g = 128, 50, 101, 4102, 450
 alg = (B * (L + N) * K + g * K + B * (L + N) * g) * 4
-t = {"kernel": "gemm_rows_sk_kernel (feature GEMM launch, grid 255 x 768; partial tiles of the K-step hand-over included)",
+t = {"kernel": "gemm_rows_skc_kernel (feature GEMM launch, grid 256 x 768: 255 workgroups on the tiles of the rows with id != 0 + the item-row gather's; partial tiles of the hand-over and the cleared rows included)",
      "source": "separate rocprofv3 --pmc passes of bench.py --steps 20 (tools/profile_round.sh)",
      "FETCH_SIZE_KiB_avg": sum(fe) / len(fe), "WRITE_SIZE_KiB_avg": sum(wr) / len(wr),
      "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM), WRITE_SIZE exact, KiB x1024",

@@ -23,7 +23,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemm_rows_split_kernel" in r["Kernel_Name"] or "gemm_rows_sk_kernel" in r["Kernel_Name"]:
+        if "gemm_rows_split_kernel" in r["Kernel_Name"] or "gemm_rows_sk" in r["Kernel_Name"]:
             name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, cs in sorted(acc.items()):

@@ -14,7 +14,7 @@ import csv, glob, os, re, sys
 out = sys.argv[1]
 f = glob.glob(os.path.join(out, "tr/**/*kernel_trace.csv"), recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "gemm_rows_sk_kernel" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "gemm_rows_sk" in r["Kernel_Name"]]
 i0, i1 = starts[-3], starts[-2]
 # a step begins a few launches before its feature GEMM: take everything from the previous step's adam_kernel end
 t0 = int(rows[i0]["Start_Timestamp"])

@@ -25,6 +25,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     lib.carca_set_debug_buffer(None)
 r = buf[65536:].view(256, 16).cpu().double()
+print("the gather's workgroup (last one): %.1f us" % ((float(r[255, 1]) - float(r[255, 0])) / 100.0))
 act = r[:, 3] > 0
 info = r[:, 10:13].clone().long()
 r = torch.where(r > 0, r - r[:, :1], torch.full_like(r, -1.0))  # per workgroup, since its own start (the XCDs' clocks differ)
