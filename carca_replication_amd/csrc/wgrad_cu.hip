@@ -123,9 +123,14 @@ __global__ __launch_bounds__(1024) void wgrad_rowtab_kernel(const WgradCuDev arg
       bool in[PER], keep[PER];
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
-        const int row = base + 1024 * j + tid;
-        in[j] = row < sg.rows;
-        id[j] = (in[j] && sg.ids) ? sg.ids[row] : 1;
+        in[j] = base + 1024 * j + tid < sg.rows;
+        id[j] = 1;
+      }
+      if (sg.ids) {
+        // (UNCONDITIONAL loads from clamped rows, all eight requested before anything looks at them: under `in[j]` each
+        // load sat in its own branch with its own wait, eight round trips per super-tile -- the kernel measured 28 us)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) id[j] = sg.ids[min(base + 1024 * j + tid, sg.rows - 1)];
       }
       unsigned long long bal[PER];
 #pragma unroll
