@@ -1030,6 +1030,39 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
   // steps 1 / 2 / 4, around each piece)
 #define SKC_STAMP(k) do { if (args.dbg && tid == 0) args.dbg[65536 + id * 16 + (k)] = wall_clock64(); } while (0)
   SKC_STAMP(0);
+  // This workgroup's share of the left-out rows (global rows id, id + nblk, ...): a lane looks at one row's id, the wave
+  // then clears the rows it found one by one.  Run LAST (after the pieces; at once by the workgroups without a stretch):
+  // nothing in this launch reads those rows, and in the prologue the barrier behind it waited for the stores (~4 us).
+  // (Reads the segments from the kernel arguments again: nothing of it stays alive across the K loops.)
+  auto clear_left_out = [&]() {
+    int ro[CARCA_MAX_SEGS + 1];
+    ro[0] = 0;
+#pragma unroll
+    for (int i = 0; i < CARCA_MAX_SEGS; ++i) ro[i + 1] = ro[i] + D.seg[i].rows;
+    const int R = ro[CARCA_MAX_SEGS];
+#pragma unroll 1
+    for (int k0 = wave * 64; id + (long)k0 * nblk < R; k0 += 12 * 64) {
+      const long g = id + (long)(k0 + lane) * nblk;
+      int sg = 0;
+#pragma unroll
+      for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+        if (D.seg[i].rows > 0 && g >= ro[i]) sg = i;
+      const int pv = D.seg[sg].ids[min(g, (long)R - 1) - ro[sg]];
+      const bool pad = g < R && pv == 0;
+      unsigned long long bal = __ballot(pad);
+      while (bal) {
+        const int b = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const long gz = id + (long)(k0 + b) * nblk;
+        int sz = 0;
+#pragma unroll
+        for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+          if (D.seg[i].rows > 0 && gz >= ro[i]) sz = i;
+        float* crow = D.seg[sz].c + (size_t)(gz - ro[sz]) * D.ldc;
+        for (int cc = lane; cc < D.ncols_out; cc += 64) crow[cc] = 0.f;
+      }
+    }
+  };
   // ---- 1. kept rows per 64-row chunk ----------------------------------------------------------------------------
   // (first chunk entry / first global row of segment s: running sums over at most four segments, recomputed where needed --
   // arrays indexed by a run-time s would live in scratch)
@@ -1107,7 +1140,7 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
   }
   __syncthreads();
   SKC_STAMP(1);
-  // ---- 2. wave 0: the chunks' counts become running sums per segment; the others clear the left-out rows --------
+  // ---- 2. wave 0: the chunks' counts become running sums per segment -------------------------------------------
   if (wave == 0) {
 #pragma unroll 1
     for (int s = 0; s < D.nseg; ++s) {
@@ -1133,32 +1166,6 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
         }
       }
       if (lane == 63) Cp[cb0 + nch] = incl;  // the segment's kept rows
-    }
-  } else {
-    // this workgroup's share of the left-out rows: global rows id, id + nblk, ... -- a lane looks at one row's id, the wave
-    // then clears the rows it found one by one
-    const int R = seg_roff(D.nseg);
-#pragma unroll 1
-    for (int k0 = (wave - 1) * 64; id + (long)k0 * nblk < R; k0 += 11 * 64) {
-      const long g = id + (long)(k0 + lane) * nblk;
-      int sg = 0;
-#pragma unroll
-      for (int i = 1; i < CARCA_MAX_SEGS; ++i)
-        if (i < D.nseg && g >= seg_roff(i)) sg = i;
-      const int pv = D.seg[sg].ids[min(g, (long)R - 1) - seg_roff(sg)];
-      const bool pad = g < R && pv == 0;
-      unsigned long long bal = __ballot(pad);
-      while (bal) {
-        const int b = __ffsll((long long)bal) - 1;
-        bal &= bal - 1;
-        const long gz = id + (long)(k0 + b) * nblk;
-        int sz = 0;
-#pragma unroll
-        for (int i = 1; i < CARCA_MAX_SEGS; ++i)
-          if (i < D.nseg && gz >= seg_roff(i)) sz = i;
-        float* crow = D.seg[sz].c + (size_t)(gz - seg_roff(sz)) * D.ldc;
-        for (int cc = lane; cc < D.ncols_out; cc += 64) crow[cc] = 0.f;
-      }
     }
   }
   __syncthreads();
@@ -1189,7 +1196,10 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
   const int y = (int)max(1l, min(cap, (long)nblk - (long)x * nfull));
   const int xcd = id & 7, nw = x * nfull + y, q8 = nw >> 3, r8 = nw & 7;
   const int cnt = xcd < r8 ? q8 + 1 : q8;
-  if (nrb == 0 || (id >> 3) >= cnt) return;
+  if (nrb == 0 || (id >> 3) >= cnt) {
+    clear_left_out();
+    return;
+  }
   const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
   const bool lone = w >= x * nfull;
   const int nteams = lone ? y : x;                       // stretches of this workgroup's kind
@@ -1320,6 +1330,7 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
       cu_tile<2, XC, SK_DYN>(args, As, Bs, rb, nfull_ * 96, s0, s1, !give, part, flag, dyn);
     SKC_STAMP(5 + 2 * p);
   }
+  clear_left_out();
 #undef SKC_STAMP
 }
 
