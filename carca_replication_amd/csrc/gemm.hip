@@ -1002,8 +1002,8 @@ __global__ __launch_bounds__(768) void gemm_rows_sk_kernel(const GemmDev args) {
 //    finds partials written most of a kernel ago.
 // Left-out rows of the output are cleared (each workgroup its share).  Results: the same sums as gemm_rows_sk_kernel in
 // another grouping of the K range (1e-7 relative), the same bits from run to run.
-constexpr int SKC_RB = 6;       // row blocks one workgroup's stretch may touch (the launcher checks rows against it)
-constexpr int SKC_CH = 2304;    // 64-row chunks of all segments (+ one entry per segment)
+constexpr int SKC_RB = 8;       // row blocks one workgroup's stretch may touch (the launcher checks rows against it)
+constexpr int SKC_CH = 1536;    // 64-row chunks of all segments (+ one entry per segment)
 
 template <int XC>
 __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) {
@@ -1271,6 +1271,8 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
   if (tid == 0) {
     // partial tile / flag of this workgroup's first piece (consecutive over the stretches of a column block)
     const int slot = (lone ? nfull * x : cb * x) + tj;
+    if (rbB - rbA + 1 > SKC_RB && args.sk_err)  // (the launcher's bound on rows rules this out)
+      __hip_atomic_store(args.sk_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int np = 0;
     for (int rb = rbA; rb <= rbB && np < SKC_RB; ++rb, ++np) {
       const int s0 = rb == rbA ? sA : 0, s1 = rb == rbB ? sB : nfast;
@@ -1857,6 +1859,12 @@ int* g_sk_err_dev = nullptr;   // carca_poll_errors
 // A kernel's failure that no launch status can carry (today: a stream-K taker that gave up waiting): CARCA_OK, or
 // CARCA_ERR_UNSUPPORTED with the message set -- the word is cleared by the call that reports it.
 static int sk_check_error_word() {
+  if (g_sk_err_host && *(volatile int*)g_sk_err_host == 2) {
+    *(volatile int*)g_sk_err_host = 0;
+    carca_set_error("gemm_rows: an EARLIER gemm_rows_skc_kernel launch met a stretch of more row blocks than its lists hold "
+                    "(its output is wrong): a launcher bug -- carca_set_tuning(0, 23) selects the kernel over every row");
+    return CARCA_ERR_UNSUPPORTED;
+  }
   if (g_sk_err_host && *(volatile int*)g_sk_err_host != 0) {
     *(volatile int*)g_sk_err_host = 0;
     carca_set_error("gemm_rows: an EARLIER stream-K launch gave up waiting for a partial tile (its output is wrong): "
@@ -1956,7 +1964,7 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
   if (ncb < 2 || desc->ncols_out != desc->N) return 1;
   const int rem = desc->N - 96 * nfull, xc = rem - 64;
   if (xc < 1 || xc > 2) return 1;
-  if (desc->colvec || desc->pos || desc->gate_scale != 0.f) return 1;
+  if (desc->colvec || desc->pos) return 1;  // (gate_scale only matters with a gate, and a segment with one is refused below)
   long rows = 0;
   GemmDev g{};
   g.d = *desc;
@@ -1972,7 +1980,14 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
   // (worth a persistent grid: at least most of a round of tiles if every row counted, and K long enough to share)
   if (nfast < 64 || ((rows + 383) / 384) * ncb < ncu / 2 || ncu > 1024) return 1;
   // (what the kernel's LDS lists hold: 64-row chunks of all segments, and SKC_RB row blocks per workgroup's stretch)
-  if (rows / 64 + 2 * desc->nseg > SKC_CH || ((rows + 383) / 384 + desc->nseg) > (SKC_RB - 2) * ((ncu - 1) / ncb)) return 1;
+  {
+    // a stretch of S row blocks touches at most ceil(S) + 1 of them; the longer stretches are the lone workgroups' (the
+    // kernel's own split of the grid into x teams and y lone workgroups, with every row kept)
+    const long nrb_max = (rows + 383) / 384 + desc->nseg, nblk = ncu - 1;
+    const long cheap = xc == 2 ? 74 : 71;
+    const long x = std::max(1l, nblk * 100 / (nfull * 100 + cheap)), y = std::max(1l, nblk - (x + 1) * nfull);
+    if (rows / 64 + 2 * desc->nseg > SKC_CH || (nrb_max + x - 1) / x + 1 > SKC_RB || (nrb_max + y - 1) / y + 1 > SKC_RB) return 1;
+  }
   g.ncb = ncb;
   g.skc_cheap = xc == 2 ? 74 : 71;  // (two MFMA column tiles of three + the VALU columns: 0.74 of a full step measured)
   if (!g_sk_err_host) {

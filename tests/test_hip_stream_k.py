@@ -217,3 +217,96 @@ def test_deterministic_mode_keeps_a_non_finite_gradient_visible():
         assert float(tab[1, 0]) == 1.0 and torch.isinf(tab[2, 3]) and torch.isnan(tab[3, 0]) and float(tab[4, 1]) == 3e8
     finally:
         ops.set_deterministic(False)
+
+
+@pytest.mark.parametrize("pattern", ["scattered", "left_padded", "one_segment_all_padding", "nothing_left_out", "all_padding"])
+def test_the_compacting_kernel_on_awkward_id_patterns(tuning, pattern):
+    """gemm_rows_skc_kernel (rows with id 0 left out, stretches over the kept rows' blocks) against the kernels that multiply
+    every row (tuning variant 23), on id patterns the batches of the hot path never produce: zeros sprinkled anywhere, a
+    segment that is nothing but padding, no padding at all, nothing but padding.  Kept rows agree to the round-off of another
+    grouping of the K sum; left-out rows are exact zeros."""
+    from carca_replication_amd import ops
+
+    K0, K1, N = 2048, 6, 450
+    rows = [6400, 5000, 3333]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = (torch.rand(N, K0 + K1, device="cuda", generator=g) * 2 - 1) * 0.03
+    b = torch.randn(N, device="cuda", generator=g) * 0.01
+    segs, ids_all = [], []
+    for si, r in enumerate(rows):
+        a = torch.rand(r, K0, device="cuda", generator=g)
+        c = torch.rand(r, K1, device="cuda", generator=g)
+        ids = torch.randint(1, 1000, (r,), device="cuda", dtype=torch.int32, generator=g)
+        if pattern == "scattered":
+            ids[torch.rand(r, device="cuda", generator=g) < 0.37] = 0
+        elif pattern == "left_padded":
+            t = torch.arange(r, device="cuda") % 50
+            npad = torch.randint(0, 48, ((r + 49) // 50,), device="cuda", generator=g).repeat_interleave(50)[:r]
+            ids[t < npad] = 0
+        elif pattern == "one_segment_all_padding" and si == 1:
+            ids[:] = 0
+        elif pattern == "all_padding":
+            ids[:] = 0
+        segs.append(dict(a0=a, a1=c, ids=ids))
+        ids_all.append(ids)
+
+    def run():
+        return ops.gemm_rows(segs, w[:, :K0], N, K0, 452, bt1=w[:, K0:], K1=K1, bias=b, mask_rows=True, ncols_out=N)
+
+    ops.gemm_rows_log(True)
+    got = run()
+    log = ops.gemm_rows_log()
+    ops.gemm_rows_log(False)
+    assert "gemm_rows_skc_kernel" in log
+    tuning(0, 23)
+    want = run()
+    tuning(0, 0)
+    torch.cuda.synchronize()
+    ops.poll_errors()
+    for x, y, ids in zip(got, want, ids_all):
+        assert float(x[ids == 0][:, :N].abs().max() if (ids == 0).any() else 0.0) == 0.0
+        scale = float(y[:, :N].abs().max()) + 1e-30
+        assert float((x[:, :N] - y[:, :N]).abs().max()) <= 4e-6 * scale + 1e-12  # (two groupings of a K = 2054 fp32 sum)
+    again = run()
+    for x, y in zip(got, again):
+        assert torch.equal(x[:, :N], y[:, :N])  # the same bits from run to run
+
+
+def test_the_compacting_kernel_at_b512_rows(tuning):
+    """C3's row count (77,312 rows, 202 row blocks when nothing is left out): stretches of five and more row blocks per
+    workgroup -- the launcher's bound on what the kernel's LDS lists hold."""
+    from carca_replication_amd import ops
+
+    K0, K1, N, B = 2048, 6, 450, 512
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = (torch.rand(N, K0 + K1, device="cuda", generator=g) * 2 - 1) * 0.03
+    b = torch.randn(N, device="cuda", generator=g) * 0.01
+    for full in (True, False):
+        segs, ids_all = [], []
+        for T in (50, 101):
+            r = B * T
+            ids = torch.randint(1, 1000, (r,), device="cuda", dtype=torch.int32, generator=g)
+            if not full and T == 50:
+                t = torch.arange(r, device="cuda") % 50
+                ids[t < torch.randint(0, 48, (B,), device="cuda", generator=g).repeat_interleave(50)] = 0
+            segs.append(dict(a0=torch.rand(r, K0, device="cuda", generator=g), a1=torch.rand(r, K1, device="cuda", generator=g),
+                             ids=ids))
+            ids_all.append(ids)
+
+        def run():
+            return ops.gemm_rows(segs, w[:, :K0], N, K0, 452, bt1=w[:, K0:], K1=K1, bias=b, mask_rows=True, ncols_out=N)
+
+        ops.gemm_rows_log(True)
+        got = run()
+        assert "gemm_rows_skc_kernel" in ops.gemm_rows_log()
+        ops.gemm_rows_log(False)
+        tuning(0, 23)
+        want = run()
+        tuning(0, 0)
+        torch.cuda.synchronize()
+        ops.poll_errors()
+        for x, y, ids in zip(got, want, ids_all):
+            scale = float(y[:, :N].abs().max())
+            assert float((x[:, :N] - y[:, :N]).abs().max()) <= 4e-6 * scale
+            if (ids == 0).any():
+                assert float(x[ids == 0][:, :N].abs().max()) == 0.0
