@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
     int idv[32];
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
-      const int g = min(g0 + ((u >> 3) * 12 + wave) * 8 + (u & 7), G - 1);  // (wave-uniform)
+      const int g = g0 + ((u >> 3) * 12 + wave) * 8 + (u & 7);  // (wave-uniform)
       int rows = seg_rows[0], gb = 0;
       const int32_t* ip = seg_ids[0];
 #pragma unroll
@@ -1123,9 +1123,10 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
           gb = seg_g0[i];
           ip = seg_ids[i];
         }
-      const int row = (g - gb) * 64 + lane;
-      const int v = ip[min(row, rows - 1)];
-      idv[u] = row < rows ? v : 0;
+      // (a buffer load bounded by the segment's rows: rows past its end -- and chunks past the last one -- read as id 0;
+      // scalar base + one lane offset instead of a 64-bit address per lane)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(ip), 0, (g < G && !(args.diag & 1)) ? rows * 4 : 0, 0x00020000);
+      idv[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs, ((g - gb) * 64 + lane) * 4, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
@@ -2020,6 +2021,7 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
   g.sk_flag = (int*)parts;
   g.sk_part = (float*)(parts + flag_bytes);
   g.dbg = carca_debug_buffer();
+  g.diag = carca_tuning(CARCA_TUNE_DIAG);  // (bit 0: the prologue's id loads read nothing -- timing experiment, wrong results)
   if (g_rows_log_on) carca_rows_log(xc == 1 ? "gemm_rows_skc_kernel<1>" : "gemm_rows_skc_kernel<2>", desc, grid);
   hipEvent_t e0, e1;
   const bool ev = carca_take_launch_events(&e0, &e1);

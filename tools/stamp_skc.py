@@ -21,7 +21,10 @@ with torch.no_grad():
         model(profile=profile, targets=[target])
     torch.cuda.synchronize()
     lib.carca_set_debug_buffer(buf.data_ptr())
+    if os.environ.get("DIAG"):
+        ops.set_tuning(15, int(os.environ["DIAG"]))
     model(profile=profile, targets=[target])
+    ops.set_tuning(15, 0)
     torch.cuda.synchronize()
     lib.carca_set_debug_buffer(None)
 r = buf[65536:].view(256, 16).cpu().double()
