@@ -72,7 +72,7 @@ struct GemmDev {
   int* sk_err;  // host-visible word: a taker's bounded wait expired
   unsigned sk_spin;  // the bound: sleeps of ~0.4 us a taker spends on one flag before it gives up (launcher: 2^23, ~5 s)
   int sk_withhold;   // TEST ONLY (tuning key 13): 1 + index of the one flag its giver does not raise; 0 = none
-  int skc_cheap;     // (unused)
+  int skc_cheap;     // gemm_rows_skc_kernel: cost of a K step of the narrow column block's tile in 1/100 of a full tile's step
 };
 
 

@@ -46,7 +46,10 @@ int carca_abi_version(void);
  *   key 0  row / weight-gradient GEMM: 1 force 128x96 tiles, 2 force the one-block-per-CU kernels, 3 = 2 + in-kernel
  *          stamps, 4 no buffer loads, 5 tiled weight gradient only, 6 never group weight gradients / row GEMMs,
  *          7 force the one-block-per-CU row GEMM with 384 x 128 tiles, 8 never let the item-row gather ride in the
- *          feature GEMM's launch
+ *          feature GEMM's launch, 15 the one-tile-per-workgroup feature GEMM (no hand-over of partial tiles), 19 the gather
+ *          keeps its own launch beside the stream-K kernels, 21 split-precision kernel without LDS-DMA, 22 weight gradient
+ *          over every row, 23 feature GEMM over every row (gemm_rows_sk_kernel instead of gemm_rows_skc_kernel, which
+ *          leaves rows with id 0 out); any non-zero value also moves the narrow row products off their default kernel
  *   key 1  attention kernels: 1 one workgroup per user, 2 always two, 3 one 8-wave workgroup per user (the variant
  *          for batches of more users than CUs, two workgroups resident per CU)
  *   key 2  weight gradient: row-split slot target      key 4  weight gradient: minimum 32-row chunks per split
@@ -69,7 +72,8 @@ int carca_abi_version(void);
  *          the launch's output is wrong, the library's error word is set and carca_poll_errors / the next such launch fail
  *   key 13 ... TEST ONLY: 1 + index of the one partial tile whose giver withholds its flag (exercises key 12's expiry)
  *   key 14 persistent scoring kernel: 1 = ticket dealing of a step's first jobs (A/B)
- *   key 15 timing diagnostics of the 80 x 96 row GEMM and the scoring kernels (bit masks; WRONG results)
+ *   key 15 timing diagnostics of the 80 x 96 row GEMM, the scoring kernels, the split-precision kernels and the prologue of
+ *          gemm_rows_skc_kernel (bit masks; WRONG results)
  *   key 16 PRECISION OF THE FEATURE GEMM (AllEmbedding.feats_embed, carca.py:86), opt-in: 0 = exact-fp32 MFMA (default,
  *          the path every parity figure is quoted on); 1 = operands split into three bf16 parts, six bf16-MFMA products,
  *          fp32 accumulation (fp32-class accuracy on the 16x faster pipe); 2 = two fp16 parts (the second scaled by
