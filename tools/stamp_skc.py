@@ -34,6 +34,8 @@ info = r[:, 10:13].clone().long()
 r = torch.where(r > 0, r - r[:, :1], torch.full_like(r, -1.0))  # per workgroup, since its own start (the XCDs' clocks differ)
 us = lambda x: x / 100.0  # noqa: E731
 print("workgroups with a stretch:", int(act.sum()))
+if not act.any():
+    sys.exit(0)  # (DIAG=1: no ids read, nothing kept)
 for k, name in ((0, "start"), (1, "after chunk counts"), (2, "after running sums / clearing"), (3, "after row lists")):
     x = us(r[act, k])
     print(f"{name:32s} mean {x.mean():7.2f} us   max {x.max():7.2f}")
