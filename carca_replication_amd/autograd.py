@@ -158,7 +158,10 @@ class _Tail:
 SPLIT_EMBED_BWD = "graph"  # "graph": while a hipGraph is being captured (engine.GraphedTrainStep) -- an eager step is bound by
                            # its ~40 launches' host time (1.7 ms at C2), which the split's extra launches only add to (eager
                            # steps measured 1.71-2.48 ms with it, 1.79 without); True: always; False: never
-SPLIT_SIDE_CUS = 96        # CU budget of the second stream's weight-gradient launch; the first stream's gets the rest
+SPLIT_SIDE_CUS = 128       # CU budget of the second stream's weight-gradient launch (round 4, after both feats_embed products
+                           # left the padding's rows out: 96 / rest 1.213 ms, 128 / all 1.205, 144 / all 1.213, one stream 1.238)
+SPLIT_MAIN_CUS = 256       # CU budget of the FIRST stream's weight-gradient launch (the profile rows', issued behind the encoder's
+                           # backward chain); 0 = the CUs the second stream's launch leaves
 SPLIT_MAIN_TARGET_USERS = 0.04  # share of the FIRST target segment's users left to the first stream (balance; C2: 0 / 0.04 / 0.08
                                 # -> 1.654 / 1.642 / 1.655 ms per step)
 SPLIT_MIN_GFLOP = 20.0     # the split pays when d feats_embed is long against the launches it doubles (C2: 71 GFLOP per pass)
@@ -198,6 +201,8 @@ class _SideEmbed:
                 ops.set_tuning(10, 0)
 
     def main_cus(self) -> int:
+        if SPLIT_MAIN_CUS > 0:
+            return min(SPLIT_MAIN_CUS, self.cus)
         return max(8, self.cus - min(SPLIT_SIDE_CUS, self.cus))
 
     def join(self, gbp) -> None:

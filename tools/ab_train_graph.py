@@ -1,6 +1,6 @@
 """A/B of the GRAPHED train step (engine.GraphedTrainStep at C2, B = 128) under settings of the backward's two-stream
 split (autograd.SPLIT_EMBED_BWD / SPLIT_SIDE_CUS / SPLIT_MAIN_TARGET_USERS), interleaved in one process.
-usage: ab_train_graph.py "split=0" "split=1,side=128,frac=0.0" "split=1,side=96,frac=0.1" ...   (+ "t<key>=<value>" = tuning keys)"""
+usage: ab_train_graph.py "split=0" "split=1,side=128,frac=0.0" "split=1,side=96,main=256,frac=0.1" ...   (+ "t<key>=<value>" = tuning keys)"""
 import os
 import sys
 
@@ -29,6 +29,7 @@ res = {s: [] for s in settings}
 for rnd in range(int(os.environ.get("ROUNDS", "4"))):
     for s in settings:
         autograd.SPLIT_EMBED_BWD, autograd.SPLIT_SIDE_CUS, autograd.SPLIT_MAIN_TARGET_USERS = "graph", 128, 0.04
+        autograd.SPLIT_MAIN_CUS = 256
         for k in range(8):
             lib.carca_set_tuning(k, 0)
         for kv in filter(None, s.split(",")):
@@ -37,6 +38,8 @@ for rnd in range(int(os.environ.get("ROUNDS", "4"))):
                 autograd.SPLIT_EMBED_BWD = "graph" if v == "graph" else bool(int(v))
             elif k == "side":
                 autograd.SPLIT_SIDE_CUS = int(v)
+            elif k == "main":
+                autograd.SPLIT_MAIN_CUS = int(v)
             elif k == "frac":
                 autograd.SPLIT_MAIN_TARGET_USERS = float(v)
             elif k.startswith("t"):
