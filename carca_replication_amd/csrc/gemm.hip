@@ -1963,8 +1963,9 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
   if (!desc->mask_rows) return 1;  // (rows with id 0 may be left out only where the product masks them)
   const int ncb = (desc->ncols_out + 95) / 96, nfull = ncb - 1;
   if (ncb < 2 || desc->ncols_out != desc->N) return 1;
-  const int rem = desc->N - 96 * nfull, xc = rem - 64;
-  if (xc < 1 || xc > 2) return 1;
+  // (the narrow last column block: two MFMA column tiles -- of 33..64 columns -- + up to 2 VALU columns)
+  const int rem = desc->N - 96 * nfull, xc = rem > 64 ? rem - 64 : 0;
+  if (rem <= 32 || xc > 2) return 1;
   if (desc->colvec || desc->pos) return 1;  // (gate_scale only matters with a gate, and a segment with one is refused below)
   long rows = 0;
   GemmDev g{};
@@ -1985,12 +1986,12 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
     // a stretch of S row blocks touches at most ceil(S) + 1 of them; the longer stretches are the lone workgroups' (the
     // kernel's own split of the grid into x teams and y lone workgroups, with every row kept)
     const long nrb_max = (rows + 383) / 384 + desc->nseg, nblk = ncu - 1;
-    const long cheap = xc == 2 ? 74 : 71;
+    const long cheap = xc == 2 ? 74 : (xc == 1 ? 71 : 68);
     const long x = std::max(1l, nblk * 100 / (nfull * 100 + cheap)), y = std::max(1l, nblk - (x + 1) * nfull);
     if (rows / 64 + 2 * desc->nseg > SKC_CH || (nrb_max + x - 1) / x + 1 > SKC_RB || (nrb_max + y - 1) / y + 1 > SKC_RB) return 1;
   }
   g.ncb = ncb;
-  g.skc_cheap = xc == 2 ? 74 : 71;  // (two MFMA column tiles of three + the VALU columns: 0.74 of a full step measured)
+  g.skc_cheap = xc == 2 ? 74 : (xc == 1 ? 71 : 68);  // (two MFMA column tiles of three + the VALU columns: 0.74 of a full step measured)
   if (!g_sk_err_host) {
     if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped) != hipSuccess) return 1;
     *g_sk_err_host = 0;
@@ -2022,10 +2023,14 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
   g.sk_part = (float*)(parts + flag_bytes);
   g.dbg = carca_debug_buffer();
   g.diag = carca_tuning(CARCA_TUNE_DIAG);  // (bit 0: the prologue's id loads read nothing -- timing experiment, wrong results)
-  if (g_rows_log_on) carca_rows_log(xc == 1 ? "gemm_rows_skc_kernel<1>" : "gemm_rows_skc_kernel<2>", desc, grid);
+  if (g_rows_log_on)
+    carca_rows_log(xc == 0 ? "gemm_rows_skc_kernel<0>" : (xc == 1 ? "gemm_rows_skc_kernel<1>" : "gemm_rows_skc_kernel<2>"), desc, grid);
   hipEvent_t e0, e1;
   const bool ev = carca_take_launch_events(&e0, &e1);
-  if (xc == 1) {
+  if (xc == 0) {
+    if (ev) hipExtLaunchKernelGGL((gemm_rows_skc_kernel<0>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
+    else hipLaunchKernelGGL((gemm_rows_skc_kernel<0>), dim3(grid), dim3(768), 0, stream, g);
+  } else if (xc == 1) {
     if (ev) hipExtLaunchKernelGGL((gemm_rows_skc_kernel<1>), dim3(grid), dim3(768), 0, stream, e0, e1, 0, g);
     else hipLaunchKernelGGL((gemm_rows_skc_kernel<1>), dim3(grid), dim3(768), 0, stream, g);
   } else {
@@ -2181,7 +2186,10 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
       return rc == 1 ? launch_gemm_rows_cu<0>(desc, stream) : rc;
     }
     case GEMM_CU_STAMPS: return launch_gemm_rows_cu<1>(desc, stream);
-    case GEMM_CU128: return launch_gemm_rows_cu<0, 4>(desc, stream);
+    case GEMM_CU128: {  // (384 x 128 tiles fill one round where 96-wide ones would not -- unless the rows with id 0 can go)
+      const int rc = launch_gemm_rows_skc(desc, stream, nullptr, nullptr);
+      return rc == 1 ? launch_gemm_rows_cu<0, 4>(desc, stream) : rc;
+    }
     case GEMM_WIDE64: return launch_gemm_rows<64, 96, 32, 4, true>(desc, stream);
     case GEMM_WIDE64_PF2: return launch_gemm_rows<64, 96, 32, 2, true>(desc, stream);
     case GEMM_N96: return launch_gemm_rows_n96(desc, stream);
@@ -2204,7 +2212,10 @@ int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* 
     rc = launch_gemm_rows_sk(desc, stream, ga, rode);
     return rc == 1 ? launch_gemm_rows_cu<0, 3>(desc, stream, ga, rode) : rc;
   }
-  if (c == GEMM_CU128) return launch_gemm_rows_cu<0, 4>(desc, stream, ga, rode);
+  if (c == GEMM_CU128) {
+    const int rc = launch_gemm_rows_skc(desc, stream, ga, rode);
+    return rc == 1 ? launch_gemm_rows_cu<0, 4>(desc, stream, ga, rode) : rc;
+  }
   return carca_gemm_rows(desc, stream_);
 }
 

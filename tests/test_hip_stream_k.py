@@ -310,3 +310,42 @@ def test_the_compacting_kernel_at_b512_rows(tuning):
             assert float((x[:, :N] - y[:, :N]).abs().max()) <= 4e-6 * scale
             if (ids == 0).any():
                 assert float(x[ids == 0][:, :N].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N", [640, 449, 434])
+def test_the_compacting_kernel_with_other_narrow_column_blocks(tuning, N):
+    """N = 640 = 6 x 96 + 64 (C4's g: the narrow block is exactly two MFMA column tiles, teams of six) and N = 449 (one VALU
+    column) and N = 434 (a narrow block of 50 columns) through gemm_rows_skc_kernel, against the kernels that multiply every row."""
+    from carca_replication_amd import ops
+
+    K0, K1 = 2048, 6
+    g = torch.Generator(device="cuda").manual_seed(9)
+    w = (torch.rand(N, K0 + K1, device="cuda", generator=g) * 2 - 1) * 0.03
+    b = torch.randn(N, device="cuda", generator=g) * 0.01
+    segs, ids_all = [], []
+    for r in (6400, 12928):
+        ids = torch.randint(1, 1000, (r,), device="cuda", dtype=torch.int32, generator=g)
+        if r == 6400:
+            t = torch.arange(r, device="cuda") % 50
+            ids[t < torch.randint(0, 48, (r // 50,), device="cuda", generator=g).repeat_interleave(50)] = 0
+        segs.append(dict(a0=torch.rand(r, K0, device="cuda", generator=g), a1=torch.rand(r, K1, device="cuda", generator=g), ids=ids))
+        ids_all.append(ids)
+    ld = (N + 3) // 4 * 4
+
+    def run():
+        return ops.gemm_rows(segs, w[:, :K0], N, K0, ld, bt1=w[:, K0:], K1=K1, bias=b, mask_rows=True, ncols_out=N)
+
+    ops.gemm_rows_log(True)
+    got = run()
+    assert "gemm_rows_skc_kernel" in ops.gemm_rows_log()
+    ops.gemm_rows_log(False)
+    tuning(0, 23)
+    want = run()
+    tuning(0, 0)
+    torch.cuda.synchronize()
+    ops.poll_errors()
+    for x, y, ids in zip(got, want, ids_all):
+        scale = float(y[:, :N].abs().max())
+        assert float((x[:, :N] - y[:, :N]).abs().max()) <= 4e-6 * scale
+        if (ids == 0).any():
+            assert float(x[ids == 0][:, :N].abs().max()) == 0.0
