@@ -237,7 +237,10 @@ int carca_gemm_wgrad_group(const CarcaWgradDesc* descs /*host, [n]*/, int n, voi
  *   q = [attrs ; ctx] W_f^T + b_f ; z = E[ids] * sqrt(d) ; e = [z ; q] W_j^T + b_j (+ pos[t]) ;
  *   e *= (ids != 0).
  * zq is workspace AND the tensor the backward needs: [sum(rows), d + g], rows of segment s
- * start at sum(rows of earlier segments).  e_out rows have stride ld_e >= d, columns d..ld_e-1
+ * start at sum(rows of earlier segments).  The q columns of rows with id 0 are written as ZEROS, not computed: their e is
+ * masked (carca.py:92-94) and their gradient is zero, so the feature product leaves those rows out where that pays
+ * (gemm_rows_skc_kernel: 16 % of an evaluation batch's rows at BASELINE's profile lengths, 47 % of a training batch's).
+ * e_out rows have stride ld_e >= d, columns d..ld_e-1
  * are written as zeros.  `stages` selects which of the three launches to issue (bit 0 gather,
  * bit 1 feature GEMM, bit 2 joint GEMM; 7 = all) so a profiler can bracket one of them with events. */
 typedef struct CarcaRowSeg {
