@@ -914,15 +914,17 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
       float v = 0.f;
       if (n_ok) {
         v = (D.alpha != 0.f ? D.alpha * acc[tn][r] : acc[tn][r]) + bias;
-        if (sg.add_pos) v += D.pos[(size_t)(row % sg.T) * D.N + n];
-        if (sg.add) v += sg.add[(size_t)row * D.ld_add + n];
-        if (sg.rowscale) v += sg.rowscale[row] * cv;
-        if (sg.gate) {
-          const float gv = sg.gate[(size_t)row * D.ld_gate + n];
-          const float gs = D.gate_scale != 0.f ? D.gate_scale : 1.0f;
-          v *= gv > 0.f ? gs : ((gv < 0.f || !D.gate_zero_drops) ? D.gate_slope * gs : 0.f);
+        if constexpr (!IDX) {  // (gemm_rows_skc_kernel is admitted for the plain epilogue only: alpha, bias, kept rows)
+          if (sg.add_pos) v += D.pos[(size_t)(row % sg.T) * D.N + n];
+          if (sg.add) v += sg.add[(size_t)row * D.ld_add + n];
+          if (sg.rowscale) v += sg.rowscale[row] * cv;
+          if (sg.gate) {
+            const float gv = sg.gate[(size_t)row * D.ld_gate + n];
+            const float gs = D.gate_scale != 0.f ? D.gate_scale : 1.0f;
+            v *= gv > 0.f ? gs : ((gv < 0.f || !D.gate_zero_drops) ? D.gate_slope * gs : 0.f);
+          }
+          if (D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;
         }
-        if (!IDX && D.mask_rows) v = sg.ids[row] != 0 ? v : 0.f;
       }
       sg.c[(size_t)row * D.ldc + n] = v;
     }
