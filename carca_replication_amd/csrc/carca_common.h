@@ -201,6 +201,20 @@ __device__ __forceinline__ void carca_gather_rows(const CarcaGatherArgs& ga, int
   }
 }
 
+// First statement of a kernel with a big argument block: ONE scalar load per 64-byte line of the kernel-argument segment, all
+// in flight together.  hipcc loads arguments where the code first needs them; behind branches on other arguments that is a
+// chain of dependent scalar loads, each a cold miss when the kernel starts -- gemm_rows_skc_kernel's eight of them were the
+// 8.9 us in front of its first barrier (tools/stamp_skc.py).
+template <int BYTES>
+__device__ __forceinline__ void carca_warm_kernargs() {
+  typedef const __attribute__((address_space(4))) int* karg_ptr;
+  karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  int w = 0;
+#pragma unroll
+  for (int i = 0; i < (BYTES + 63) / 64; ++i) w ^= ka[i * 16];
+  asm volatile("" ::"s"(w));
+}
+
 // tuning knobs (api.hip): small integers a tuning run selects with carca_set_tuning(); 0 = shipped choice.  ONE meaning
 // per key (include/carca_hip.h lists them); keys 3..7 are used by number.
 enum { CARCA_TUNE_GEMM_VARIANT = 0, CARCA_TUNE_ATTN_VARIANT = 1, CARCA_TUNE_WGRAD_SLOTS = 2, CARCA_TUNE_DETERMINISTIC = 8,

@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(768) void gemm_rows_sk_kernel(const GemmDev args) {
 // another grouping of the K range (1e-7 relative), the same bits from run to run.
 constexpr int SKC_RB = 8;       // row blocks one workgroup's stretch may touch (the launcher checks rows against it)
 constexpr int SKC_CH = 1536;    // 64-row chunks of all segments (+ one entry per segment)
+constexpr int SKC_LDS_IDS = 2 * 384 * 36;  // ids the prologue keeps in LDS (the A buffers' space: 27,648)
 
 template <int XC>
 __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) {
@@ -1014,6 +1015,8 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
   __shared__ int Rl[SKC_RB * 384];  // kept rows of this workgroup's row blocks
   __shared__ int Cp[SKC_CH];        // kept rows before each 64-row chunk of its segment (+ the segment's total)
   __shared__ int Pc[8 * SKC_RB + 4];  // this workgroup's pieces (step 5)
+  carca_warm_kernargs<sizeof(GemmDev)>();
+  if (args.dbg && (threadIdx.x & 63) == 0) args.dbg[65536 + 4096 + blockIdx.x * 16 + (threadIdx.x >> 6)] = wall_clock64();
   const CarcaGemmDesc& D = args.d;
   const int id = blockIdx.x, nblk = gridDim.x - args.has_pas;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1110,8 +1113,60 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
       gb += (nrows_[i] + 63) / 64;
     }
   }
+  // Up to SKC_LDS_IDS ids go to LDS by LDS-DMA, from two LOOPS of a few instructions each: the prologue runs once per
+  // workgroup, so every line of its code is an instruction-cache miss -- the unrolled version below (32 loads' address
+  // arithmetic, 32 ballots: ~10 KB of straight-line code) spent 8.4 us in front of its first barrier whether its loads read
+  // anything or not (tuning key 15 bit 0), and the waves of a workgroup start within 0.05 us of each other.
+  int* const Ai = reinterpret_cast<int*>(As);
+  const bool ids_in_lds = G * 64 <= SKC_LDS_IDS;
+  SKC_STAMP(4096 + 12);
+  if (ids_in_lds) {
+    // (segment by segment: picking the segment of every chunk with compares made each iteration a chain of ~20 dependent
+    // scalar instructions, 150 cycles -- 25 iterations of it were the larger part of the 8.4 us)
+    typedef __attribute__((address_space(3))) void* lds_ptr;
 #pragma unroll 1
-  for (int g0 = 0; g0 < G; g0 += 12 * 32) {
+    for (int sgi = 0; sgi < D.nseg; ++sgi) {
+      int rows = nrows_[0], gb = 0;
+      const int32_t* ip = ids_[0];
+#pragma unroll
+      for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+        if (i <= sgi) {
+          gb += (nrows_[i - 1] + 63) / 64;
+          if (i == sgi) {
+            rows = nrows_[i];
+            ip = ids_[i];
+          }
+        }
+      const __amdgpu_buffer_rsrc_t rs = carca_rsrc(ip);
+      const int nch = (rows + 63) / 64;
+#pragma unroll 4
+      for (int c = wave; c < nch; c += 12)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(Ai + (gb + c) * 64), 4, min(c * 64 + lane, rows - 1) * 4, 0, 0, 0);
+    }
+    SKC_STAMP(4096 + 13);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SKC_STAMP(4096 + 14);
+#pragma unroll 1
+    for (int sgi = 0; sgi < D.nseg; ++sgi) {
+      int rows = nrows_[0], gb = 0;
+#pragma unroll
+      for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+        if (i <= sgi) {
+          gb += (nrows_[i - 1] + 63) / 64;
+          if (i == sgi) rows = nrows_[i];
+        }
+      const int nch = (rows + 63) / 64;
+#pragma unroll 4
+      for (int c = wave; c < nch; c += 12) {
+        const bool keep = c * 64 + lane < rows && Ai[(gb + c) * 64 + lane] != 0;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) Cp[gb + c + sgi] = __popcll(bal);
+      }
+    }
+    SKC_STAMP(4096 + 15);
+  }
+#pragma unroll 1
+  for (int g0 = ids_in_lds ? G : 0; g0 < G; g0 += 12 * 32) {
     int idv[32];
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
@@ -1246,7 +1301,17 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
       }
       ch = l;
     }
-    for (int c0 = cl + sub * 4; c0 < ch; c0 += nsub * 4) {
+    if (ids_in_lds) {
+      const int gbase = cb0 - s;  // (chunk c of the segment is chunk gbase + c of all segments: one Cp entry fewer per segment)
+#pragma unroll 1
+      for (int c = cl + sub; c < ch; c += nsub) {
+        const bool keep = c * 64 + lane < sg.rows && Ai[(gbase + c) * 64 + lane] != 0;
+        const unsigned long long bal = __ballot(keep);
+        const int pos = Cp[cb0 + c] + __popcll(bal & below);
+        if (keep && pos >= p0 && pos < p1) Rl[(rb - rbA) * 384 + pos - p0] = c * 64 + lane;
+      }
+    }
+    for (int c0 = ids_in_lds ? ch : cl + sub * 4; c0 < ch; c0 += nsub * 4) {
       int idv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {

@@ -15,7 +15,7 @@ model = build_model(dict(d=90, H=3, n_blocks=2), 12102, 450, 6, 4096, 50).cuda()
 profile, target, _ = synth_eval_batch(128, 50, 101, 12102, 4096, 6, seed=1)
 profile, target = tuple(t.cuda() for t in profile), tuple(t.cuda() for t in target)
 lib = _lib.load()
-buf = torch.zeros(65536 + 256 * 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(65536 + 2 * 256 * 16, dtype=torch.int64, device="cuda")
 with torch.no_grad():
     for _ in range(30):
         model(profile=profile, targets=[target])
@@ -27,7 +27,11 @@ with torch.no_grad():
     ops.set_tuning(15, 0)
     torch.cuda.synchronize()
     lib.carca_set_debug_buffer(None)
-r = buf[65536:].view(256, 16).cpu().double()
+r = buf[65536:65536 + 4096].view(256, 16).cpu().double()
+ws = buf[65536 + 4096:].view(256, 16).cpu().double()[:, :12]
+print("a workgroup's waves start within %.2f us of each other (mean over workgroups; max %.2f); wave 0 first: %.0f %%" % (
+    float((ws.max(1).values - ws.min(1).values).mean()) / 100, float((ws.max(1).values - ws.min(1).values).max()) / 100,
+    100 * float((ws.argmin(1) == 0).float().mean())))
 print("the gather's workgroup (last one): %.1f us" % ((float(r[255, 1]) - float(r[255, 0])) / 100.0))
 act = r[:, 3] > 0
 info = r[:, 10:13].clone().long()
@@ -39,7 +43,11 @@ if not act.any():
 for k, name in ((0, "start"), (1, "after chunk counts"), (2, "after running sums / clearing"), (3, "after row lists")):
     x = us(r[act, k])
     print(f"{name:32s} mean {x.mean():7.2f} us   max {x.max():7.2f}")
-for piece in range(3):
+fine = buf[65536 + 4096:].view(256, 16).cpu().double()[:, 12:16] - buf[65536:65536 + 4096].view(256, 16).cpu().double()[:, :1]
+for k, name in ((0, "  prologue: arguments read"), (1, "  prologue: id loads issued"), (2, "  prologue: ids in LDS"), (3, "  prologue: chunks counted")):
+    x = fine[act, k] / 100.0
+    print(f"{name:32s} mean {x.mean():7.2f} us   max {x.max():7.2f}")
+for piece in range(1):
     a, b = r[:, 4 + 2 * piece], r[:, 5 + 2 * piece]
     m = act & (b >= 0)
     if m.any():
@@ -53,7 +61,7 @@ for w in (0, 1, 2, 3, 4, 5, 128, 250, 254):
 # us per K step by kind of piece: whole row blocks / given (first) pieces / taken (last) pieces, teams and lone workgroups
 import collections
 acc = collections.defaultdict(list)
-raw = buf[65536:].view(256, 16).cpu().double()
+raw = buf[65536:65536 + 4096].view(256, 16).cpu().double()
 for wg in range(256):
     for pc in range(3):
         v = int(info[wg, pc])
