@@ -162,8 +162,10 @@ SPLIT_SIDE_CUS = 128       # CU budget of the second stream's weight-gradient la
                            # left the padding's rows out: 96 / rest 1.213 ms, 128 / all 1.205, 144 / all 1.213, one stream 1.238)
 SPLIT_MAIN_CUS = 256       # CU budget of the FIRST stream's weight-gradient launch (the profile rows', issued behind the encoder's
                            # backward chain); 0 = the CUs the second stream's launch leaves
-SPLIT_MAIN_TARGET_USERS = 0.04  # share of the FIRST target segment's users left to the first stream (balance; C2: 0 / 0.04 / 0.08
-                                # -> 1.654 / 1.642 / 1.655 ms per step)
+SPLIT_MAIN_TARGET_USERS = 0.25  # share of the FIRST target segment's users left to the first stream, whose last launch takes
+                                # every CU once the second stream's is done (C2, round 4: 0.04 / 0.15 / 0.2 / 0.25 / 0.3 / 0.35
+                                # -> 1.215 / 1.196 / 1.188 / 1.185 / 1.203 / 1.207 ms per graphed step; round 3: 0 / 0.04 / 0.08
+                                # -> 1.654 / 1.642 / 1.655)
 SPLIT_MIN_GFLOP = 20.0     # the split pays when d feats_embed is long against the launches it doubles (C2: 71 GFLOP per pass)
 _SIDE_STREAMS = {}
 

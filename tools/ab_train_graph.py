@@ -28,7 +28,7 @@ lib = _lib.load()
 res = {s: [] for s in settings}
 for rnd in range(int(os.environ.get("ROUNDS", "4"))):
     for s in settings:
-        autograd.SPLIT_EMBED_BWD, autograd.SPLIT_SIDE_CUS, autograd.SPLIT_MAIN_TARGET_USERS = "graph", 128, 0.04
+        autograd.SPLIT_EMBED_BWD, autograd.SPLIT_SIDE_CUS, autograd.SPLIT_MAIN_TARGET_USERS = "graph", 128, 0.25
         autograd.SPLIT_MAIN_CUS = 256
         for k in range(8):
             lib.carca_set_tuning(k, 0)
