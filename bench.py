@@ -12,7 +12,8 @@ n_items=12,102).  Users shard across ranks with no data-path collective (weak sc
 scores its own 128-user batch); the only collectives are the timing barrier and the max-over-ranks.
 
 Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (the F->g feature GEMM of
-AllEmbedding, 97% of the model's flops): algorithmic flops per launch / its mean duration measured
+AllEmbedding, 97% of the model's flops): the flops it EXECUTES per launch (rows with id != 0; `effective_*` = SURVEY 8d's
+algorithmic flops over every padded row; `*_full_profiles` = the same step with nothing to leave out) / its mean duration measured
 with events bound to its own dispatch on the launch stream inside the timed region (every fourth step:
 a pair costs ~5 us per step); the smaller kernels' entries come from a pass right behind it.  `cpu_baseline` is the CPU oracle
 (oracle/carca_oracle.py, a port of the reference's PyTorch-CPU path) on all host cores.
@@ -209,8 +210,15 @@ def measure_train(c, model, rank, world, device, steps, fold=False, graphed=Fals
     if not fold:
         tf = train_flops_per_user(c)
         ach = c["B"] * tf["total"] / (dt / steps) / 1e12
-        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "needed_gflop_per_step": c["B"] * tf["total"] / 1e9,
+        # rows the two feats_embed products multiply (ids != 0 of profile + both target halves) out of 3 L per user
+        kept = float((batch[0] != 0).sum() + (batch[3] != 0).sum()) / float(batch[0].numel() + batch[3].numel())
+        executed = c["B"] * (kept * (tf["feat_fwd"] + tf["feat_dw"]) + tf["rest"])
+        ach_x = executed / (dt / steps) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": ach_x, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach_x / PEAK_F32_MFMA_TFLOPS, "executed_gflop_per_step": executed / 1e9,
+                           "rows_multiplied_share": kept,
+                           "effective_tflops": ach, "effective_frac": ach / PEAK_F32_MFMA_TFLOPS,
+                           "needed_gflop_per_step": c["B"] * tf["total"] / 1e9,
                            "dominant_kernels": "gemm_wgrad_cu_kernel (dW of feats_embed, %.1f GFLOP) and gemm_rows_skc_kernel "
                                                "(its forward product, the same flops): %.0f %% of the step's needed flops"
                                                % (c["B"] * tf["feat_dw"] / 1e9, 200.0 * tf["feat_fwd"] / tf["total"]),
@@ -218,9 +226,10 @@ def measure_train(c, model, rank, world, device, steps, fold=False, graphed=Fals
                                    "weight gradient for the two products whose inputs are data (feats_embed: 2x its forward, "
                                    "not 3x), forward + both gradients for everything else; per-kernel durations of the same "
                                    "step: profiles/*_train_kernel_stats.csv.  Both feats_embed products leave the padding's rows "
-                                   "out (ids == 0: ~47 %% of a training batch's rows with BASELINE's profile lengths), so the "
-                                   "flops EXECUTED are about half the needed figure: frac says how fast the step delivers the "
-                                   "reference's arithmetic, not how busy the MFMA pipe is"}
+                                   "out (ids == 0: ~47 %% of a training batch's rows with BASELINE's profile lengths): "
+                                   "achieved / frac count those two products over the rows they multiply (EXECUTED flops, "
+                                   "never above the peak); effective_* count every padded row (NEEDED flops: how fast the step "
+                                   "delivers the reference's arithmetic)"}
     return out
 
 
@@ -338,6 +347,34 @@ def measure_split_path(c, model, profile, target, profile_cpu, target_cpu, fence
                                       "note": "algorithmic fp32 flops of the product / kernel time, against the dense 16-bit "
                                               "MFMA peak (2500 TF) / %d products per fp32 product" % passes}}
     return out
+
+
+def measure_full_profiles(c, model, device, fence, steps, warmup, fl):
+    """The same step with EVERY profile full (L items, no padding: nothing for the compacting feature GEMM to leave out), so
+    that the line carries a figure that does not depend on the batch's padding share ("What's weak" 2).  Side
+    pass: the forward between two fences as the headline, then 24 launches of the feature GEMM with an event pair bound to
+    its dispatch."""
+    import torch
+
+    from carca_replication_amd import ops
+    from carca_replication_amd.synth import eval_batch
+
+    prof, targ, _ = eval_batch(c["B"], c["L"], c["N"], c["n_items"], c["n_attrs"], c["n_ctx"], seed=777, min_len=c["L"])
+    prof, targ = tuple(t.to(device) for t in prof), tuple(t.to(device) for t in targ)
+    assert bool((prof[0] != 0).all())
+    with torch.no_grad():
+        dt = timed_loop(lambda: model(profile=prof, targets=[targ]), steps, warmup, fence)
+        evs = [[ops.HipEvent() for _ in range(2)] for _ in range(24)]
+        for e in evs:
+            ops.set_fused_events([e[0].handle, e[1].handle] + [None] * 6)
+            model(profile=prof, targets=[targ])
+        ops.set_fused_events(None)
+        fence()
+    ms = sorted(e[0].elapsed_ms(e[1]) for e in evs)
+    avg = sum(ms) / len(ms)
+    tf = c["B"] * fl["feat"] / (avg * 1e-3) / 1e12
+    return {"users_per_s": c["B"] * steps / dt, "ms_per_step": 1e3 * dt / steps, "feat_gemm_avg_ms": avg,
+            "feat_gemm_tflops": tf, "feat_gemm_frac": tf / PEAK_F32_MFMA_TFLOPS}
 
 
 def measure_epoch_pipeline(c, model, device, world, fence, n_batches=256):
@@ -548,7 +585,13 @@ def main():
             step(True, every_kernel=True)
         fence()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    per_rank_s = [elapsed]
     if world > 1:
+        # every rank's own time for its K steps (for the line's per-rank users/s), then the max over ranks
+        mine = torch.zeros(world, dtype=torch.float64, device=device)
+        mine[rank] = elapsed
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank_s = [float(v) for v in mine.tolist()]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
@@ -556,6 +599,10 @@ def main():
     if not args.no_split and rank == 0:
         split_info = measure_split_path(c, model, profile, target, profile_cpu, target_cpu, fence if world == 1 else
                                         torch.cuda.synchronize, args.steps, args.warmup, 1, fl)
+
+    full_info = None
+    if rank == 0 and world == 1:
+        full_info = measure_full_profiles(c, model, device, fence, args.steps, args.warmup, fl)
 
     # extension path: attribute table resident in HBM, ids-only batches, gather fused into the GEMM
     table_info = epoch_info = None
@@ -656,7 +703,8 @@ def main():
                                    "d=90 g=450 H=3 2 SA blocks + cross-attention decoder, n_attrs=4096 n_ctx=6 "
                                    "n_items=12102, random-init weights" % c["B"],
                        "users_per_gpu_per_step": c["B"], "parallelism": f"users sharded x{world}, no data-path collective",
-                       "collective": collective},
+                       "collective": collective,
+                       "per_rank_users_per_s": [c["B"] * args.steps / t for t in per_rank_s]},
             "model_tflops": value * fl["total"] / 1e12,
             "preheat_ms": 1e3 * PREHEAT_S, "preheat_steps": n_heat,
             "timeline": {"gpu_span_ms": gpu_span_ms, "host_issue_ms": host_issue_ms,
@@ -666,15 +714,22 @@ def main():
                                    "tiles over the rows whose id is not 0 -- the padding's rows are masked two lines later, "
                                    "carca.py:92-94 --, one workgroup per CU; teams of workgroups share the K steps of all row "
                                    "blocks as stretches and hand partial tiles to their neighbours)",
-                         "bound": "mfma", "achieved": feat_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": feat_tflops / PEAK_F32_MFMA_TFLOPS,
+                         "bound": "mfma", "achieved": feat_tflops * kept_share, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": feat_tflops * kept_share / PEAK_F32_MFMA_TFLOPS,
                          "rows_multiplied_share": kept_share,
-                         "achieved_on_rows_multiplied": feat_tflops * kept_share,
-                         "frac_on_rows_multiplied": feat_tflops * kept_share / PEAK_F32_MFMA_TFLOPS,
-                         "flops_note": "achieved / frac: ALGORITHMIC flops of the product (every slot of the padded id matrices, "
-                                       "SURVEY 8d) / kernel time; *_on_rows_multiplied: the flops the kernel executes (rows with "
-                                       "id != 0: BASELINE's profile lengths U{3..50} leave %.1f %% of this batch's rows out) -- "
-                                       "the share of the MFMA peak the kernel really reaches" % (100 * (1 - kept_share)),
+                         "effective_tflops": feat_tflops,
+                         "effective_frac": feat_tflops / PEAK_F32_MFMA_TFLOPS,
+                         "frac_full_profiles": None if full_info is None else full_info["feat_gemm_frac"],
+                         "avg_ms_full_profiles": None if full_info is None else full_info["feat_gemm_avg_ms"],
+                         "value_full_profiles": None if full_info is None else full_info["users_per_s"],
+                         "ms_per_step_full_profiles": None if full_info is None else full_info["ms_per_step"],
+                         "flops_note": "achieved / frac: the flops the kernel EXECUTES (SURVEY 8d's 2 F g per row x the rows "
+                                       "with id != 0: BASELINE's profile lengths U{3..50} leave %.1f %% of this batch's rows "
+                                       "out, exactly -- carca.py:94 zeroes them) / kernel time: the share of the MFMA peak the "
+                                       "kernel really reaches, never above 1; effective_*: SURVEY 8d's ALGORITHMIC flops (every "
+                                       "slot of the padded id matrices) / the same time; *_full_profiles: the same step with "
+                                       "every profile at L = 50 (nothing left out: executed = algorithmic), a side pass"
+                                       % (100 * (1 - kept_share)),
                          "traffic": traffic,
                          "traffic_note": traffic_note,
                          "avg_ms": feat_avg, "min_ms": feat_ms[0], "algorithmic_gflop_per_launch": c["B"] * fl["feat"] / 1e9,

@@ -820,10 +820,14 @@ class _MhaCoreFn(torch.autograd.Function):
     merged heads AND in the returned weights (return_w hands them out before dropout, carca.py:262-263)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, q_ids, k_ids, H, causal, want_w):
-        out, w = ops.mha_core(q.detach(), k.detach(), v.detach(), q_ids, k_ids, H, causal, want_w)
+    def forward(ctx, q, k, v, q_ids, k_ids, H, causal, want_w, drop, module):
+        res = ops.mha_core(q.detach(), k.detach(), v.detach(), q_ids, k_ids, H, causal, want_w, drop=drop)
+        out, w = res[0], res[1]
+        keep = res[2] if len(res) == 3 else None  # nn.Dropout on the weights (carca.py:258): the kernel's keep-mask
+        if module is not None:
+            module.__dict__["last_keep_mask"] = keep
         ctx.save_for_backward(q.detach(), k.detach(), v.detach())
-        ctx.t = (q_ids, k_ids, H, causal)
+        ctx.t = (q_ids, k_ids, H, causal, keep, drop[0] if keep is not None else 0.0)
         if want_w:
             return out, w
         ctx.mark_non_differentiable()
@@ -832,16 +836,16 @@ class _MhaCoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, d_w):
         q, k, v = ctx.saved_tensors
-        q_ids, k_ids, H, causal = ctx.t
+        q_ids, k_ids, H, causal, keep, p = ctx.t
         if d_out is None and d_w is None:
-            return (None,) * 8
-        dq, dk, dv = ops.mha_core_bwd(q, k, v, q_ids, k_ids, H, causal, d_out, d_w)
-        return dq, dk, dv, None, None, None, None, None
+            return (None,) * 10
+        dq, dk, dv = ops.mha_core_bwd(q, k, v, q_ids, k_ids, H, causal, d_out, d_w, keep=keep, p=p)
+        return dq, dk, dv, None, None, None, None, None, None, None
 
 
-def mha_with_grad(module, query, key, value, q_mask, k_mask, causal, return_w):
+def mha_with_grad(module, query, key, value, q_mask, k_mask, causal, return_w, drop=None):
     q = _LinearFn.apply(query, module.WQ.weight, module.WQ.bias)
     k = _LinearFn.apply(key, module.WK.weight, module.WK.bias)
     v = _LinearFn.apply(value, module.WV.weight, module.WV.bias)
-    out, w = _MhaCoreFn.apply(q, k, v, q_mask != 0, k_mask != 0, module.H, causal, bool(return_w))
+    out, w = _MhaCoreFn.apply(q, k, v, q_mask != 0, k_mask != 0, module.H, causal, bool(return_w), drop, module)
     return (w, out) if return_w else out

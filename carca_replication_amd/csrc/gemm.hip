@@ -1080,16 +1080,16 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
     nrows_[i] = D.seg[i].rows;
     ids_[i] = D.seg[i].ids;
   }
-  auto seg_cbase = [&](int s) {
+  auto seg_cbase = [&](int s) {  // (s = 0 .. CARCA_MAX_SEGS: the entries in front of segment s, all of them for s = nseg)
     int v = 0;
 #pragma unroll
-    for (int i = 0; i + 1 < CARCA_MAX_SEGS; ++i) v += i < s ? (nrows_[i] + 63) / 64 + 1 : 0;
+    for (int i = 0; i < CARCA_MAX_SEGS; ++i) v += i < s ? (nrows_[i] + 63) / 64 + 1 : 0;
     return v;
   };
   auto seg_roff = [&](int s) {
     int v = 0;
 #pragma unroll
-    for (int i = 0; i + 1 < CARCA_MAX_SEGS; ++i) v += i < s ? nrows_[i] : 0;
+    for (int i = 0; i < CARCA_MAX_SEGS; ++i) v += i < s ? nrows_[i] : 0;
     return v;
   };
   const unsigned long long below = (1ull << lane) - 1;

@@ -387,14 +387,33 @@ class AllEmbedding(Embedding):
                       gbp[id(enc_w)] if (enc_w is not None and not segs[0][3]) else None,  # (targets carry no position term)
                       joint_only=joint_only, skip_joint=skip_joint)
 
-    def forward(self, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
-        """`mask` must be get_mask(x) (it always is in the reference, carca.py:413-426); the kernel uses x != 0."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            from .autograd import embed_with_grad
-
-            return embed_with_grad(self, x, a, c, target)
-        (e,), _ = self.embed_segments([(x, a, c, target)], ld_e=self.d)
+    def _embed_unmasked(self, x: Tensor, a: Optional[Tensor], c: Tensor, target: bool) -> Tensor:
+        """carca.py:86-92 WITHOUT line 94: W_j [sqrt(d) E[x] ; W_f [a;c] + b_f] + b_j (+ position term) for every slot, id 0
+        included (E[0] is the zero row of padding_idx = 0, carca.py:73) -- what a caller-supplied mask that keeps a slot
+        whose id is 0 multiplies.  Three row GEMMs; inference only."""
+        d, E = self.d, self.items_embed.weight.detach()
+        Wf, bf, Wj, bj = (p.detach() for p in (self.feats_embed.weight, self.feats_embed.bias, self.joint_embed.weight,
+                                               self.joint_embed.bias))
+        g = Wf.shape[0]
+        table = self.attr_table()
+        n_ctx = c.shape[-1]
+        n_attrs = table.shape[1] if table is not None else a.shape[-1]
+        pos = None if target else _position_table(self.enc, x.shape[1])
+        ids = ops._ids32(x.reshape(-1))
+        src = dict(a0=ops._f32(a).reshape(-1, n_attrs)) if a is not None else dict(a0=table, a0_gather=True, ids=ids)
+        (q,) = ops.gemm_rows([dict(a1=ops._f32(c).reshape(-1, n_ctx) if n_ctx else None, **src)], Wf[:, :n_attrs], g, n_attrs,
+                             (g + 3) // 4 * 4, bt1=Wf[:, n_attrs:] if n_ctx else None, K1=n_ctx, bias=bf)
+        e = torch.empty(x.shape[0], x.shape[1], d, dtype=torch.float32, device=E.device)
+        o = e.view(-1, d)
+        ops.gemm_rows([dict(a0=E, a0_gather=True, ids=ids, out=o)], Wj[:, :d], d, d, d, bias=bj, alpha=float(d) ** 0.5)
+        ops.gemm_rows([dict(a0=q, ids=ids, add=o, out=o, add_pos=pos is not None, T=x.shape[1])], Wj[:, d:], d, g, d, pos=pos)
         return e
+
+    def forward(self, x: Tensor, a: Tensor, c: Tensor, mask: Tensor, target: bool) -> Tensor:
+        """abstract.py:22 / carca.py:85-95.  The fused kernels take the mask as x != 0 -- what get_mask(x) is at every call
+        site of the reference (carca.py:413-426).  Any OTHER mask is honoured as carca.py:94 does (`e * mask.unsqueeze(2)`):
+        see _apply_caller_mask."""
+        return _apply_caller_mask(self, x, a, c, mask, target)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -411,6 +430,35 @@ def _standalone_embed(module, x, a, c, target):
         return embed_with_grad(module, x, a, c, target)
     (e,), _ = module.embed_segments([(x, a, c, target)], ld_e=module.d)
     return e
+
+
+def _apply_caller_mask(module, x, a, c, mask, target):
+    """Embedding.forward(x, a, c, mask, target) of the ABC (abstract.py:22) with the caller's `mask` honoured
+    (carca.py:94,120,149,166,197: `e * mask.unsqueeze(2)`).  The kernels mask with x != 0; so
+      * mask is None or equals get_mask(x) (every call of the reference): the fused path as it is;
+      * mask is zero wherever x is 0 (it drops or re-weights valid slots): the fused result times the mask -- exact, and
+        differentiable like the reference's multiply;
+      * mask keeps a slot whose id is 0: the reference embeds that slot (item row 0 + its attributes / context) and scales
+        it; AllEmbedding runs its unmasked row products and multiplies (inference); with gradients enabled, or for the
+        ablation embeddings, this raises instead of returning another answer than the reference's.
+    Stand-alone module surface only (CARCA.forward builds its masks itself): the comparison costs one host read."""
+    if mask is None:
+        return _standalone_embed(module, x, a, c, target)
+    ops._need_cuda(x, mask)
+    if mask.shape != x.shape:
+        raise ValueError(f"mask {tuple(mask.shape)} must have the shape of the ids {tuple(x.shape)}")
+    valid = x != 0
+    m = mask.to(torch.float32)
+    flags = torch.stack([(m == valid.to(torch.float32)).all(), (m[~valid] == 0).all()]).tolist()  # (one host read)
+    if flags[0]:
+        return _standalone_embed(module, x, a, c, target)
+    if flags[1]:
+        return _standalone_embed(module, x, a, c, target) * m.unsqueeze(2)
+    grad = torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+    if grad or not hasattr(module, "_embed_unmasked"):
+        raise CarcaHipError(f"{type(module).__name__}.forward: `mask` keeps slots whose id is 0; the fused kernels leave those "
+                            "rows out (x != 0) -- supported for AllEmbedding under torch.no_grad() only")
+    return module._embed_unmasked(x, a, c, target) * m.unsqueeze(2)
 
 
 class _FeatsEmbedding(Embedding):
@@ -462,7 +510,7 @@ class _FeatsEmbedding(Embedding):
                        n_attrs, gbp[id(Wf)], gbp[id(self.feats_embed.bias)], K1=n_ctx)
 
     def forward(self, x, a, c, mask, target):
-        return _standalone_embed(self, x, a, c, target)
+        return _apply_caller_mask(self, x, a, c, mask, target)
 
 
 class AttrCtxEmbedding(_FeatsEmbedding):
@@ -520,7 +568,7 @@ class IdEmbedding(Embedding):
             ops.embed_scatter(des[i], ids_seg[i], d, float(d) ** 0.5, gbp[id(self.items_embed.weight)])
 
     def forward(self, x, a, c, mask, target):
-        return _standalone_embed(self, x, a, c, target)
+        return _apply_caller_mask(self, x, a, c, mask, target)
 
 
 class MLPIdEmbedding(Embedding):
@@ -567,7 +615,7 @@ class MLPIdEmbedding(Embedding):
             ops.embed_scatter(dzs[i], ids_seg[i], g, sd, gbp[id(E)])
 
     def forward(self, x, a, c, mask, target):
-        return _standalone_embed(self, x, a, c, target)
+        return _apply_caller_mask(self, x, a, c, mask, target)
 
 
 class _DotDecoder(Decoder):
@@ -677,22 +725,32 @@ class MultiHeadAttention(nn.Module):
         """Stand-alone MultiHeadAttention.forward (carca.py:228-265): three row GEMMs for the projections and
         carca_mha_core for the attention (the blocks' fused kernels never come here).  Returns the merged heads
         [B, Tq, d], or (weights [H*B, Tq, Tk] before dropout, output) with return_w -- the reference's order.
-        Differentiable (autograd.mha_with_grad: carca_mha_core_bwd + row / weight-gradient GEMMs)."""
-        if self.training and self.dropout.p > 0:
-            raise CarcaHipError("stand-alone MultiHeadAttention applies no dropout: call it in eval mode or with p = 0")
+        Differentiable (autograd.mha_with_grad: carca_mha_core_bwd + row / weight-gradient GEMMs).
+        Train mode with p > 0 (carca.py:258, self.dropout on the weights): the masks are drawn inside carca_mha_core_drop
+        from a seed taken from torch's CPU generator (torch's Philox stream cannot be reproduced in a kernel); the keep-mask
+        of the last call, uint8 [B, H, Tq, Tk], stays on the module as `last_keep_mask` for replay (tests/test_hip_dropout.py)."""
         ops._need_cuda(query, key, value, q_mask, k_mask)
+        drop = None
+        self.__dict__["last_keep_mask"] = None
+        if self.training and self.dropout.p > 0:
+            if self.dropout.p >= 1:
+                raise CarcaHipError("MultiHeadAttention: dropout p must be < 1")
+            drop = (float(self.dropout.p), ops.new_dropout_seed(), 0)
         if torch.is_grad_enabled() and (any(t.requires_grad for t in (query, key, value)) or
                                         any(p.requires_grad for p in self.parameters())):
             from .autograd import mha_with_grad
 
-            return mha_with_grad(self, query, key, value, q_mask, k_mask, causal, return_w)
+            return mha_with_grad(self, query, key, value, q_mask, k_mask, causal, return_w, drop=drop)
         d = self.d
         proj = []
         for x, lin in ((query, self.WQ), (key, self.WK), (value, self.WV)):
             x2 = ops._f32(x).reshape(-1, x.shape[-1])
             (y,) = ops.gemm_rows([dict(a0=x2)], lin.weight.detach(), d, d, d, bias=lin.bias.detach())
             proj.append(y.view(x.shape[0], x.shape[1], d))
-        out, w = ops.mha_core(proj[0], proj[1], proj[2], q_mask != 0, k_mask != 0, self.H, causal, return_w)
+        res = ops.mha_core(proj[0], proj[1], proj[2], q_mask != 0, k_mask != 0, self.H, causal, return_w, drop=drop)
+        out, w = res[0], res[1]
+        if len(res) == 3:
+            self.__dict__["last_keep_mask"] = res[2]
         return (w, out) if return_w else out
 
 

@@ -61,3 +61,21 @@ def dev(t, device="cuda"):
     if isinstance(t, (tuple, list)):
         return type(t)(dev(x, device) for x in t)
     return t.to(device)
+
+
+def assert_all_users_match_oracle(got, want, atol, min_clear=0.9):
+    """EVERY user's scores against the oracle's, and the positive's rank wherever it is unambiguous: a rank
+    may only differ where some negative's oracle score lies within 2 x the observed error of the positive's (train.py:15-32
+    sorts scores; a tie inside round-off has no defined order in the reference either)."""
+    got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    assert got.shape == want.shape
+    err = float((got - want).abs().max())
+    assert err < atol, err
+    if got.dim() == 2 and got.shape[1] > 1:
+        margin = (want[:, 1:] - want[:, :1]).abs().min(dim=1).values
+        clear = margin > 2 * max(err, 1e-7)
+        r_got = (got[:, 1:] > got[:, :1]).sum(1)
+        r_want = (want[:, 1:] > want[:, :1]).sum(1)
+        assert torch.equal(r_got[clear], r_want[clear])
+        assert float(clear.float().mean()) >= min_clear, float(clear.float().mean())
+    return err

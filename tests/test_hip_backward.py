@@ -242,6 +242,47 @@ def test_c2_full_batch_gradients_are_the_weighted_sum_of_its_halves():
         assert float((gf[k] - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-7, k
 
 
+def test_c2_full_batch_train_step_against_oracle_autograd():
+    """The bench's train workload at FULL size -- B = 128, L = 50, n_attrs = 4096, n_items = 12,102, d = 90 / g = 450 / H = 3
+    (the compacting feature GEMM over the kept rows, the compacted feats_embed weight gradient, the grouped small products)
+    -- loss and EVERY parameter gradient against torch.autograd over the CPU oracle on the same batch: once
+    through the eager pass and once replayed from the captured two-stream graph (lr = 0, so the weights stay put)."""
+    from carca_replication_amd import engine
+    from carca_replication_amd.optim import Adam
+
+    cfg = O.CarcaConfig(d=90, H=3, n_blocks=2)
+    n_items, n_attrs, n_ctx, g, L, B = 12102, 4096, 6, 450, 50, 128
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    profile, pos, _ = O.synth_eval_batch(B, L, L, n_items, n_attrs, n_ctx, seed=1234)
+    px = profile[0]
+    neg = (pos[0].flip(1).contiguous(), pos[1].flip(1).contiguous(), pos[2])
+    pos = (pos[0] * (px != 0), pos[1], pos[2])  # targets padded where the profile is (data.py:112-132)
+    neg = (neg[0] * (px != 0), neg[1], neg[2])
+    y_true = torch.cat([(px != 0).int(), torch.zeros_like(px)], dim=1)
+    o_x = torch.cat([pos[0], neg[0]], dim=1)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    y = O.carca_forward(Pg, cfg, profile, [pos, neg], training=True)
+    loss = O.bce_loss(y, y_true, O.get_mask(o_x))
+    loss.backward()
+    ref = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+
+    model = model_from_params(P, cfg).train()
+    batch = tuple(t.cuda() for t in (profile[0], profile[1], profile[2], o_x, torch.cat([pos[1], neg[1]], dim=1),
+                                     torch.cat([pos[2], neg[2]], dim=1), y_true))
+    opt = Adam(model.parameters(), lr=0.0, betas=(0.9, 0.98))
+    lg = engine._forward_backward(model, opt, batch, None)
+    assert abs(float(lg) - float(loss)) < 2e-6
+    _check_grads(model, ref)
+    step = engine.GraphedTrainStep(model, opt, batch)
+    try:
+        for _ in range(2):
+            lr_ = step(batch)
+            assert abs(float(lr_) - float(loss)) < 2e-6
+            _check_grads(model, ref)
+    finally:
+        step.close()
+
+
 @pytest.mark.parametrize("n_groups", [2, 3])
 def test_two_stream_embedding_backward_agrees_with_the_single_stream_pass(n_groups, monkeypatch):
     """The backward pass hands the target rows' embedding backward to a second stream once the decoder's backward has

@@ -3,13 +3,14 @@ image features, n_items = 166 k; C5 = Games shape, B = 128, 1 + 1000 candidates,
 attributes, 6 timestamp context features).  The oracle cannot run these batches in test time; the domain's invariants can:
 a user's scores do not depend on who else is in the batch (the same users in smaller batches take other kernels, pinned
 against the oracle at that size elsewhere), ids-only batches over the registered attribute table equal the dense batch,
-and the first eight users are checked against the oracle directly (scores to 1e-4, every rank identical)."""
+and EVERY user is checked against the oracle directly (scores to 2e-5, every unambiguous rank identical; the CPU port
+scores ~1 k users/s, so this is seconds)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import carca_oracle as O
-from tests.model_util import model_from_params
+from tests.model_util import assert_all_users_match_oracle, model_from_params
 
 pytestmark = pytest.mark.gpu
 Y_ATOL = 1e-4
@@ -47,11 +48,11 @@ def _run(cfg, g, n_items, n_attrs, n_ctx, L, N, B, table, p_c, o_c, p_x, o_x, sp
         ids_only = model(profile=(px, None, p_c), targets=[(ox, None, o_c)])
         model.embeds.register_attr_table(None)
     assert float((full - ids_only).abs().max()) < 1e-6
-    c8 = lambda t: t[:8].cpu()  # noqa: E731
-    want = O.carca_forward(P, cfg, (c8(p_x), c8(p_a), c8(p_c)), [(c8(o_x), c8(o_a), c8(o_c))], training=False)
-    got = full[:8].cpu()
-    assert float((got - want).abs().max()) < Y_ATOL
-    assert torch.equal(O.positive_rank(got), O.positive_rank(want))
+    # EVERY user against the oracle, 128 at a time (the dense batch goes to the host in slices: C3's is 1.3 GB)
+    for i in range(0, B, 128):
+        c = lambda t: t[i:i + 128].cpu()  # noqa: E731
+        want = O.carca_forward(P, cfg, (c(p_x), c(p_a), c(p_c)), [(c(o_x), c(o_a), c(o_c))], training=False)
+        assert_all_users_match_oracle(full[i:i + 128], want, 2e-5)
     assert bool(torch.isfinite(full).all()) and float(full.std()) > 0
     return full
 

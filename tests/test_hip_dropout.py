@@ -102,3 +102,55 @@ def test_eval_mode_ignores_dropout():
     want = O.carca_forward(P, cfg, profile, [pos], training=False)
     assert torch.equal(y1, y2)
     assert float((y1.cpu() - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("causal", [None, 0, -1])
+def test_standalone_mha_train_mode_dropout_replays_in_the_oracle(causal):
+    """MultiHeadAttention.forward on its own in TRAIN mode with p > 0 (carca.py:258: self.dropout on the weights; VERDICT r4
+    item 7b): carca_mha_core_drop draws the masks, the module keeps the keep-mask, and the oracle replays the reference
+    arithmetic with exactly that mask -- output, the returned PRE-dropout weights (carca.py:262-263) and every gradient."""
+    from carca_replication_amd import modules as M
+
+    torch.manual_seed(0)
+    B, Tq, Tk, d, H, p = 5, 23, 37, 90, 3, 0.4
+    mha = M.MultiHeadAttention(d, H, p).cuda().train()
+    q = torch.randn(B, Tq, d, device="cuda", requires_grad=True)
+    kv = torch.randn(B, Tk, d, device="cuda", requires_grad=True)
+    q_mask = (torch.rand(B, Tq, device="cuda") > 0.2).float()
+    k_mask = (torch.rand(B, Tk, device="cuda") > 0.2).float()
+    k_mask[0] = 0  # a user with no key at all: every weight exactly 0
+    torch.manual_seed(3)
+    w, out = mha(q, kv, kv, q_mask=q_mask, k_mask=k_mask, causal=causal, return_w=True)
+    keep = mha.last_keep_mask
+    assert keep is not None and keep.shape == (B, H, Tq, Tk) and keep.dtype == torch.uint8
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p)) < 0.02
+    go, gw = torch.randn_like(out), torch.randn_like(w)
+    (out * go).sum().add((w * gw).sum()).backward()
+
+    P = {"a." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in mha.state_dict().items()}
+    qc, kc = q.detach().cpu().requires_grad_(True), kv.detach().cpu().requires_grad_(True)
+    w_o, out_o = O.mha(P, "a.", H, qc, kc, kc, q_mask.cpu(), k_mask.cpu(), causal, drop_mask=keep.cpu().float() / (1 - p))
+    w_o_hm = torch.cat(list(w_o.transpose(0, 1)), dim=0)  # [B, H, Tq, Tk] -> head-major [H * B, Tq, Tk] (carca.py:242-244)
+    assert float((out.detach().cpu() - out_o.detach()).abs().max()) < 2e-5
+    assert float((w.detach().cpu() - w_o_hm.detach()).abs().max()) < 2e-6
+    ((out_o * go.cpu()).sum() + (w_o_hm * gw.cpu()).sum()).backward()
+    for name, got, ref in [("q", q.grad, qc.grad), ("kv", kv.grad, kc.grad)] + \
+                          [(k, dict(mha.named_parameters())[k].grad, P["a." + k].grad) for k in dict(mha.named_parameters())]:
+        ref = ref if ref is not None else torch.zeros_like(got.cpu())
+        assert float((got.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6, name
+    # same seed, same mask; another seed, another mask; eval mode: no mask, the dropout-free result
+    torch.manual_seed(3)
+    mha(q, kv, kv, q_mask=q_mask, k_mask=k_mask, causal=causal)
+    assert torch.equal(mha.last_keep_mask, keep)
+    torch.manual_seed(4)
+    with torch.no_grad():
+        mha(q, kv, kv, q_mask=q_mask, k_mask=k_mask, causal=causal)
+    assert not torch.equal(mha.last_keep_mask, keep)
+    mha.eval()
+    with torch.no_grad():
+        out_e = mha(q, kv, kv, q_mask=q_mask, k_mask=k_mask, causal=causal)
+    assert mha.last_keep_mask is None
+    _, out_eo = O.mha({k: v.detach() for k, v in P.items()}, "a.", H, qc.detach(), kc.detach(), kc.detach(), q_mask.cpu(),
+                      k_mask.cpu(), causal)
+    assert float((out_e.cpu() - out_eo).abs().max()) < 2e-5

@@ -10,7 +10,7 @@ import torch
 
 from oracle import carca_oracle as O
 from tests.golden_util import G1_NAMES, G7_NAMES, load, oracle_config
-from tests.model_util import dev, model_from_fixture, model_from_params
+from tests.model_util import assert_all_users_match_oracle, dev, model_from_fixture, model_from_params
 
 pytestmark = pytest.mark.gpu
 
@@ -409,8 +409,8 @@ def test_c2_full_batch_is_batch_split_invariant(d, H, g):
     The bench's exact workload (C2: B = 128 users, n_items = 12102, n_attrs = 4096; one-block-per-CU feature GEMM with
     the gather riding along, two workgroups per user) through a size-independent property: a user's scores do not depend
     on who else is in the batch.  The same users in eight batches of 16 take different kernels (tiled feature GEMM, its
-    own gather launch) whose B = 16 results are pinned against the oracle above; the first eight users are checked
-    against the oracle here as well."""
+    own gather launch) whose B = 16 results are pinned against the oracle above; EVERY user of the full batch is checked
+    against the oracle here as well (2e-5, ranks wherever they are unambiguous)."""
     cfg = O.CarcaConfig(d=d, H=H, n_blocks=2)
     n_items, n_attrs, n_ctx, L, N, B = 12102, 4096, 6, 50, 101, 128
     P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
@@ -424,9 +424,10 @@ def test_c2_full_batch_is_batch_split_invariant(d, H, g):
     split = torch.cat(parts, dim=0)
     assert full.shape == split.shape == (B, N)
     assert float((full - split).abs().max()) < 2e-5
-    want = O.carca_forward(P, cfg, tuple(t[:8] for t in profile), [tuple(t[:8] for t in target)], training=False)
-    assert float((full[:8] - want).abs().max()) < Y_ATOL
-    assert torch.equal(O.positive_rank(full[:8]), O.positive_rank(want))
+    # ALL 128 users against the oracle (0.1-0.2 s on the box's cores), not a sample: the compacting feature GEMM, the joint
+    # GEMM, both SA blocks and the scoring kernel at the bench's exact shape ("What's weak" 1)
+    want = O.carca_forward(P, cfg, profile, [target], training=False)
+    assert_all_users_match_oracle(full, want, 2e-5)
 
 
 # ---- the stand-alone module surface of the ABCs (abstract.py:31, carca.py:25-31, 54-60, 228-265) -----------------------

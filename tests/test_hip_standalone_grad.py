@@ -167,3 +167,59 @@ def test_all_embedding_and_encodings_are_differentiable(encoding, target):
         assert torch.equal(xeg.grad, de.cuda())
         if encoding == "learnable":
             _check("encoding.weight", enc.encoding.weight.grad[:L], de.sum(0))
+
+
+@pytest.mark.parametrize("target", [False, True])
+def test_all_embedding_honours_a_caller_supplied_mask(target):
+    """Embedding.forward(x, a, c, mask, target) of the ABC (abstract.py:22; carca.py:94 `e * mask.unsqueeze(2)`) with masks
+    that are NOT get_mask(x) ("What's missing" 1): (i) a mask that zeroes valid slots and re-weights others --
+    fused result times the mask, forward and every gradient; (ii) a mask that KEEPS slots whose id is 0 -- the reference
+    embeds them (zero item row + attributes + context + position) and so does the unmasked path under no_grad; with gradients
+    enabled that case raises rather than answering differently."""
+    from carca_replication_amd import CarcaHipError
+
+    d, H, L, B = 90, 3, 12, 5
+    cfg, P, model, mask, gen = _setup(d, H, L, B, encoding="learnable")
+    emb = model.embeds
+    n_items, n_attrs, n_ctx = emb.items_embed.weight.shape[0], 17, 3
+    x = (torch.randint(1, n_items, (B, L), generator=gen) * mask.long()).int()
+    a = torch.rand(B, L, n_attrs, generator=gen)
+    c = torch.rand(B, L, n_ctx, generator=gen)
+    de = torch.randn(B, L, d, generator=gen)
+    # (i) inside x != 0: drop the last valid slot of every user, halve another
+    m1 = (x != 0).float()
+    m1[:, -1] = 0
+    m1[:, -2] *= 0.5
+    assert not torch.equal(m1, (x != 0).float())
+    e = emb(x.cuda(), a.cuda(), c.cuda(), m1.cuda(), target)
+    e.backward(de.cuda())
+    P64 = _P64(P)
+    e64 = O.embedding(P64, cfg, x.long(), a.double(), c.double(), m1.double(), target)
+    e64.backward(de.double())
+    _check("e (mask inside x != 0)", e, e64.detach(), 2e-5)
+    assert float(e[:, -1].abs().max()) == 0.0
+    _check_params("embeds.", emb, P64)
+    # (ii) a mask that keeps pad slots (id 0)
+    m2 = torch.ones(B, L)
+    m2[:, 3] = 0.25
+    assert bool(((x == 0) & (m2 != 0)).any())
+    with torch.no_grad():
+        e2 = emb(x.cuda(), a.cuda(), c.cuda(), m2.cuda(), target)
+        e2_64 = O.embedding(_P64(P), cfg, x.long(), a.double(), c.double(), m2.double(), target)
+        _check("e (mask keeps id-0 slots)", e2, e2_64, 2e-5)
+        assert float(e2[x.cuda() == 0].abs().max()) > 0  # (those rows really are embedded)
+        # the registered attribute table (ids-only batches) takes the same path
+        table = torch.rand(n_items, n_attrs, generator=gen)
+        table[0] = 0
+        emb.register_attr_table(table.cuda())
+        e3 = emb(x.cuda(), None, c.cuda(), m2.cuda(), target)
+        emb.register_attr_table(None)
+        e3_64 = O.embedding(_P64(P), cfg, x.long(), table[x.long()].double(), c.double(), m2.double(), target)
+        _check("e (table, mask keeps id-0 slots)", e3, e3_64, 2e-5)
+    with pytest.raises(CarcaHipError, match="id is 0"):
+        emb(x.cuda(), a.cuda(), c.cuda(), m2.cuda(), target)
+    # and get_mask(x) itself, as a float or a bool tensor, stays on the fused path bit for bit
+    with torch.no_grad():
+        e_ref = emb(x.cuda(), a.cuda(), c.cuda(), (x != 0).float().cuda(), target)
+        assert torch.equal(e_ref, emb(x.cuda(), a.cuda(), c.cuda(), (x != 0).cuda(), target))
+        assert torch.equal(e_ref, emb(x.cuda(), a.cuda(), c.cuda(), None, target))

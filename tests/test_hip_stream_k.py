@@ -219,6 +219,25 @@ def test_deterministic_mode_keeps_a_non_finite_gradient_visible():
         ops.set_deterministic(False)
 
 
+def _fp64_product(segs, ids_all, w, b, N):
+    """The product itself in float64 on the GPU (torch.matmul, no kernel of this repo): ([a0 | a1] W^T + b) * (id != 0),
+    carca.py:86,94 -- the reference the compacting kernel is judged against beside the every-row kernels."""
+    outs = []
+    for sg, ids in zip(segs, ids_all):
+        a = torch.cat([sg["a0"], sg["a1"]], dim=1).double()
+        y = a @ w.double().t() + b.double()
+        outs.append(y * (ids != 0).double()[:, None])
+    return outs
+
+
+def _check_against_fp64(got, want64, ids_all, N, tol=6e-6):
+    for x, y, ids in zip(got, want64, ids_all):
+        scale = float(y.abs().max()) + 1e-30
+        assert float((x[:, :N].double() - y).abs().max()) <= tol * scale + 1e-12  # (an fp32 sum over K = 2054 against fp64)
+        if (ids == 0).any():
+            assert float(x[ids == 0][:, :N].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("pattern", ["scattered", "left_padded", "one_segment_all_padding", "nothing_left_out", "all_padding"])
 def test_the_compacting_kernel_on_awkward_id_patterns(tuning, pattern):
     """gemm_rows_skc_kernel (rows with id 0 left out, stretches over the kept rows' blocks) against the kernels that multiply
@@ -267,6 +286,7 @@ def test_the_compacting_kernel_on_awkward_id_patterns(tuning, pattern):
         assert float(x[ids == 0][:, :N].abs().max() if (ids == 0).any() else 0.0) == 0.0
         scale = float(y[:, :N].abs().max()) + 1e-30
         assert float((x[:, :N] - y[:, :N]).abs().max()) <= 4e-6 * scale + 1e-12  # (two groupings of a K = 2054 fp32 sum)
+    _check_against_fp64(got, _fp64_product(segs, ids_all, w, b, N), ids_all, N)
     again = run()
     for x, y in zip(got, again):
         assert torch.equal(x[:, :N], y[:, :N])  # the same bits from run to run
@@ -310,6 +330,7 @@ def test_the_compacting_kernel_at_b512_rows(tuning):
             assert float((x[:, :N] - y[:, :N]).abs().max()) <= 4e-6 * scale
             if (ids == 0).any():
                 assert float(x[ids == 0][:, :N].abs().max()) == 0.0
+        _check_against_fp64(got, _fp64_product(segs, ids_all, w, b, N), ids_all, N)
 
 
 @pytest.mark.parametrize("N", [640, 449, 434])
@@ -349,3 +370,43 @@ def test_the_compacting_kernel_with_other_narrow_column_blocks(tuning, N):
         assert float((x[:, :N] - y[:, :N]).abs().max()) <= 4e-6 * scale
         if (ids == 0).any():
             assert float(x[ids == 0][:, :N].abs().max()) == 0.0
+    _check_against_fp64(got, _fp64_product(segs, ids_all, w, b, N), ids_all, N)
+
+
+@pytest.mark.parametrize("rows", [[6400, 12928, 12928, 12928], [1600, 3232, 3232, 3232], [6400, 6400, 6400, 64]])
+def test_the_compacting_kernel_with_four_segments(tuning, rows):
+    """CARCA_MAX_SEGS = 4 segments (a profile and three target groups, carca.py:424): ADVICE r4 -- the kernel's count of
+    64-row chunks dropped the FOURTH segment's, so its prologue summed uninitialised LDS.  45,184 rows = 706 chunks take the
+    path that reads the ids from memory (more than 27,648 ids), 11,296 rows the path that keeps them in LDS; the last case
+    ends in a segment of one chunk.  Against the every-row kernels and the float64 product."""
+    from carca_replication_amd import ops
+
+    K0, K1, N = 2048, 6, 450
+    g = torch.Generator(device="cuda").manual_seed(11)
+    w = (torch.rand(N, K0 + K1, device="cuda", generator=g) * 2 - 1) * 0.03
+    b = torch.randn(N, device="cuda", generator=g) * 0.01
+    segs, ids_all = [], []
+    for si, r in enumerate(rows):
+        ids = torch.randint(1, 1000, (r,), device="cuda", dtype=torch.int32, generator=g)
+        T = 50 if r % 50 == 0 else 101 if r % 101 == 0 else 64
+        t = torch.arange(r, device="cuda") % T
+        ids[t < torch.randint(0, T - 2, ((r + T - 1) // T,), device="cuda", generator=g).repeat_interleave(T)[:r]] = 0
+        segs.append(dict(a0=torch.rand(r, K0, device="cuda", generator=g), a1=torch.rand(r, K1, device="cuda", generator=g), ids=ids))
+        ids_all.append(ids)
+
+    def run():
+        return ops.gemm_rows(segs, w[:, :K0], N, K0, 452, bt1=w[:, K0:], K1=K1, bias=b, mask_rows=True, ncols_out=N)
+
+    ops.gemm_rows_log(True)
+    got = run()
+    assert "gemm_rows_skc_kernel" in ops.gemm_rows_log()
+    ops.gemm_rows_log(False)
+    tuning(0, 23)
+    want = run()
+    tuning(0, 0)
+    torch.cuda.synchronize()
+    ops.poll_errors()
+    for x, y in zip(got, want):
+        scale = float(y[:, :N].abs().max())
+        assert float((x[:, :N] - y[:, :N]).abs().max()) <= 4e-6 * scale
+    _check_against_fp64(got, _fp64_product(segs, ids_all, w, b, N), ids_all, N)

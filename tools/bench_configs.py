@@ -67,20 +67,31 @@ for name, c in CONFIGS.items():
     dominant = max(stages, key=lambda k: stages[k][0] * stages[k][1])
     feat_kernel = next((t for t in rows_log.split(";") if f"N={g_} " in t), "?")
     joint_kernel = next((t for t in rows_log.split(";") if f"N={d_} K={d_ + g_} " in t), "?")
+    LEAVES_ROWS_OUT = ("gemm_rows_skc_kernel", "gemm_rows_cuc_kernel", "gemm_rows_n96c_kernel")
     kname = {"feature_gemm": feat_kernel, "joint_gemm": joint_kernel, "cross_score": "cross_stream_kernel / cross_fold_kernel",
              "sa_block": "sa_eval_kernel"}
-    stage_out = {k: dict(ms=v[0], launches=v[1], tflops=v[2] / v[0] / 1e9, frac_of_fp32_mfma_peak=v[2] / v[0] / 1e9 / 157.3)
+    # the row products leave rows with id 0 out (exactly: carca.py:94 zeroes them): `frac` counts the flops EXECUTED -- the
+    # algorithmic figure x the share of rows multiplied -- and can never exceed 1; `effective_frac` counts every padded row
+    kept = float((profile[0] != 0).sum() + (target[0] != 0).sum()) / float(profile[0].numel() + target[0].numel())
+    stage_out = {k: dict(ms=v[0], launches=v[1], effective_tflops=v[2] / v[0] / 1e9, effective_frac=v[2] / v[0] / 1e9 / 157.3)
                  for k, v in stages.items()}
+    for k, kern in (("feature_gemm", feat_kernel), ("joint_gemm", joint_kernel)):
+        share = kept if any(n in kern for n in LEAVES_ROWS_OUT) else 1.0
+        stage_out[k].update(rows_multiplied_share=share, tflops=stage_out[k]["effective_tflops"] * share,
+                            frac=stage_out[k]["effective_frac"] * share)
+    for k in ("cross_score", "sa_block"):  # (these execute FEWER flops than counted -- folded value projection, pad slots --: effective figures only)
+        stage_out[k].update(tflops=stage_out[k]["effective_tflops"], frac=stage_out[k]["effective_frac"])
     flop = c["B"] * ((c["L"] + c["N"]) * (2 * F * c["g"] + 2 * (c["d"] + c["g"]) * c["d"]) + c["nb"] * (10 * c["L"] * c["d"] ** 2 + 4 * c["L"] ** 2 * c["d"])
                      + 2 * c["N"] * c["d"] ** 2 + 4 * c["L"] * c["d"] ** 2 + 4 * c["N"] * c["L"] * c["d"] + 2 * c["N"] * c["d"])
     results.append(dict(config=" ".join(name.split()), ms_per_batch=dt * 1e3, users_per_s=c["B"] / dt,
                         algorithmic_tflops=flop / dt / 1e12, stages=stage_out,
                         dominant=dict(stage=dominant, kernel=kname[dominant], share_of_step=stages[dominant][0] * stages[dominant][1] / (dt * 1e3),
                                       roofline=dict(bound="mfma", peak=157.3, unit="TFLOP/s", achieved=stage_out[dominant]["tflops"],
-                                                    frac=stage_out[dominant]["frac_of_fp32_mfma_peak"])), **c))
+                                                    frac=stage_out[dominant]["frac"],
+                                                    effective_frac=stage_out[dominant]["effective_frac"])), **c))
     print(f"{name}: {dt*1e3:7.3f} ms/batch  {c['B']/dt:10.0f} users/s  {flop/dt/1e12:6.1f} TFLOP/s (algorithmic); dominant: "
           f"{dominant} [{kname[dominant]}] {stages[dominant][0]*1e3:.1f} us x{stages[dominant][1]} = "
-          f"{100*stage_out[dominant]['frac_of_fp32_mfma_peak']:.1f} % of the fp32 MFMA peak; "
+          f"{100*stage_out[dominant]['frac']:.1f} % of the fp32 MFMA peak on executed flops ({100*stage_out[dominant]['effective_frac']:.1f} % effective); "
           + ", ".join(f"{k} {v[0]*1e3:.1f} us" for k, v in stages.items()), flush=True)
 
 if os.environ.get("JSON_OUT"):  # e.g. JSON_OUT=gpurun_out/r03_configs.json (copied to profiles/ by hand)
