@@ -129,7 +129,7 @@ class GemmDesc(C.Structure):
                 ("ldb1", C.c_int32), ("N", C.c_int32), ("ldc", C.c_int32), ("ncols_out", C.c_int32), ("bias", _fp),
                 ("pos", _fp), ("colvec", _fp), ("ld_add", C.c_int32), ("ld_gate", C.c_int32),
                 ("gate_slope", C.c_float), ("mask_rows", C.c_int32), ("alpha", C.c_float), ("gate_scale", C.c_float),
-                ("gate_zero_drops", C.c_int32)]
+                ("gate_zero_drops", C.c_int32), ("add_table", _fp), ("ld_add_table", C.c_int32)]
 
 
 class WgradSeg(C.Structure):
@@ -224,7 +224,7 @@ class ForwardDesc(C.Structure):
                 ("fold_ldwc", C.c_int32), ("x_out", _fp * MAX_BLOCKS), ("sa_save", SaSave * MAX_BLOCKS), ("ca_save", CaSave),
                 ("save_blocks", C.c_int32), ("save_cross", C.c_int32), ("p_embed", C.c_float), ("p_block", C.c_float),
                 ("p_cross", C.c_float), ("seed", C.c_uint64), ("m_embed", _fp), ("seed_offset", C.c_void_p),
-                ("n_events", C.c_int32)]
+                ("n_events", C.c_int32), ("z_table", _fp), ("ld_z_table", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/carca_hip.h declares

@@ -420,8 +420,11 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     // gather + feature GEMM in one call: the gather rides in the GEMM's launch when that leaves a CU idle (C2: 255 blocks)
     // ev[0], ev[1]: bound to the feature GEMM's own dispatch (start / end of that kernel, no packets of their own)
     if (ev && ev[0] && ev[1]) carca_arm_launch_events(ev[0], ev[1]);
+    // (z_table: the item term comes out of the projected table in the joint product's epilogue -- no gather at all)
+    const bool ztab = D->z_table != nullptr && !D->save_blocks && !D->save_cross;
     rc = carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
-                         D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_GATHER | CARCA_EMBED_FEAT, stream_);
+                         D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e,
+                         ztab ? CARCA_EMBED_FEAT : (CARCA_EMBED_GATHER | CARCA_EMBED_FEAT), stream_);
     hipEvent_t left0, left1;
     if (carca_take_launch_events(&left0, &left1) && rc == CARCA_OK) {
       carca_set_error("forward: the feature GEMM's launch did not take the timing events");
@@ -429,8 +432,12 @@ extern "C" int carca_forward(const CarcaForwardDesc* D, void* const* ev, void* s
     }
     if (rc != CARCA_OK) return rc;
     if (ev && D->n_events >= 8 && ev[6] && ev[7]) carca_arm_launch_events(ev[6], ev[7]);
-    CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
-                              D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_JOINT, stream_));
+    if (ztab)
+      CARCA_TRY(carca_embed_joint_ztab(D->segs, nseg, D->d, D->g, D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e,
+                                       D->z_table, D->ld_z_table, stream_));
+    else
+      CARCA_TRY(carca_embed_fwd(D->segs, nseg, D->n_attrs, D->n_ctx, D->d, D->g, D->items_w, D->feats_w, D->feats_b,
+                                D->joint_w, D->joint_b, D->pos, D->zq, D->ld_e, CARCA_EMBED_JOINT, stream_));
     {
       hipEvent_t l0, l1;
       (void)carca_take_launch_events(&l0, &l1);  // (a joint product on a kernel that does not take events: leave them unset)

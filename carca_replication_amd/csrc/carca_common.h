@@ -250,6 +250,10 @@ int carca_gemm_rows_split_try(const CarcaGemmDesc* desc, hipStream_t stream);
 // carca_gemm_rows with the item-row gather riding along where the kernel choice leaves a CU idle; *rode tells whether
 // it did (otherwise the caller launches the gather itself)
 int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* ga, int* rode, void* stream);
+// the joint embedding over q's columns with the item term from a projected table (embed.hip; CarcaForwardDesc.z_table)
+struct CarcaRowSeg;
+int carca_embed_joint_ztab(const CarcaRowSeg* segs, int nseg, int d, int g, const float* joint_w, const float* joint_b,
+                           const float* pos, const float* zq, int ld_e, const float* z_table, int ld_z_table, void* stream);
 // carca_embed_scatter over several row segments in one launch (backward.hip)
 int carca_embed_scatter_segs(const float* const* dz, int ld_dz, const int32_t* const* ids, const int* rows, int nseg,
                              int d, float scale, float* d_items, void* stream);

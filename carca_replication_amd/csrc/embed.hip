@@ -104,3 +104,29 @@ extern "C" int carca_embed_fwd(const CarcaRowSeg* segs, int nseg, int n_attrs, i
   }
   return CARCA_OK;
 }
+
+// The joint product with the item term taken from a PROJECTED table (CarcaForwardDesc.z_table, inference):
+//   e = (q W_jq^T + z_table[id] + b_j (+ pos)) * mask,   z_table = sqrt(d) items_w W_jz^T,
+// over the g columns of q alone -- zq's z columns are never written (no gather launch) and never read.
+int carca_embed_joint_ztab(const CarcaRowSeg* segs, int nseg, int d, int g, const float* joint_w, const float* joint_b,
+                           const float* pos, const float* zq, int ld_e, const float* z_table, int ld_z_table,
+                           void* stream_) {
+  CARCA_CHECK_ARG(segs && nseg >= 1 && nseg <= CARCA_MAX_SEGS && joint_w && joint_b && zq && z_table && ld_z_table >= d,
+                  "embed_joint: bad arguments");
+  const int ldz = d + g;
+  CarcaGemmDesc ja{};
+  int row_start = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const CarcaRowSeg& sg = segs[s];
+    CARCA_CHECK_ARG(sg.rows >= 1 && sg.T >= 1 && sg.ids && sg.e_out, "embed_joint: segment %d malformed", s);
+    CarcaGemmSeg& j = ja.seg[s];
+    j.a0 = zq + (size_t)row_start * ldz + d; j.c = sg.e_out; j.ids = sg.ids;
+    j.rows = sg.rows; j.T = sg.T; j.add_pos = sg.add_pos;
+    row_start += sg.rows;
+  }
+  ja.nseg = nseg;
+  ja.lda0 = ldz; ja.K0 = g; ja.bt0 = joint_w + d; ja.ldb0 = ldz;
+  ja.N = d; ja.ldc = ld_e; ja.ncols_out = ld_e; ja.bias = joint_b; ja.pos = pos; ja.mask_rows = 1;
+  ja.add_table = z_table; ja.ld_add_table = ld_z_table;
+  return carca_gemm_rows(&ja, stream_);
+}

@@ -73,6 +73,8 @@ struct GemmDev {
   unsigned sk_spin;  // the bound: sleeps of ~0.4 us a taker spends on one flag before it gives up (launcher: 2^23, ~5 s)
   int sk_withhold;   // TEST ONLY (tuning key 13): 1 + index of the one flag its giver does not raise; 0 = none
   int skc_cheap;     // gemm_rows_skc_kernel: cost of a K step of the narrow column block's tile in 1/100 of a full tile's step
+  int skc_ov, skc_ov_lone;  // ... and what OWNING a row block costs (tail tile, partials taken, epilogue) in K steps of the
+                            // workgroup's kind: the stretches are cut equal in steps + that overhead (step 3 of the kernel)
 };
 
 
@@ -1007,6 +1009,8 @@ __global__ __launch_bounds__(768) void gemm_rows_sk_kernel(const GemmDev args) {
 constexpr int SKC_RB = 8;       // row blocks one workgroup's stretch may touch (the launcher checks rows against it)
 constexpr int SKC_CH = 1536;    // 64-row chunks of all segments (+ one entry per segment)
 constexpr int SKC_LDS_IDS = 2 * 384 * 36;  // ids the prologue keeps in LDS (the A buffers' space: 27,648)
+constexpr int SKC_OV_MAX = 12;  // bound on the row-block ownership cost in K steps (a stretch holds at least 16 steps)
+constexpr int SKC_OV_TEAM = 4, SKC_OV_LONE = 4;  // defaults (tools/stamp_skc.py; tuning keys 17 / 18)
 
 template <int XC>
 __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) {
@@ -1263,7 +1267,19 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
   const int nteams = lone ? y : x;                       // stretches of this workgroup's kind
   const int tj = lone ? w - x * nfull : w / nfull;       // its stretch
   const int cb = lone ? nfull : w - tj * nfull;          // its column block
-  const long lo = total * tj / nteams, hi = total * (tj + 1) / nteams;
+  // The stretches are equal in COST, not in steps: the workgroup that owns a row block (the one whose stretch holds the
+  // block's first step) also runs the block's ctx tail tile, adds the partial tiles of the stretches behind it and writes
+  // the block out -- `ov` K steps' worth.  Every row block is therefore laid out `ov` steps longer on a virtual axis (the
+  // overhead in front of its first step), the axis is cut into equal stretches and mapped back: a cut inside an
+  // overhead zone falls on the block's boundary.  (Cut equal in steps, the workgroups that own nothing -- a stretch inside
+  // one block: 11 of C2's 54 teams -- ended ~15 us before the owners: tools/stamp_skc.py.)
+  const int ov = lone ? args.skc_ov_lone : args.skc_ov;
+  const long vw = nfast + ov, vtotal = vw * nrb;
+  auto cut = [&](long j) {  // first step of stretch j (j = nteams: one past the last step)
+    const long v = vtotal * j / nteams, b = v / vw, r = v - b * vw;
+    return b * nfast + max(0l, r - (long)ov);
+  };
+  const long lo = cut(tj), hi = cut(tj + 1);
   const int rbA = (int)(lo / nfast), sA = (int)(lo - (long)rbA * nfast);
   int rbB = (int)(hi / nfast), sB = (int)(hi - (long)rbB * nfast);
   if (sB == 0) {  // (the stretch ends on a row block's boundary)
@@ -1350,10 +1366,10 @@ __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) 
         if (i < D.nseg && rb >= rbs[i]) sg = i;
       int mode = s0 > 0 ? SK_GIVE : (s1 < nfast ? SK_TAKE : SK_PLAIN), ntake = 0;
       if (mode == SK_TAKE) {
-        // the stretches behind this one that start inside the row block: tj + 1 .. the last j' with lo(j') < end
+        // the stretches behind this one that start inside the row block: tj + 1 .. the last j' with lo(j') < end (this
+        // stretch ends inside the block, so every later start is past the block's first step)
         const long end = (long)(rb + 1) * nfast;
-        const long last = (end * nteams + total - 1) / total - 1;
-        ntake = (int)min(last, (long)nteams - 1) - tj;
+        for (int j2 = tj + 1; j2 < nteams && cut(j2) < end; ++j2) ++ntake;
         if (ntake <= 0) mode = SK_PLAIN;  // (cannot happen with s1 < nfast; a taker must never wait for nobody)
       }
       int* pc = Pc + 8 * np;
@@ -1481,9 +1497,24 @@ __global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) 
   };
   auto store_stage = [&](int st, int ring, int buf) {
     const int kb = st * BK;
+    if (kb + BK <= D.K0) {  // (uniform: a full stage)
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) *reinterpret_cast<f32x4*>(&Sm[ldsx[i] + buf * bstr[i]]) = rg[ring][i];
+      return;
+    }
+    // the last stage of a K that is no multiple of 64 (and, for K0 % 4 != 0 -- the joint product over the g = 450 columns
+    // of q --, no multiple of 4): the load of a group that starts at column kc < K0 was clamped to start at K0 - 4, so
+    // its elements sit `sh` places further up; what lies past K0 is zeros in both operands
 #pragma unroll
     for (int i = 0; i < NSL; ++i) {
-      const f32x4 v = kb + c4s[i] * 4 < D.K0 ? rg[ring][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int kc = kb + c4s[i] * 4, sh = kc - min(kc, D.K0 - 4);  // (0 for groups that end inside K0)
+      const f32x4 r = rg[ring][i];
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = sh == 0 ? r[e] : (sh == 1 ? r[(e + 1) & 3] : (sh == 2 ? r[(e + 2) & 3] : r[(e + 3) & 3]));
+        v[e] = (kc + e < D.K0) ? x : 0.f;
+      }
       *reinterpret_cast<f32x4*>(&Sm[ldsx[i] + buf * bstr[i]]) = v;
     }
   };
@@ -1497,6 +1528,13 @@ __global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) 
   const bool fancy = !(diag & 4);
   const bool use_pos = sg.add_pos && D.pos;
 
+  const bool use_tab = D.add_table != nullptr && sg.ids != nullptr;
+  int idv0[5][4];  // with add_table: the ids of the lane's twenty rows, requested now (the table rows need them after the loop)
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      idv0[rt][r] = use_tab ? gload1i(sg.ids, min(row0 + 16 * rt + 4 * mq + r, sg.rows - 1)) : 0;
   f32x4 acc[5];
 #pragma unroll
   for (int rt = 0; rt < 5; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1545,7 +1583,7 @@ __global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) 
   float* Part = Sm;  // [BM][BN + 4]
   constexpr int PS = BN + 4;
   int idv[5][4];
-  float posv[5][4];
+  float posv[5][4], tabv[5][4];
   float bias;
   {
     const float* posp = use_pos ? D.pos : D.bt0;
@@ -1569,8 +1607,10 @@ __global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) 
             tt %= sg.T;
           }
         }
-        idv[rt][r] = gload1i(idp, sg.ids ? row : 0);
+        idv[rt][r] = use_tab ? idv0[rt][r] : gload1i(idp, sg.ids ? row : 0);
         posv[rt][r] = gload1(posp, use_pos ? tt * D.N + nn : 0);
+        // (the addend gathered by id, CarcaGemmDesc.add_table: the rows' ids were requested before the K loop)
+        tabv[rt][r] = gload1(use_tab ? D.add_table : D.bt0, use_tab ? idv0[rt][r] * D.ld_add_table + nn : 0);
       }
   }
   if (kh == 1) {
@@ -1598,6 +1638,7 @@ __global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) 
           continue;
         }
         if (use_pos) v += posv[rt][r];
+        if (use_tab) v += tabv[rt][r];
         if (sg.add) v += sg.add[(size_t)row * D.ld_add + n];
         if (sg.rowscale) v += sg.rowscale[row] * cv;
         if (sg.gate) {
@@ -1950,7 +1991,7 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
   if (ncb < 2 || desc->ncols_out != desc->N) return 1;
   const int rem = desc->N - 96 * nfull, xc = rem - 64;
   if (xc < 1 || xc > 2) return 1;  // (the cheap tile is two MFMA column tiles + 1..2 VALU columns)
-  if (desc->colvec || desc->pos || desc->gate_scale != 0.f) return 1;
+  if (desc->colvec || desc->pos || desc->gate_scale != 0.f || desc->add_table) return 1;
   int rb = 0;
   GemmDev g{};
   g.d = *desc;
@@ -2033,7 +2074,7 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
   // (the narrow last column block: two MFMA column tiles -- of 33..64 columns -- + up to 2 VALU columns)
   const int rem = desc->N - 96 * nfull, xc = rem > 64 ? rem - 64 : 0;
   if (rem <= 32 || xc > 2) return 1;
-  if (desc->colvec || desc->pos) return 1;  // (gate_scale only matters with a gate, and a segment with one is refused below)
+  if (desc->colvec || desc->pos || desc->add_table) return 1;  // (gate_scale only matters with a gate, and a segment with one is refused below)
   long rows = 0;
   GemmDev g{};
   g.d = *desc;
@@ -2055,10 +2096,20 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
     const long nrb_max = (rows + 383) / 384 + desc->nseg, nblk = ncu - 1;
     const long cheap = xc == 2 ? 74 : (xc == 1 ? 71 : 68);
     const long x = std::max(1l, nblk * 100 / (nfull * 100 + cheap)), y = std::max(1l, nblk - (x + 1) * nfull);
-    if (rows / 64 + 2 * desc->nseg > SKC_CH || (nrb_max + x - 1) / x + 1 > SKC_RB || (nrb_max + y - 1) / y + 1 > SKC_RB) return 1;
+    // (a stretch is at most ceil(nrb (nfast + ov) / teams) steps long and touches one block more than it spans)
+    const long ovm = SKC_OV_MAX, wv = nfast + ovm;
+    if (rows / 64 + 2 * desc->nseg > SKC_CH || (nrb_max * wv + x * nfast - 1) / (x * nfast) + 1 > SKC_RB ||
+        (nrb_max * wv + y * nfast - 1) / (y * nfast) + 1 > SKC_RB)
+      return 1;
   }
   g.ncb = ncb;
   g.skc_cheap = xc == 2 ? 74 : (xc == 1 ? 71 : 68);  // (two MFMA column tiles of three + the VALU columns: 0.74 of a full step measured)
+  {
+    // owning a row block, in K steps (tuning keys 17 / 18: value - 1, so that 1 switches the correction off; A/B)
+    const int t = carca_tuning(17), tl = carca_tuning(18);
+    g.skc_ov = std::min(SKC_OV_MAX, t > 0 ? t - 1 : SKC_OV_TEAM);
+    g.skc_ov_lone = std::min(SKC_OV_MAX, tl > 0 ? tl - 1 : SKC_OV_LONE);
+  }
   if (!g_sk_err_host) {
     if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped) != hipSuccess) return 1;
     *g_sk_err_host = 0;
@@ -2159,7 +2210,7 @@ static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice, bool*
     CARCA_CHECK_ARG(sg.T >= 1 || (!sg.a0_bstride && !sg.a1_bstride && !sg.add_pos), "gemm_rows: segment %d needs T >= 1",
                     s);
     CARCA_CHECK_ARG(!(sg.add_pos && (!desc->pos || sg.T < 1 || !sg.ids)) && !(desc->mask_rows && !sg.ids) &&
-                        !(sg.rowscale && !desc->colvec) && !(sg.a0_gather && !sg.ids),
+                        !(sg.rowscale && !desc->colvec) && !(sg.a0_gather && !sg.ids) && !(desc->add_table && !sg.ids),
                     "gemm_rows: segment %d epilogue needs a pointer that is NULL", s);
     rb128 += (sg.rows + 127) / 128;
   }
@@ -2193,13 +2244,17 @@ static int gemm_rows_choose(const CarcaGemmDesc* desc, GemmChoice* choice, bool*
     if (fits && (variant == 9 || variant == 10)) *choice = variant == 9 ? GEMM_WIDE64 : GEMM_WIDE64_PF2;
     // one 80 x 96 block per CU: narrow output over ONE k-source with a K worth pipelining, rows that fill the chip in about
     // one round, every operand row 16-byte aligned (variant 11 forces it where it applies, 12 forbids it)
-    if (fits && variant != 12 && desc->K1 == 0 && desc->N > 64 && desc->ncols_out <= 96 && desc->K0 % 4 == 0 &&
-        desc->lda0 % 4 == 0 && desc->ldb0 % 4 == 0 && ((uintptr_t)desc->bt0 & 15) == 0) {
+    // (a product with a gathered addend -- the joint embedding over q's columns, K0 = g = 450 at C2 -- comes with rows
+    // that are only 8-byte aligned and a K that is no multiple of 4: the kernel's loads take any dword alignment and its
+    // last stage shifts / masks by element; everybody else keeps the 16-byte conditions the kernel was measured under)
+    const bool loose = desc->add_table != nullptr && desc->K0 >= 4;
+    if (fits && variant != 12 && desc->K1 == 0 && desc->N > 64 && desc->ncols_out <= 96 &&
+        (loose || (desc->K0 % 4 == 0 && desc->lda0 % 4 == 0 && desc->ldb0 % 4 == 0 && ((uintptr_t)desc->bt0 & 15) == 0))) {
       bool ok = true;
       int rb80 = 0;
       for (int s = 0; s < desc->nseg; ++s) {
         const CarcaGemmSeg& sg = desc->seg[s];
-        ok = ok && !sg.a0_gather && ((uintptr_t)sg.a0 & 15) == 0 && sg.a0_bstride % 4 == 0;
+        ok = ok && !sg.a0_gather && (loose || (((uintptr_t)sg.a0 & 15) == 0 && sg.a0_bstride % 4 == 0));
         rb80 += (sg.rows + n96::BM - 1) / n96::BM;
       }
       const int cus = carca_num_cus();

@@ -13,7 +13,7 @@ __device__ __forceinline__ void gemm_rows_epilogue(const CarcaGemmDesc& D, const
   int rid[16];
   float rsc[16];
   const int last = sg.rows - 1;
-  if (D.mask_rows) {
+  if (D.mask_rows || D.add_table) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) rid[r] = sg.ids[min(row_w + (r & 3) + 8 * (r >> 2) + 4 * lh, last)];
   } else {
@@ -35,7 +35,11 @@ __device__ __forceinline__ void gemm_rows_epilogue(const CarcaGemmDesc& D, const
     const int nc = n_ok ? n : D.N - 1;
     const float bias = (n_ok && D.bias) ? D.bias[n] : 0.f;
     const float cv = (n_ok && D.colvec) ? D.colvec[n] : 0.f;
-    float posv[16], addv[16], gatev[16];
+    float posv[16], addv[16], gatev[16], tabv[16];
+    if (D.add_table) {  // (the addend gathered by id: CarcaGemmDesc.add_table)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tabv[r] = D.add_table[(size_t)rid[r] * D.ld_add_table + nc];
+    }
     if (sg.add_pos) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -58,6 +62,7 @@ __device__ __forceinline__ void gemm_rows_epilogue(const CarcaGemmDesc& D, const
         v = (D.alpha != 0.f ? D.alpha * acc[tn][r] : acc[tn][r]) + bias;
         if (sg.add_pos) v += posv[r];
         if (sg.add) v += addv[r];
+        if (D.add_table) v += tabv[r];
         if (sg.rowscale) v += rsc[r] * cv;
         if (sg.gate) {
           const float gv = gatev[r];

@@ -642,7 +642,7 @@ int carca_gemm_rows_split_try(const CarcaGemmDesc* desc, hipStream_t stream) {
   // k-source 0 on the MFMA pipe in 32-wide K steps (16-byte groups: K0 a multiple of 4); k-source 1 (a handful of
   // context columns) as fp32 FMAs
   if (desc->K0 % 4 != 0 || desc->K0 < 4 || desc->K1 > 8) return 1;
-  if (desc->colvec || desc->pos) return 1;  // (the plain epilogue only: alpha, bias, row mask; gate_scale acts through seg.gate)
+  if (desc->colvec || desc->pos || desc->add_table) return 1;  // (the plain epilogue only: alpha, bias, row mask; gate_scale acts through seg.gate)
   for (int s = 0; s < desc->nseg; ++s)
     if (desc->seg[s].add || desc->seg[s].gate || desc->seg[s].rowscale || desc->seg[s].add_pos) return 1;
   SplitDev g{};

@@ -204,6 +204,7 @@ class AllEmbedding(Embedding):
         state.pop("_wj_t", None)
         state.pop("_fold_train", None)
         state.pop("_wf_t", None)
+        state.pop("_ztab_cache", None)
         return state
 
     def register_attr_table(self, attrs: Optional[Tensor]) -> None:
@@ -242,6 +243,21 @@ class AllEmbedding(Embedding):
         self.__dict__["_fold_cache"] = (key, wc, bias_c)
         self.__dict__["_wf_t"] = wf_t  # [F, g] transposed copy, reused by the re-associated backward of the same step
         return wc, bias_c
+
+    def z_table(self) -> Tensor:
+        """sqrt(d) E W_jz^T, [n_items, d]: the item term of joint_embed (carca.py:87-89) per ITEM instead of per batch row,
+        composed on the device with carca_gemm_rows and cached per weight version (inference only: CarcaForwardDesc.z_table
+        -- the joint product then runs over q's columns and adds row `id` of this table; no gather launch, no z columns)."""
+        prm = (self.items_embed.weight, self.joint_embed.weight)
+        key = (_WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in prm)
+        cache = self.__dict__.get("_ztab_cache")
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        E, Wj = (p.detach() for p in prm)
+        d = self.d
+        (zt,) = ops.gemm_rows([dict(a0=E)], Wj[:, :d], d, d, d, alpha=float(d) ** 0.5)
+        self.__dict__["_ztab_cache"] = (key, zt)
+        return zt
 
     def _pos(self, T: int) -> Optional[Tensor]:
         return _position_table(self.enc, T)
@@ -759,6 +775,7 @@ class MultiHeadAttention(nn.Module):
 # that every training-mode forward advances: a training forward always repacks (weights change every step anyway) and
 # the first inference forward after training repacks once; inference loops keep their caches.
 _WEIGHT_EPOCH = [0]
+USE_Z_TABLE = True  # inference: the joint embedding's item term from AllEmbedding.z_table() (False: gather + d + g columns; A/B)
 
 
 def note_training_forward() -> None:
@@ -1132,6 +1149,11 @@ class CARCA(_PackedModule, Model):
             D.fold_wc, D.fold_bias, D.fold_ldwc = wc.data_ptr(), bias_c.data_ptr(), wc.stride(0)
         else:
             D.fold_wc, D.fold_bias, D.fold_ldwc = None, None, 0
+        D.z_table, D.ld_z_table = None, 0
+        if train is None and not self.training and D.fold_wc is None and USE_Z_TABLE:
+            zt = emb.z_table()  # (inference: the item term of the joint embedding per item, cached per weight version)
+            keep.append(zt)
+            D.z_table, D.ld_z_table = zt.data_ptr(), zt.stride(0)
         if train is None:
             D.x_work[0], D.x_work[1] = plan["xw"][0].data_ptr(), plan["xw"][1].data_ptr()
         repack: list = []  # (after a training step every module repacks: one launch for all of them)

@@ -144,7 +144,7 @@ int carca_pack_weights(const CarcaPackDesc* descs, int n, void* stream);
  * (one launch for profile + target groups); k runs over up to two column sources (a0 | a1), each
  * with its own Bt, so torch.cat((a, c), -1) @ W^T never materialises the concatenation.
  * Epilogue, in this order, each part optional:
- *   v = alpha * acc + bias[n] + pos[(row % T)][n] + add[row][n] + rowscale[row] * colvec[n]
+ *   v = alpha * acc + bias[n] + pos[(row % T)][n] + add[row][n] + add_table[ids[row]][n] + rowscale[row] * colvec[n]
  *   v *= gate_scale * (gate[row][n] > 0 ? 1 : gate_slope) (LeakyReLU' (x dropout1'), from the saved activation)
  *   v  = ids[row] != 0 ? v : 0                          (when mask_rows)
  *   C[row][n] = v for n < N;  C[row][n] = 0 for N <= n < ncols_out                              */
@@ -182,6 +182,11 @@ typedef struct CarcaGemmDesc {
   float alpha;             /* v = alpha * acc + bias + ...; 0 means 1 */
   float gate_scale;        /* extra factor on the gate (1/(1-p) when the saved activation went through dropout); 0 = 1 */
   int32_t gate_zero_drops; /* 1: an exactly-zero saved activation was DROPPED -> gradient 0 (else LeakyReLU'(0) = slope) */
+  /* An addend GATHERED by id: v += add_table[ids[row]][n] (every segment needs ids).  How the joint embedding takes the
+   * item rows without a gather launch and without their K columns: e = q W_jq^T + (sqrt(d) E W_jz^T)[id] + b_j
+   * (carca.py:87-89), the bracket prepared once per weight version (CarcaForwardDesc.z_table). */
+  const float* add_table;  /* [n_rows_of_the_table, ld_add_table] or NULL */
+  int32_t ld_add_table;
 } CarcaGemmDesc;
 int carca_gemm_rows(const CarcaGemmDesc* desc /*host*/, void* stream);
 /* Opt-in split-precision path of the product above (tuning key 16; csrc/gemm_split.hip): the weight matrix as packed
@@ -684,6 +689,14 @@ typedef struct CarcaForwardDesc {
   int32_t n_events;            /* entries of carca_forward's `ev` array: 0 or 4 = the four described there, 8 = four more:
                                 * ev[4], ev[5] bound to the FIRST SelfAttentionBlock's dispatch, ev[6], ev[7] to the joint
                                 * GEMM's (AllEmbedding.joint_embed, carca.py:89) */
+  /* Optional PROJECTED item table (inference, nothing saved for a backward): z_table[i] = sqrt(d) items_w[i] W_jz^T,
+   * [n_items, ld_z_table], prepared once per weight version.  joint_embed is linear (carca.py:89), so
+   *   e = [z ; q] W_j^T + b_j = q W_jq^T + z_table[id] + b_j:
+   * the item rows are never gathered into zq (no gather launch, carca.py:87-88), the joint product runs over the g
+   * columns of q only, and the item term is added per row in its epilogue.  Same algebra, another fp32 summation order
+   * (~1e-7 relative).  NULL = the reference's operation order (gather, then one product over d + g columns). */
+  const float* z_table;
+  int32_t ld_z_table;
 } CarcaForwardDesc;
 int carca_forward(const CarcaForwardDesc* desc /*host*/, void* const* ev /*4 hipEvent_t or NULL*/, void* stream);
 /* Event helpers so that a host language without a HIP binding can time kernels on the launch stream. */

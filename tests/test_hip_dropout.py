@@ -135,10 +135,14 @@ def test_standalone_mha_train_mode_dropout_replays_in_the_oracle(causal):
     assert float((out.detach().cpu() - out_o.detach()).abs().max()) < 2e-5
     assert float((w.detach().cpu() - w_o_hm.detach()).abs().max()) < 2e-6
     ((out_o * go.cpu()).sum() + (w_o_hm * gw.cpu()).sum()).backward()
-    for name, got, ref in [("q", q.grad, qc.grad), ("kv", kv.grad, kc.grad)] + \
-                          [(k, dict(mha.named_parameters())[k].grad, P["a." + k].grad) for k in dict(mha.named_parameters())]:
+    pairs = [("q", q.grad, qc.grad), ("kv", kv.grad, kc.grad)] + \
+            [(k, dict(mha.named_parameters())[k].grad, P["a." + k].grad) for k in dict(mha.named_parameters())]
+    # (WK.bias: true gradient 0 -- the softmax is invariant to a shift of a query's scores -- so what both sides hold is the
+    # round-off of sums whose terms are the size of the OTHER gradients: an absolute floor relative to those)
+    floor = 1e-5 * max(float(r.abs().max()) for _, _, r in pairs if r is not None)
+    for name, got, ref in pairs:
         ref = ref if ref is not None else torch.zeros_like(got.cpu())
-        assert float((got.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6, name
+        assert float((got.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + floor, name
     # same seed, same mask; another seed, another mask; eval mode: no mask, the dropout-free result
     torch.manual_seed(3)
     mha(q, kv, kv, q_mask=q_mask, k_mask=k_mask, causal=causal)

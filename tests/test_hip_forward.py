@@ -694,3 +694,38 @@ def test_eval_metrics_in_one_launch_equals_the_separate_kernels(B, N):
     assert float(sums[3]) == float(loss) and float(sums[4]) == B
     want = O.bce_loss(y, y_true, (ids != 0).float())
     assert abs(float(sums[3]) - float(want)) < 2e-6
+
+
+@pytest.mark.parametrize("d,H,g,B", [(90, 3, 450, 128), (128, 4, 640, 128), (64, 2, 256, 8), (90, 3, 450, 7)])
+def test_projected_item_table_equals_the_gathered_item_rows(d, H, g, B, monkeypatch):
+    """Inference takes the joint embedding's item term from AllEmbedding.z_table() = sqrt(d) E W_jz^T (one row per ITEM,
+    cached per weight version) and runs the product over q's g columns only (K = 450: no multiple of 4, rows 8-byte
+    aligned -- the one-block-per-CU kernel's ragged last stage at B = 128, the tiled kernels below): same scores as the
+    reference's order (gather E[x] sqrt(d), one product over d + g columns, carca.py:87-89) to round-off, the oracle's to
+    2e-5, and a weight update invalidates the table."""
+    from carca_replication_amd import modules as M
+
+    cfg = O.CarcaConfig(d=d, H=H, n_blocks=2, encoding="learnable")
+    n_items, n_attrs, n_ctx, L, N = 700, 96, 6, 50, 101
+    P = O.perturb_params(O.init_params(cfg, n_items, g, n_ctx, n_attrs, L, seed=0), seed=1)
+    profile, target, _ = O.synth_eval_batch(B, L, N, n_items, n_attrs, n_ctx, seed=5)
+    model = model_from_params(P, cfg).eval()
+    p_dev, t_dev = dev(profile), dev(target)
+    with torch.no_grad():
+        got = model(profile=p_dev, targets=[t_dev])
+        assert model.embeds.__dict__.get("_ztab_cache") is not None  # (the table path was taken)
+        monkeypatch.setattr(M, "USE_Z_TABLE", False)
+        ref = model(profile=p_dev, targets=[t_dev])
+        monkeypatch.setattr(M, "USE_Z_TABLE", True)
+        assert float((got - ref).abs().max()) < 2e-6
+        want = O.carca_forward(P, cfg, profile, [target], training=False)
+        assert_all_users_match_oracle(got, want, 2e-5)
+        # another weight version: items_embed and joint_embed move, the cached table must not survive
+        model.embeds.items_embed.weight.mul_(1.25)
+        model.embeds.joint_embed.weight[:, :d].mul_(0.5)
+        M.note_training_forward()
+        P2 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        got2 = model(profile=p_dev, targets=[t_dev])
+        want2 = O.carca_forward(P2, cfg, profile, [target], training=False)
+        assert float((got2 - got).abs().max()) > 1e-3
+        assert_all_users_match_oracle(got2, want2, 2e-5)

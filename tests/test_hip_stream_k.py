@@ -373,12 +373,13 @@ def test_the_compacting_kernel_with_other_narrow_column_blocks(tuning, N):
     _check_against_fp64(got, _fp64_product(segs, ids_all, w, b, N), ids_all, N)
 
 
-@pytest.mark.parametrize("rows", [[6400, 12928, 12928, 12928], [1600, 3232, 3232, 3232], [6400, 6400, 6400, 64]])
+@pytest.mark.parametrize("rows", [[12800, 8448, 8448, 8448], [6400, 4224, 4224, 4224], [6400, 6400, 5760, 64]])
 def test_the_compacting_kernel_with_four_segments(tuning, rows):
     """CARCA_MAX_SEGS = 4 segments (a profile and three target groups, carca.py:424): ADVICE r4 -- the kernel's count of
-    64-row chunks dropped the FOURTH segment's, so its prologue summed uninitialised LDS.  45,184 rows = 706 chunks take the
-    path that reads the ids from memory (more than 27,648 ids), 11,296 rows the path that keeps them in LDS; the last case
-    ends in a segment of one chunk.  Against the every-row kernels and the float64 product."""
+    64-row chunks dropped the FOURTH segment's, so its prologue summed uninitialised LDS.  Row counts that the launcher sends
+    to the one-block-per-CU kernels (whole rounds of 384-row blocks): 38,144 rows = 596 chunks take the path that reads the
+    ids from memory (more than 27,648 ids), 19,072 rows the path that keeps them in LDS; the last case ends in a segment of
+    one chunk.  Against the every-row kernels and the float64 product."""
     from carca_replication_amd import ops
 
     K0, K1, N = 2048, 6, 450

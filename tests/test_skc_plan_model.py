@@ -25,8 +25,18 @@ def split_grid(nblk, nfull, cheap, total):
     return x, y
 
 
-def pieces(tj, nteams, total, nfast):
-    lo, hi = total * tj // nteams, total * (tj + 1) // nteams
+def cut(j, nteams, nrb, nfast, ov):
+    """First step of stretch j: the row blocks laid out `ov` steps longer each (the cost of owning one, in front of its first
+    step), cut into equal stretches, mapped back (gemm.hip, step 3: 'equal in COST, not in steps')."""
+    vw = nfast + ov
+    v = vw * nrb * j // nteams
+    b, r = divmod(v, vw)
+    return b * nfast + max(0, r - ov)
+
+
+def pieces(tj, nteams, total, nfast, ov=0):
+    nrb = total // nfast
+    lo, hi = cut(tj, nteams, nrb, nfast, ov), cut(tj + 1, nteams, nrb, nfast, ov)
     rbA, sA = lo // nfast, lo % nfast
     rbB, sB = hi // nfast, hi % nfast
     if sB == 0:
@@ -37,16 +47,18 @@ def pieces(tj, nteams, total, nfast):
         mode, ntake = ("give" if s0 > 0 else ("take" if s1 < nfast else "plain")), 0
         if mode == "take":
             end = (rb + 1) * nfast
-            last = (end * nteams + total - 1) // total - 1
-            ntake = min(last, nteams - 1) - tj
+            j2 = tj + 1
+            while j2 < nteams and cut(j2, nteams, nrb, nfast, ov) < end:
+                ntake, j2 = ntake + 1, j2 + 1
             if ntake <= 0:
                 mode = "plain"
         out.append((rb, s0, s1, mode, ntake))
     return out
 
 
+@pytest.mark.parametrize("ov", [0, 4, 12])
 @pytest.mark.parametrize("nblk,nfull,cheap", [(256, 4, 74), (255, 4, 74), (256, 6, 68), (256, 2, 68), (304, 4, 71)])
-def test_every_step_once_every_partial_taken(nblk, nfull, cheap):
+def test_every_step_once_every_partial_taken(nblk, nfull, cheap, ov):
     for nrb, nfast in itertools.product([1, 2, 3, 7, 27, 43, 51, 85, 170, 202, 203], [64, 65, 128, 200]):
         total = nrb * nfast
         x, y = split_grid(nblk, nfull, cheap, total)
@@ -56,7 +68,7 @@ def test_every_step_once_every_partial_taken(nblk, nfull, cheap):
             gives = {}   # row block -> stretches that hand a partial tile to its owner
             takes = {}   # row block -> (owner stretch, partials it waits for)
             for tj in range(nteams):
-                ps = pieces(tj, nteams, total, nfast)
+                ps = pieces(tj, nteams, total, nfast, ov)
                 assert len(ps) >= 1
                 assert sum(1 for p in ps if p[3] == "give") <= 1 and (not ps or all(p[3] != "give" for p in ps[1:]))
                 for rb, s0, s1, mode, ntake in ps:
@@ -76,18 +88,23 @@ def test_every_step_once_every_partial_taken(nblk, nfull, cheap):
                 assert rb in takes and takes[rb][1] == len(g)
 
 
-def test_the_launchers_bound_on_row_blocks_per_stretch():
-    """launch_gemm_rows_skc admits a product only if ceil(nrb_max / x) + 1 and ceil(nrb_max / y) + 1 stay within SKC_RB, with
-    y taken for x + 1 teams (the kernel may pick either): then no stretch, whatever the kept rows, touches more blocks."""
-    nblk, nfull, cheap, nfast = 255, 4, 74, 128
+@pytest.mark.parametrize("nfast", [64, 128])
+def test_the_launchers_bound_on_row_blocks_per_stretch(nfast):
+    """launch_gemm_rows_skc admits a product only if ceil(nrb_max (nfast + SKC_OV_MAX) / (teams nfast)) + 1 stays within
+    SKC_RB for x teams and for y lone workgroups, with y taken for x + 1 teams (the kernel may pick either): then no stretch,
+    whatever the kept rows and whatever ownership cost up to SKC_OV_MAX, touches more blocks."""
+    nblk, nfull, cheap, ov_max = 255, 4, 74, 12
+    wv = nfast + ov_max
     for nrb_max in range(1, 260):
         x0 = max(1, nblk * 100 // (nfull * 100 + cheap))
         y0 = max(1, nblk - (x0 + 1) * nfull)
-        admitted = (nrb_max + x0 - 1) // x0 + 1 <= SKC_RB and (nrb_max + y0 - 1) // y0 + 1 <= SKC_RB
+        admitted = ((nrb_max * wv + x0 * nfast - 1) // (x0 * nfast) + 1 <= SKC_RB and
+                    (nrb_max * wv + y0 * nfast - 1) // (y0 * nfast) + 1 <= SKC_RB)
         if not admitted:
             continue
         for nrb in {1, nrb_max // 2 + 1, nrb_max}:
             total = nrb * nfast
             x, y = split_grid(nblk + 1, nfull, cheap, total)
             for nteams in (x, y):
-                assert max(len(pieces(tj, nteams, total, nfast)) for tj in range(nteams)) <= SKC_RB
+                for ov in (0, 4, ov_max):
+                    assert max(len(pieces(tj, nteams, total, nfast, ov)) for tj in range(nteams)) <= SKC_RB

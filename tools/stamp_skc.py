@@ -23,6 +23,11 @@ with torch.no_grad():
     lib.carca_set_debug_buffer(buf.data_ptr())
     if os.environ.get("DIAG"):
         ops.set_tuning(15, int(os.environ["DIAG"]))
+    # OV / OVL: the row-block ownership cost of the stretch plan in K steps (teams / lone workgroups; tuning keys 17 / 18)
+    if os.environ.get("OV"):
+        ops.set_tuning(17, int(os.environ["OV"]) + 1)
+    if os.environ.get("OVL"):
+        ops.set_tuning(18, int(os.environ["OVL"]) + 1)
     model(profile=profile, targets=[target])
     ops.set_tuning(15, 0)
     torch.cuda.synchronize()
@@ -72,3 +77,18 @@ for wg in range(256):
 for k, v in sorted(acc.items()):
     us_, st = sum(x for x, _ in v), sum(s_ for _, s_ in v)
     print(f"{k}: {len(v):3d} pieces, {st / len(v):6.1f} steps each, {us_ / st:.3f} us per step (ends included)")
+
+# when the workgroups END (us since their own start), by what their stretch holds: the plan balances these (gemm.hip, step 3)
+ends = collections.defaultdict(list)
+for wg in range(256):
+    if not bool(act[wg]):
+        continue
+    kinds = [int(info[wg, pc]) & 7 for pc in range(3) if int(info[wg, pc]) > 0]
+    steps = sum(int(info[wg, pc]) >> 3 for pc in range(3) if int(info[wg, pc]) > 0)
+    lone = any(k & 4 for k in kinds)
+    owns = sum(1 for k in kinds if (k & 3) in (0, 2))
+    gives = sum(1 for k in kinds if (k & 3) == 1)
+    ends[("lone" if lone else "team") + f" gives {gives} owns {owns}"].append((float(last[wg]) / 100.0, steps))
+for k, v in sorted(ends.items()):
+    e = [x for x, _ in v]
+    print(f"{k}: {len(v):3d} workgroups, {sum(s_ for _, s_ in v) / len(v):6.1f} steps, end mean {sum(e) / len(e):7.2f} us  min {min(e):7.2f}  max {max(e):7.2f}")
