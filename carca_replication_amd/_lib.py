@@ -240,6 +240,7 @@ SIGNATURES = {
     "carca_capture_scope": (_i, [_fp, C.POINTER(C.c_ulonglong)]),
     "carca_capture_bytes": (C.c_longlong, [C.c_ulonglong]),
     "carca_capture_release": (_i, [C.c_ulonglong]),
+    "carca_release_stream_scratch": (_i, [_fp]),
     "carca_padded_dims": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "carca_pack_weights": (_i, [C.POINTER(PackDesc), _i, _fp]),
     "carca_embed_fwd": (_i, [C.POINTER(RowSeg), _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),

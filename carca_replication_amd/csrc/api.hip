@@ -290,21 +290,43 @@ unsigned long long capture_id(hipStream_t stream) {
 }
 }  // namespace
 
+namespace {
+// hipFree synchronises the device and is refused while a stream of this thread captures in global mode: outgrown buffers
+// are therefore freed (a) only from a launch path that is not itself inside a capture, (b) outside g_mem_mu, (c) inside a
+// relaxed capture-mode window, so that a capture running on ANOTHER thread does not turn the call into an error that
+// invalidates it.
+void free_outside_lock(const std::vector<void*>& ps) {
+  if (ps.empty()) return;
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  for (void* p : ps) (void)hipFree(p);
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  (void)hipGetLastError();
+}
+}  // namespace
+
 void* carca_stream_scratch(hipStream_t stream, int tag, size_t bytes, size_t zero_bytes, bool* fresh) {
+  std::vector<void*> to_free;
+  struct FreeAtExit {
+    std::vector<void*>& v;
+    ~FreeAtExit() { free_outside_lock(v); }
+  } free_at_exit{to_free};  // (declared BEFORE the lock: runs after the mutex is released)
   std::lock_guard<std::mutex> lock(g_mem_mu);
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (fresh) *fresh = false;
-  for (size_t i = 0; i < g_retired.size();) {  // (outgrown buffers whose stream has nothing left in flight)
-    if (g_retired[i].dev == dev && !carca_stream_capturing(g_retired[i].stream) && hipStreamQuery(g_retired[i].stream) == hipSuccess) {
-      (void)hipFree(g_retired[i].p);
-      g_retired[i] = g_retired.back();
-      g_retired.pop_back();
-    } else {
-      ++i;
+  if (!carca_stream_capturing(stream)) {
+    for (size_t i = 0; i < g_retired.size();) {  // (outgrown buffers whose stream has nothing left in flight)
+      if (g_retired[i].dev == dev && !carca_stream_capturing(g_retired[i].stream) && hipStreamQuery(g_retired[i].stream) == hipSuccess) {
+        to_free.push_back(g_retired[i].p);
+        g_retired[i] = g_retired.back();
+        g_retired.pop_back();
+      } else {
+        ++i;
+      }
     }
+    (void)hipGetLastError();  // (hipStreamQuery reports hipErrorNotReady through the sticky last-error too)
   }
-  (void)hipGetLastError();  // (hipStreamQuery reports hipErrorNotReady through the sticky last-error too)
   ScratchSlot* sl = nullptr;
   for (auto& s : g_scratch)
     if (s.dev == dev && s.stream == stream && s.tag == tag) sl = &s;
@@ -329,6 +351,37 @@ void* carca_stream_scratch(hipStream_t stream, int tag, size_t bytes, size_t zer
   sl->bytes = want;
   if (fresh) *fresh = true;
   return p;
+}
+
+// The library's per-stream buffers of `stream` on the current device, handed back (a caller that destroys a stream it
+// launched on: the slots are keyed by the raw handle and would otherwise stay for the life of the process).  The caller
+// has synchronised the stream; refused while it is being captured.
+extern "C" int carca_release_stream_scratch(void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CARCA_CHECK_ARG(!carca_stream_capturing(stream), "release_stream_scratch: the stream is being captured");
+  std::vector<void*> to_free;
+  {
+    std::lock_guard<std::mutex> lock(g_mem_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t kept = 0;
+    for (size_t i = 0; i < g_scratch.size(); ++i) {
+      if (g_scratch[i].dev == dev && g_scratch[i].stream == stream) {
+        if (g_scratch[i].p) to_free.push_back(g_scratch[i].p);
+      } else {
+        g_scratch[kept++] = g_scratch[i];
+      }
+    }
+    g_scratch.resize(kept);
+    kept = 0;
+    for (size_t i = 0; i < g_retired.size(); ++i) {
+      if (g_retired[i].dev == dev && g_retired[i].stream == stream) to_free.push_back(g_retired[i].p);
+      else g_retired[kept++] = g_retired[i];
+    }
+    g_retired.resize(kept);
+  }
+  free_outside_lock(to_free);
+  return CARCA_OK;
 }
 
 void* carca_capture_alloc(hipStream_t stream, size_t bytes, bool host_mapped, void** device_view, size_t zero_bytes) {

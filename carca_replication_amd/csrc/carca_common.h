@@ -250,6 +250,10 @@ int carca_gemm_rows_split_try(const CarcaGemmDesc* desc, hipStream_t stream);
 // carca_gemm_rows with the item-row gather riding along where the kernel choice leaves a CU idle; *rode tells whether
 // it did (otherwise the caller launches the gather itself)
 int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* ga, int* rode, void* stream);
+// host-visible word a kernel sets when it meets something no launch status can carry (1: a stream-K taker gave up waiting,
+// 2: gemm_rows_skc_kernel's row-block lists too short, 3: gemm_wgrad_cu_kernel's partial-tile slots too few); reported and
+// cleared by carca_poll_errors and by the next stream-K launch (gemm.hip).  Device view, or null.
+int* carca_kernel_error_word();
 // the joint embedding over q's columns with the item term from a projected table (embed.hip; CarcaForwardDesc.z_table)
 struct CarcaRowSeg;
 int carca_embed_joint_ztab(const CarcaRowSeg* segs, int nseg, int d, int g, const float* joint_w, const float* joint_b,

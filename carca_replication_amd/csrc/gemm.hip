@@ -1967,7 +1967,27 @@ int* g_sk_err_dev = nullptr;   // carca_poll_errors
 
 // A kernel's failure that no launch status can carry (today: a stream-K taker that gave up waiting): CARCA_OK, or
 // CARCA_ERR_UNSUPPORTED with the message set -- the word is cleared by the call that reports it.
+// the word's device view, allocated on first use (mapped + portable host memory: one word for every device of the process);
+// null when it cannot be had -- the kernels then keep their findings to themselves
+int* carca_kernel_error_word() {
+  if (!g_sk_err_host) {
+    if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    *g_sk_err_host = 0;
+    if (hipHostGetDevicePointer((void**)&g_sk_err_dev, g_sk_err_host, 0) != hipSuccess) g_sk_err_dev = nullptr;
+  }
+  return g_sk_err_dev;
+}
 static int sk_check_error_word() {
+  if (g_sk_err_host && *(volatile int*)g_sk_err_host == 3) {
+    *(volatile int*)g_sk_err_host = 0;
+    carca_set_error("gemm_wgrad: an EARLIER gemm_wgrad_cu_kernel launch met a group whose range touches more k blocks than it "
+                    "has partial-tile slots (that tile's gradient is wrong): a launcher bug -- carca_set_tuning(0, 14) "
+                    "selects the atomic flush");
+    return CARCA_ERR_UNSUPPORTED;
+  }
   if (g_sk_err_host && *(volatile int*)g_sk_err_host == 2) {
     *(volatile int*)g_sk_err_host = 0;
     carca_set_error("gemm_rows: an EARLIER gemm_rows_skc_kernel launch met a stretch of more row blocks than its lists hold "
@@ -2028,7 +2048,7 @@ static int launch_gemm_rows_sk(const CarcaGemmDesc* desc, hipStream_t stream, co
     if (rode) *rode = 1;
   }
   if (!g_sk_err_host) {
-    if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped) != hipSuccess) return 1;
+    if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return 1;
     *g_sk_err_host = 0;
     if (hipHostGetDevicePointer((void**)&g_sk_err_dev, g_sk_err_host, 0) != hipSuccess) g_sk_err_dev = nullptr;
   }
@@ -2111,7 +2131,7 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
     g.skc_ov_lone = std::min(SKC_OV_MAX, tl > 0 ? tl - 1 : SKC_OV_LONE);
   }
   if (!g_sk_err_host) {
-    if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped) != hipSuccess) return 1;
+    if (hipHostMalloc((void**)&g_sk_err_host, sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return 1;
     *g_sk_err_host = 0;
     if (hipHostGetDevicePointer((void**)&g_sk_err_dev, g_sk_err_host, 0) != hipSuccess) g_sk_err_dev = nullptr;
   }

@@ -79,6 +79,7 @@ struct WgradCuDev {
   unsigned long long* dbg;    // phase stamps of a diagnostic run (tuning variant 3)
   WgPlan* plan;   // device: written by wgrad_rowtab_kernel, read by the two kernels behind it
   int compact;    // 0: masked rows stay in the table as "reads as zeros" (tuning variant 22, A/B; the round-3 behaviour)
+  int* err;       // carca_kernel_error_word(): 3 = a group's range met more k blocks than slots_pg (launcher bug)
 };
 __device__ __forceinline__ unsigned long long* carca_debug_ptr(const WgradCuDev& a) { return a.dbg; }
 
@@ -469,11 +470,17 @@ __global__ __launch_bounds__(WG_NT) void gemm_wgrad_cu_kernel(const WgradCuDev a
       // the partial tile -> this group's slot for the k block
       const int kb_first = (int)(w_begin / nchunks);
       const size_t tile_fl = (size_t)WG_BN * WG_BK;
-      float* const mine = args.part + ((size_t)(grp * args.slots_pg + (kb - kb_first)) * args.nnb + nb) * tile_fl;
+      // (slots_pg is the launcher's PROOF-ONLY bound -- the row table's plan is made on the device after it was sized: a
+      // range that met more k blocks than that would write into the next group's slots.  Say so instead, and drop the tile)
+      const bool slot_ok = kb - kb_first < args.slots_pg;
+      if (!slot_ok && tid == 0 && args.err) __hip_atomic_store(args.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      float* const mine = args.part + ((size_t)(grp * args.slots_pg + (slot_ok ? kb - kb_first : 0)) * args.nnb + nb) * tile_fl;
+      if (slot_ok) {
 #pragma unroll
-      for (int tt = 0; tt < 3; ++tt)
+        for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[(tt * 16 + r) * WG_NT + tid] = acc[tt][r];  // (register order)
+          for (int r = 0; r < 16; ++r) mine[(tt * 16 + r) * WG_NT + tid] = acc[tt][r];  // (register order)
+      }
     }
     if (do_db && n0 + x_c4 < D.N) grad_add(&D.db[n0 + x_c4], bsum);
   }
@@ -612,6 +619,7 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   // k blocks a group's range can touch, for ANY number of chunks per k block c >= 1: a range holds at most
   // ceil(nkb c / ngroups) + 1 units, which reach into at most floor(nkb / ngroups) + 2 k blocks
   g.slots_pg = g.nkb / g.ngroups + 2;
+  g.err = carca_kernel_error_word();
   // Partials pay when a tile receives FEW of them: every partial is 147 KB written and read back (C2's feats_embed: 5.6 per
   // tile, 45 MB, ~14 us of reduce kernel against ~60 us of atomics).  A product of few tiles cut over all the groups (the
   // d x F product of the re-associated backward: 11 tiles, 23 partials each) keeps the atomics.

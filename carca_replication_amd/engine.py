@@ -257,8 +257,11 @@ class GraphedTrainStep:
             self.scope = 0
 
     def __del__(self):
+        # (the collector may run this INSIDE another capture: a synchronize or a free there would invalidate it -- leave the
+        # graph's memory to an explicit close(), or to the end of the process)
         try:
-            self.close()
+            if not torch.cuda.is_current_stream_capturing():
+                self.close()
         except Exception:
             pass
 

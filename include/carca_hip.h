@@ -102,6 +102,10 @@ int carca_poll_errors(void);
 int carca_capture_scope(void* stream, unsigned long long* id_out);
 long long carca_capture_bytes(unsigned long long id);
 int carca_capture_release(unsigned long long id);
+/* Outside a capture the same memory is one buffer per (device, stream, purpose), kept for the life of the process and keyed
+ * by the raw stream handle: a caller that DESTROYS a stream it launched on hands the stream's buffers back with this call
+ * (after synchronising the stream, on the device the launches ran on; refused while the stream is being captured). */
+int carca_release_stream_scratch(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Padded geometry shared by every entry point.  For model width d and H heads (dh = d/H):
