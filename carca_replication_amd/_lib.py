@@ -194,7 +194,7 @@ class EmbedBwdDesc(C.Structure):
     _fields_ = ([("seg", EmbedBwdSeg * MAX_SEGS)] + [(n, C.c_int32) for n in ("nseg", "d", "g", "n_attrs", "n_ctx", "ld_de", "L")]
                 + [("zq", _fp), ("joint_wt", _fp), ("ld_joint_wt", C.c_int32)]
                 + [(n, _fp) for n in ("g_items", "g_feats_w", "g_feats_b", "g_joint_w", "g_joint_b", "g_pos", "workspace",
-                                      "ev_early")] + [("skip_joint", C.c_int32)])
+                                      "ev_early")] + [("skip_joint", C.c_int32), ("only_joint", C.c_int32), ("table_stream", _fp)])
 
 
 class SaWeights(C.Structure):

@@ -167,7 +167,16 @@ SPLIT_MAIN_TARGET_USERS = 0.25  # share of the FIRST target segment's users left
                                 # -> 1.215 / 1.196 / 1.188 / 1.185 / 1.203 / 1.207 ms per graphed step; round 3: 0 / 0.04 / 0.08
                                 # -> 1.654 / 1.642 / 1.655)
 SPLIT_MIN_GFLOP = 20.0     # the split pays when d feats_embed is long against the launches it doubles (C2: 71 GFLOP per pass)
+SPLIT_TAIL_ON_SIDE = True  # round 5: the weight gradients that feed nothing -- the grouped d x d products of the decoder and the
+                           # blocks, d joint_embed -- leave the FIRST stream's chain: they are issued on the second stream behind
+                           # its big kernel (which ends first), gated by an event behind the encoder's backward; the first
+                           # stream goes from the chain straight into its own rows' embedding backward.  False: round 4's order
+SPLIT_TABLE_STREAM = True  # ... and each stream's row table (wgrad_rowtab_kernel: a function of the ids) is built on a third
+                           # stream beside that stream's d [z ; q] / scatter launches instead of between them and the big kernel
+SPLIT_TAIL_MAIN_CUS = 128  # CU budget of the first stream's big kernel under SPLIT_TAIL_ON_SIDE
+SPLIT_TAIL_MAIN_TARGET_USERS = 0.35  # ... and the share of the first target segment's users it takes (SPLIT_MAIN_TARGET_USERS' role)
 _SIDE_STREAMS = {}
+_TABLE_STREAMS = {}
 
 
 class _SideEmbed:
@@ -187,6 +196,9 @@ class _SideEmbed:
         if key not in _SIDE_STREAMS:
             _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
         self.stream = _SIDE_STREAMS[key]
+        if key not in _TABLE_STREAMS:
+            _TABLE_STREAMS[key] = torch.cuda.Stream(device=device)
+        self.table_stream = _TABLE_STREAMS[key].cuda_stream if SPLIT_TABLE_STREAM else None
         self.cus = ops.num_cus()
 
     @staticmethod
@@ -198,11 +210,21 @@ class _SideEmbed:
         with torch.cuda.stream(self.stream):
             ops.set_tuning(10, min(SPLIT_SIDE_CUS, self.cus))
             try:
-                emb.embed_backward(des, segs, zq, self.gbp, L, dpi, wj_t=wj_t, skip_joint=True)
+                emb.embed_backward(des, segs, zq, self.gbp, L, dpi, wj_t=wj_t, skip_joint=True, table_stream=self.table_stream)
             finally:
                 ops.set_tuning(10, 0)
 
+    def tail(self, fn) -> None:
+        """fn() on the second stream once the FIRST stream has got to where it is now (the end of the encoder's backward)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            fn()
+
     def main_cus(self) -> int:
+        if SPLIT_TAIL_ON_SIDE:  # (the second stream still has its tail to run when its big kernel ends: the halves stay halves)
+            return min(SPLIT_TAIL_MAIN_CUS, self.cus)
         if SPLIT_MAIN_CUS > 0:
             return min(SPLIT_MAIN_CUS, self.cus)
         return max(8, self.cus - min(SPLIT_SIDE_CUS, self.cus))
@@ -308,6 +330,67 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, wg, cp, d_wpad):
         st["B"], st["L"], d, H, dec.residual, st["training"], cpd, wg)
 
 
+EARLY_PREP = "graph"  # the backward's zero fill (gradients + staging) and its pack launch (transposed weight copies) read nothing
+                      # the forward produces: "graph" = while a hipGraph is captured they are issued on the second stream at the
+                      # START of the forward and joined in front of the backward's first kernel (14 us off the step's critical
+                      # path); False = at the start of the backward, as eager steps always do
+
+
+def _prepare_backward(model, params, st) -> dict:
+    """What _CarcaFn.backward sets up before its first kernel: the pack plan (one launch), the flat gradient buffer (one
+    fill), the second stream's buffers."""
+    from .modules import CrossAttentionBlock
+
+    emb, dec = model.embeds, model.decoder
+    d, dpi, B = emb.d, st["dpi"], st["B"]
+    dev = st["p_x"].device
+    plan = _PackPlan()
+    cpk, wpad_idx = None, None
+    if isinstance(dec, CrossAttentionBlock):
+        cpk = plan.add_attn(dec.attn, [])
+        wpad_idx = plan.add_staging(ops.PackItem(dec.ffn.weight, 1, cpk.dpo, col_heads=(cpk.dh, cpk.dhp)),
+                                    dec.ffn.weight)
+    bpks = []
+    for blk in model.encoder:
+        dpi_b = ops.padded_dims(d, blk.attn.H)[0]
+        bpks.append(plan.add_attn(blk.attn, [ops.PackItem(blk.ffn_1.weight[:, :, 0], dpi_b, dpi_b, transposed=True),
+                                             ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi_b, dpi_b, transposed=True)]))
+    # the embedding's own transposed copy (joint_embed^T for d [z ; q]) rides in the same pack launch
+    emb_wt_idx = None
+    if hasattr(emb, "backward_pack_items") and not isinstance(st["emb_saved"], str):
+        items = emb.backward_pack_items(dpi)
+        if items:
+            emb_wt_idx = len(plan.fw)
+            plan.fw += items
+    # (every id a scatter-add of this pass can touch: known for the embeddings with an item table)
+    id_lists = [sg[0] for sg in st["segs"]] if hasattr(emb, "items_embed") and len(st["segs"]) <= 4 else None
+    late = emb.late_grad_params(st["emb_saved"]) if hasattr(emb, "late_grad_params") else ()
+    split_on = torch.cuda.is_current_stream_capturing() if SPLIT_EMBED_BWD == "graph" else bool(SPLIT_EMBED_BWD)
+    may_side = (bool(SPLIT_EMBED_BWD) and st["is_ca"] and emb_wt_idx is not None and not ops.deterministic()
+                and ops.early_event is None and hasattr(emb, "side_grad_params") and len(st["segs"]) >= 2)
+    if may_side:  # (worth it only for a long d feats_embed product: every latency-bound launch of the call runs twice)
+        wf = emb.feats_embed.weight
+        rows = sum(sg[0].numel() for sg in st["segs"])
+        # ... and while the encoder's backward leaves CUs idle: its kernels run one or two workgroups per user
+        may_side = (2.0 * rows * wf.shape[0] * wf.shape[1] >= SPLIT_MIN_GFLOP * 1e9 and 2 * B <= ops.num_cus())
+    want_side = may_side and split_on
+    r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+    # (the second stream's buffers are reserved whenever the split COULD be taken: the cached gradient buffer of a model
+    # with a big item table is keyed on this size, and the eager warm-up steps of GraphedTrainStep must leave the capture
+    # the buffer they used -- a fresh one inside the capture would be zero-filled as a whole by every replay)
+    extra = r4(plan.staging_floats()) + (_SideEmbed.floats(emb) if may_side else 0)
+    grads, tail_buf, after_pass = _grad_buffers(model, params, extra, id_lists, late)
+    det = _det_pass(model) if ops.deterministic() else None
+    tail = _Tail(tail_buf)
+    plan.build(dev, tail)
+    gbp = {id(p): g for p, g in zip(params, grads)}
+    side = _SideEmbed(emb, gbp, tail, dev) if want_side else None
+    if side is not None and not side.ok:
+        side = None
+    return dict(plan=plan, cpk=cpk, wpad_idx=wpad_idx, bpks=bpks, emb_wt_idx=emb_wt_idx, grads=grads, after_pass=after_pass,
+                det=det, gbp=gbp, side=side)
+
+
 class _CarcaFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, profile, targets, *params):
@@ -331,6 +414,21 @@ class _CarcaFn(torch.autograd.Function):
             for blk in model.encoder:
                 blk._check_mode()
             dec._check_mode()
+            # EARLY_PREP: what the backward sets up before its first kernel depends on the weights and the ids alone
+            early = None
+            want_early = torch.cuda.is_current_stream_capturing() if EARLY_PREP == "graph" else bool(EARLY_PREP)
+            if want_early and p_x.is_cuda and not ops.deterministic() and ops.early_event is None:
+                key = p_x.device.index if p_x.device.index is not None else torch.cuda.current_device()
+                if key not in _SIDE_STREAMS:
+                    _SIDE_STREAMS[key] = torch.cuda.Stream(device=p_x.device)
+                ps = _SIDE_STREAMS[key]
+                ps.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(ps):
+                    pst = dict(dpi=dpi, B=B, p_x=p_x, segs=segs, emb_saved=None, is_ca=True)
+                    prep = _prepare_backward(model, params, pst)
+                    ev = torch.cuda.Event()
+                    ev.record(ps)
+                early = (prep, ev)
             tr: dict = {}
             ys = model._forward_fused((p_x, p_a, p_c), [sg[:3] for sg in segs[1:]], train=tr)
             st = dict(p_x=p_x, segs=segs, es=tr["es"], emb_saved=tr["zq"], blocks=tr["blocks"], enc_out=tr["enc_out"],
@@ -343,6 +441,9 @@ class _CarcaFn(torch.autograd.Function):
             ctx.model = model
             ctx.params = params
             ctx.st = st
+            ctx.prep = ctx.prep_event = None
+            if early is not None:  # (the backward's fill + pack, issued on the second stream before the forward's first kernel)
+                ctx.prep, ctx.prep_event = early
             joint = getattr(ys, "joint", None)
             if joint is not None and len(ys) > 1:
                 # one output tensor [B, sum N] whose column blocks are the groups' scores: autograd then hands the
@@ -413,52 +514,13 @@ class _CarcaFn(torch.autograd.Function):
         p_x = st["p_x"]
         dev = p_x.device
         # every transposed weight copy and every staging area of this pass: one pack launch, one zero fill (shared with
-        # the gradients), one unpack launch
-        from .modules import CrossAttentionBlock
-
-        plan = _PackPlan()
-        cpk, wpad_idx = None, None
-        if isinstance(dec, CrossAttentionBlock):
-            cpk = plan.add_attn(dec.attn, [])
-            wpad_idx = plan.add_staging(ops.PackItem(dec.ffn.weight, 1, cpk.dpo, col_heads=(cpk.dh, cpk.dhp)),
-                                        dec.ffn.weight)
-        bpks = []
-        for blk in model.encoder:
-            dpi_b = ops.padded_dims(d, blk.attn.H)[0]
-            bpks.append(plan.add_attn(blk.attn, [ops.PackItem(blk.ffn_1.weight[:, :, 0], dpi_b, dpi_b, transposed=True),
-                                                 ops.PackItem(blk.ffn_2.weight[:, :, 0], dpi_b, dpi_b, transposed=True)]))
-        # the embedding's own transposed copy (joint_embed^T for d [z ; q]) rides in the same pack launch
-        emb_wt_idx = None
-        if hasattr(emb, "backward_pack_items") and not isinstance(st["emb_saved"], str):
-            items = emb.backward_pack_items(dpi)
-            if items:
-                emb_wt_idx = len(plan.fw)
-                plan.fw += items
-        # (every id a scatter-add of this pass can touch: known for the embeddings with an item table)
-        id_lists = [sg[0] for sg in st["segs"]] if hasattr(emb, "items_embed") and len(st["segs"]) <= 4 else None
-        late = emb.late_grad_params(st["emb_saved"]) if hasattr(emb, "late_grad_params") else ()
-        split_on = torch.cuda.is_current_stream_capturing() if SPLIT_EMBED_BWD == "graph" else bool(SPLIT_EMBED_BWD)
-        may_side = (bool(SPLIT_EMBED_BWD) and st["is_ca"] and emb_wt_idx is not None and not ops.deterministic()
-                    and ops.early_event is None and hasattr(emb, "side_grad_params") and len(st["segs"]) >= 2)
-        if may_side:  # (worth it only for a long d feats_embed product: every latency-bound launch of the call runs twice)
-            wf = emb.feats_embed.weight
-            rows = sum(sg[0].numel() for sg in st["segs"])
-            # ... and while the encoder's backward leaves CUs idle: its kernels run one or two workgroups per user
-            may_side = (2.0 * rows * wf.shape[0] * wf.shape[1] >= SPLIT_MIN_GFLOP * 1e9 and 2 * B <= ops.num_cus())
-        want_side = may_side and split_on
-        r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
-        # (the second stream's buffers are reserved whenever the split COULD be taken: the cached gradient buffer of a model
-        # with a big item table is keyed on this size, and the eager warm-up steps of GraphedTrainStep must leave the capture
-        # the buffer they used -- a fresh one inside the capture would be zero-filled as a whole by every replay)
-        extra = r4(plan.staging_floats()) + (_SideEmbed.floats(emb) if may_side else 0)
-        grads, tail_buf, after_pass = _grad_buffers(model, params, extra, id_lists, late)
-        det = _det_pass(model) if ops.deterministic() else None
-        tail = _Tail(tail_buf)
-        plan.build(dev, tail)
-        gbp = {id(p): g for p, g in zip(params, grads)}
-        side = _SideEmbed(emb, gbp, tail, dev) if want_side else None
-        if side is not None and not side.ok:
-            side = None
+        # the gradients), one unpack launch -- issued HERE, or already under the forward (EARLY_PREP, _prepare_backward)
+        prep = ctx.prep if getattr(ctx, "prep", None) is not None else _prepare_backward(model, params, st)
+        if getattr(ctx, "prep_event", None) is not None:
+            torch.cuda.current_stream().wait_event(ctx.prep_event)
+        ctx.prep = ctx.prep_event = None
+        plan, cpk, wpad_idx, bpks, emb_wt_idx = prep["plan"], prep["cpk"], prep["wpad_idx"], prep["bpks"], prep["emb_wt_idx"]
+        grads, after_pass, det, gbp, side = prep["grads"], prep["after_pass"], prep["det"], prep["gbp"], prep["side"]
         ys = ctx.saved_tensors
         ngroups = st["ngroups"]
         if "Ns" in st:  # joint output: per-group views of the one score / gradient tensor
@@ -478,7 +540,8 @@ class _CarcaFn(torch.autograd.Function):
                 segs_all, zq_all = st["segs"], st["emb_saved"]
                 rows0 = segs_all[0][0].numel()
                 side_segs, side_des, main_extra, zq_side = list(segs_all[1:]), list(des_t), None, rows0
-                nb_main = int(SPLIT_MAIN_TARGET_USERS * segs_all[1][0].shape[0])
+                nb_main = int((SPLIT_TAIL_MAIN_TARGET_USERS if SPLIT_TAIL_ON_SIDE else SPLIT_MAIN_TARGET_USERS) *
+                              segs_all[1][0].shape[0])
                 if 0 < nb_main < segs_all[1][0].shape[0] and len(segs_all) + 1 <= ops._lib.MAX_SEGS:
                     # balance: the FIRST users of the first target segment stay with the profile rows (their [z ; q] rows
                     # follow the profile's in the saved buffer: one call, two segments)
@@ -516,6 +579,32 @@ class _CarcaFn(torch.autograd.Function):
         if st["p_emb"] > 0:  # CARCA.dropout on the profile embedding (carca.py:416)
             dx = ops.mask_mul(dx, st["m_embed"], 1.0 / (1.0 - st["p_emb"]), d, dpi)
         des = [dx] + des_t                      # d e per segment, [rows, dpi]; profile rows still unmasked
+        if side is not None and SPLIT_TAIL_ON_SIDE:
+            wj_t = plan.wT.view(emb_wt_idx)
+            m_des, m_segs = [dx], list(st["segs"][:1])
+            if main_extra is not None:
+                m_segs.append(main_extra[0])
+                m_des.append(main_extra[1])
+            all_des, all_segs = m_des + side_des, m_segs + side_segs
+
+            def tail():  # (second stream, behind its big kernel: nothing downstream reads these gradients before the join)
+                wg.launch()
+                plan.unpack(gbp)
+                emb.embed_backward(all_des, all_segs, st["emb_saved"], gbp, L, dpi, wj_t=wj_t, only_joint=True)
+
+            side.tail(tail)
+            ops.set_tuning(10, side.main_cus())
+            try:  # first stream: its own rows' d [z ; q], scatter-add and d feats_embed, straight behind the chain
+                emb.embed_backward(m_des, m_segs, st["emb_saved"], gbp, L, dpi, wj_t=wj_t, skip_joint=True,
+                                   table_stream=side.table_stream)
+            finally:
+                ops.set_tuning(10, 0)
+            side.join(gbp)
+            if det is not None:
+                det.finish()
+            after_pass()
+            ctx.st = None
+            return (None, None, None) + tuple(grads)
         wg.launch()
         if det is not None:  # (the staging areas are about to be READ: their accumulated sums out of the shadow first)
             det.flush_staging()

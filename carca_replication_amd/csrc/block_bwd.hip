@@ -285,10 +285,14 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
   CARCA_CHECK_ARG(D->d >= 1 && D->g >= 1 && D->n_attrs >= 1 && D->n_ctx >= 0 && D->ld_de >= D->d && D->L >= 1,
                   "embed_bwd: bad dims");
   CARCA_CHECK_ARG(D->zq && D->joint_wt && D->g_items && D->g_feats_w && D->g_feats_b && D->g_joint_w && D->g_joint_b &&
-                      D->workspace,
+                      (D->workspace || D->only_joint),  // (an only_joint call has no d [z ; q] to hold)
                   "embed_bwd: null pointer");
   const int d = D->d, g = D->g, ldz = d + g;
   int rc;
+  CARCA_CHECK_ARG(!(D->only_joint && D->skip_joint), "embed_bwd: only_joint and skip_joint exclude each other");
+  // the d feats_embed kernel's row table on its own stream, beside everything this call launches in front of that kernel
+  if (D->table_stream && !D->only_joint)
+    if ((rc = carca_wgrad_table_fork((hipStream_t)stream, (hipStream_t)D->table_stream))) return rc;
   // d LearnableEncoding.encoding.weight[t] += sum over users of (d e * mask)[t]   (carca.py:25-31)
   if (D->g_pos) {
     const CarcaEmbedBwdSeg& p = D->seg[0];
@@ -313,7 +317,7 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
       j.dy = sg.de; j.x = D->zq + row0 * ldz; j.ids = sg.ids; j.rows = sg.rows; j.T = 1;
     }
     row0 += sg.rows;
-    if (sg.joint_only) continue;
+    if (sg.joint_only || D->only_joint) continue;
     CARCA_CHECK_ARG((sg.attrs || sg.attrs_table) && (D->n_ctx == 0 || sg.ctx), "embed_bwd: segment %d malformed", s);
     dzq[nf] = ws;
     ws += (size_t)sg.rows * ldz;
@@ -331,7 +335,7 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
     sids[nf] = sg.ids; srows[nf] = sg.rows;
     ++nf;
   }
-  CARCA_CHECK_ARG(nf >= 1, "embed_bwd: every segment is joint_only");
+  CARCA_CHECK_ARG(nf >= 1 || D->only_joint, "embed_bwd: every segment is joint_only");
   wj.nseg = nj;
   gz.nseg = wf.nseg = nf;
   if (nj) {
@@ -339,6 +343,7 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
     wj.mask_rows = 1;
     if ((rc = carca_gemm_wgrad(&wj, stream))) return rc;
   }
+  if (D->only_joint) return CARCA_OK;
   gz.lda0 = D->ld_de; gz.K0 = d; gz.bt0 = D->joint_wt; gz.ldb0 = D->ld_joint_wt; gz.N = ldz; gz.ldc = ldz;
   gz.ncols_out = ldz; gz.gate_slope = 0.01f; gz.mask_rows = 1;
   if ((rc = carca_gemm_rows(&gz, stream))) return rc;
@@ -387,5 +392,7 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
       }
     }
   }
-  return carca_gemm_wgrad(&wf, stream);
+  rc = carca_gemm_wgrad(&wf, stream);
+  const int rj = carca_wgrad_table_join((hipStream_t)stream);  // (a product that did not take the persistent kernel: close the fork)
+  return rc ? rc : rj;
 }

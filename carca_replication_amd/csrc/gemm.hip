@@ -1010,7 +1010,12 @@ constexpr int SKC_RB = 8;       // row blocks one workgroup's stretch may touch 
 constexpr int SKC_CH = 1536;    // 64-row chunks of all segments (+ one entry per segment)
 constexpr int SKC_LDS_IDS = 2 * 384 * 36;  // ids the prologue keeps in LDS (the A buffers' space: 27,648)
 constexpr int SKC_OV_MAX = 12;  // bound on the row-block ownership cost in K steps (a stretch holds at least 16 steps)
-constexpr int SKC_OV_TEAM = 4, SKC_OV_LONE = 4;  // defaults (tools/stamp_skc.py; tuning keys 17 / 18)
+// defaults (tuning keys 17 / 18 = value + 1).  MEASURED, round 5, interleaved A/B at C2 (tools/ab_eval.py): ownership cost 0 / 4
+// / 8 steps -> feature GEMM 468.1 / 470.4 / 475.6 us: although the workgroups that own a row block END ~20 us after those
+// that own none (tools/stamp_skc.py), handing them fewer steps makes the launch longer -- the late finishers are late for
+// what the stamps do not show (their taken partials' loads contend with the givers' last stores), not for their step count.
+// The correction stays as a switch; the stretches stay equal in steps.
+constexpr int SKC_OV_TEAM = 0, SKC_OV_LONE = 0;
 
 template <int XC>
 __global__ __launch_bounds__(768) void gemm_rows_skc_kernel(const GemmDev args) {

@@ -548,6 +548,48 @@ int g_num_cus = 0;
 
 }  // namespace
 
+// The row table depends on the ids alone (which rows take part, where their operands start): a caller that has other work to
+// issue first -- carca_embed_bwd: d joint_embed, d [z ; q], the scatter-add -- FORKS a second stream off its own at entry
+// (carca_wgrad_table_fork), the next carca_wgrad_cu_try of this thread launches wgrad_rowtab_kernel THERE (17-26 us of one
+// block's latency chain beside the caller's launches instead of in front of the big kernel) and makes `stream` wait for it;
+// carca_wgrad_table_join closes a fork that no launch used.  Inside a hipGraph capture the two event edges become graph
+// edges.  The table's memory is ordered by `stream`: the fork's event sits behind every earlier launch that read it.
+namespace {
+struct TableFork {
+  hipStream_t ts = nullptr;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  bool open = false;
+};
+thread_local TableFork g_fork;
+}  // namespace
+int carca_wgrad_table_fork(hipStream_t stream, hipStream_t table_stream) {
+  if (!table_stream || table_stream == stream) return CARCA_OK;
+  TableFork& f = g_fork;
+  if (!f.ea && (hipEventCreateWithFlags(&f.ea, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&f.eb, hipEventDisableTiming) != hipSuccess)) {
+    (void)hipGetLastError();
+    f.ea = f.eb = nullptr;
+    return CARCA_OK;  // (no events: no fork -- the table is built on `stream` as before)
+  }
+  if (hipEventRecord(f.ea, stream) != hipSuccess || hipStreamWaitEvent(table_stream, f.ea, 0) != hipSuccess) {
+    carca_set_error("wgrad_table_fork: cannot fork the row-table stream: %s", hipGetErrorString(hipGetLastError()));
+    return CARCA_ERR_BADARG;
+  }
+  f.ts = table_stream;
+  f.open = true;
+  return CARCA_OK;
+}
+int carca_wgrad_table_join(hipStream_t stream) {
+  TableFork& f = g_fork;
+  if (!f.open) return CARCA_OK;
+  f.open = false;
+  if (hipEventRecord(f.eb, f.ts) != hipSuccess || hipStreamWaitEvent(stream, f.eb, 0) != hipSuccess) {
+    carca_set_error("wgrad_table_join: cannot join the row-table stream: %s", hipGetErrorString(hipGetLastError()));
+    return CARCA_ERR_BADARG;
+  }
+  return CARCA_OK;
+}
+
 // CARCA_OK: launched.  1: shape not suited / operands too large for 31-bit offsets -> caller uses the tiled kernel.
 int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   WgradCuDev g{};
@@ -640,7 +682,12 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
     g.plan = (WgPlan*)(aux + cnt_ints - plan_ints);  // (16-byte aligned: everything in front of it is whole 16-byte groups)
     g.part = (float*)(aux + cnt_ints);
   }
-  hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3(1), dim3(1024), 0, stream, g, tab);
+  if (g_fork.open) {  // (the caller forked a stream for the table at its entry: see carca_wgrad_table_fork)
+    hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3(1), dim3(1024), 0, g_fork.ts, g, tab);
+    if (int rc = carca_wgrad_table_join(stream)) return rc;
+  } else {
+    hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3(1), dim3(1024), 0, stream, g, tab);
+  }
   g.dbg = carca_debug_buffer();
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 3 && g.dbg)
     hipLaunchKernelGGL(gemm_wgrad_cu_kernel<1>, dim3(grid), dim3(WG_NT), 0, stream, g);

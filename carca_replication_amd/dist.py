@@ -68,6 +68,32 @@ def global_mask_count(ids: torch.Tensor) -> torch.Tensor:
     return cnt
 
 
+_VALIDATED: set = set()
+
+
+def validate_global_batch(n_local: int, global_batch: Optional[int], device=None) -> None:
+    """`global_batch` (users of the whole step over all ranks, shards as shard_range cuts them) checked ON EVERY RANK: the
+    ranks gather their user counts -- one tiny collective, once per (count, global_batch) pair -- and every one of them raises
+    the same ValueError when a shard is larger than ceil(global_batch / world) or the counts do not add up.  Checked by the
+    violating rank alone (what engine._row_exchange_len does on its own) the others would walk into the step's next
+    collective and wait there until the backend's timeout."""
+    if global_batch is None or not _active():
+        return
+    key = (int(n_local), int(global_batch), dist.get_world_size())
+    if key in _VALIDATED:
+        return
+    world = dist.get_world_size()
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device if device is not None else "cpu")
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    counts = [int(t.item()) for t in every]
+    per_rank = -(-int(global_batch) // world)
+    if max(counts) > per_rank or sum(counts) != int(global_batch):
+        raise ValueError(f"global_batch={global_batch} over {world} ranks allows at most {per_rank} users per rank and needs "
+                         f"them to add up; the ranks hold {counts} (dist.shard_range)")
+    _VALIDATED.add(key)
+
+
 def _buckets(grads: List[torch.Tensor], cap_bytes: int) -> List[List[torch.Tensor]]:
     out, cur, size = [], [], 0
     for g in grads:

@@ -73,7 +73,10 @@ def train_step(model, optim, batch, sharded: bool = False, global_batch: Optiona
         # summed over ranks, in place in the backward's flat buffer -- the early range started under the backward's last
         # kernel: an event recorded right before that launch (CarcaEmbedBwdDesc.ev_early) gates a side stream, RCCL's
         # own stream queues behind the side stream, and the call returns to issue the late range behind the kernel.
-        _row_exchange_len(p_x, o_x, global_batch)  # (validates global_batch ahead of the step's first collective)
+        # (global_batch validated ahead of the step's first collective -- by EVERY rank together the first time a pair
+        # (local users, global_batch) is seen, so that all of them raise; by this rank alone from then on)
+        cdist.validate_global_batch(p_x.shape[0], global_batch, p_x.device if p_x.is_cuda else None)
+        _row_exchange_len(p_x, o_x, global_batch)
         denom = cdist.global_mask_count(o_x)
         # (deterministic mode: the early range's sums sit in the fixed-point shadow until the pass ends -- no early start)
         ev = _early_event() if p_x.is_cuda and not ops.deterministic() else None
@@ -194,6 +197,9 @@ class GraphedTrainStep:
                  global_batch: Optional[int] = None):
         self.model, self.optim, self.sharded, self.global_batch = model, optim, sharded, global_batch
         example_batch = as_batch7(example_batch)
+        if sharded:  # (the shapes are fixed from here on: one check, by every rank together, before anything is captured)
+            cdist.validate_global_batch(example_batch[0].shape[0], global_batch,
+                                        example_batch[0].device if example_batch[0].is_cuda else None)
         self.inputs = tuple(t if t is None else t.clone() for t in example_batch)
         self.denom = torch.ones(1, dtype=torch.float32, device=self.inputs[0].device) if sharded else None
         if sharded:

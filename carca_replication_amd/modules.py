@@ -374,7 +374,8 @@ class AllEmbedding(Embedding):
         backward pass packs it in ITS pack launch and hands the view back as embed_backward(..., wj_t=)."""
         return [ops.PackItem(self.joint_embed.weight, self.d + self.feats_embed.weight.shape[0], dpi, transposed=True)]
 
-    def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int, wj_t=None, joint_only=None, skip_joint=False) -> None:
+    def embed_backward(self, des, segs, zq, gbp, L: int, dpi: int, wj_t=None, joint_only=None, skip_joint=False,
+                       only_joint=False, table_stream=None) -> None:
         """Backward of embed_segments (carca.py:85-95): des[i] = d e of segment i, [rows, dpi], NOT yet masked;
         accumulates into the gradient buffers gbp[id(param)].  One host call (carca_embed_bwd): position-encoding
         gradient, d joint_embed, d [z ; q], item-row scatter-add, d feats_embed.  joint_only / skip_joint: see
@@ -400,8 +401,9 @@ class AllEmbedding(Embedding):
                            g_feats_b=gbp[id(self.feats_embed.bias)], g_joint_w=gbp[id(self.joint_embed.weight)],
                            g_joint_b=gbp[id(self.joint_embed.bias)]),
                       table, d, g_feats, n_attrs, n_ctx, L,
-                      gbp[id(enc_w)] if (enc_w is not None and not segs[0][3]) else None,  # (targets carry no position term)
-                      joint_only=joint_only, skip_joint=skip_joint)
+                      # (targets carry no position term; an only_joint call leaves it to the call that owns the profile rows)
+                      gbp[id(enc_w)] if (enc_w is not None and not segs[0][3] and not only_joint) else None,
+                      joint_only=joint_only, skip_joint=skip_joint, only_joint=only_joint, table_stream=table_stream)
 
     def _embed_unmasked(self, x: Tensor, a: Optional[Tensor], c: Tensor, target: bool) -> Tensor:
         """carca.py:86-92 WITHOUT line 94: W_j [sqrt(d) E[x] ; W_f [a;c] + b_f] + b_j (+ position term) for every slot, id 0

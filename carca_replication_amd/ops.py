@@ -761,10 +761,12 @@ early_event = None
 
 
 def embed_bwd(des, segs, zq: Tensor, joint_wt: Tensor, grads: dict, table: Optional[Tensor], d: int, g: int, n_attrs: int,
-              n_ctx: int, L: int, g_pos: Optional[Tensor], joint_only=None, skip_joint: bool = False) -> None:
+              n_ctx: int, L: int, g_pos: Optional[Tensor], joint_only=None, skip_joint: bool = False,
+              only_joint: bool = False, table_stream: Optional[int] = None) -> None:
     """Backward of AllEmbedding.forward over all segments as ONE host call (carca_embed_bwd).  des[i]: d e [rows, ld]
     (unmasked); segs[i] = (ids, attrs or None, ctx, is_target); joint_wt: [d + g, ld] transposed joint weight.
-    joint_only[i] / skip_joint: a pass that runs the target rows' share on a second stream (include/carca_hip.h)."""
+    joint_only[i] / skip_joint / only_joint: a pass that runs the target rows' share on a second stream; table_stream: raw
+    handle of a stream for the big weight-gradient kernel's row table (include/carca_hip.h)."""
     lib = _lib.load()
     nseg = len(des)
     D = _lib.EmbedBwdDesc()
@@ -781,7 +783,7 @@ def embed_bwd(des, segs, zq: Tensor, joint_wt: Tensor, grads: dict, table: Optio
         S = D.seg[i]
         S.de, S.ids, S.rows, S.T = de.data_ptr(), ids32.data_ptr(), de.shape[0], x.shape[1]
         rows[i] = de.shape[0]
-        if joint_only is not None and joint_only[i]:
+        if only_joint or (joint_only is not None and joint_only[i]):
             S.joint_only = 1
             rows[i] = 0  # (no d [z ; q] workspace)
             keep += [de, ids32]
@@ -805,6 +807,8 @@ def embed_bwd(des, segs, zq: Tensor, joint_wt: Tensor, grads: dict, table: Optio
     D.workspace = ws.data_ptr()
     D.ev_early = early_event.handle if early_event is not None else None
     D.skip_joint = 1 if skip_joint else 0
+    D.only_joint = 1 if only_joint else 0
+    D.table_stream = table_stream
     _lib.check(lib.carca_embed_bwd(C.byref(D), _stream()), "embed_bwd")
     del keep
 

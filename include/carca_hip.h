@@ -578,6 +578,12 @@ typedef struct CarcaEmbedBwdDesc {
   int32_t skip_joint;     /* 1: no d joint_embed in this call (a later call of the pass lists these segments joint_only):
                            * a backward pass may hand the target rows' share to a second stream as soon as their d e is
                            * final and keep the small d joint_embed product in ONE launch over all rows */
+  int32_t only_joint;     /* 1: d joint_embed (and g_pos) over the listed segments and NOTHING else -- the counterpart of
+                           * skip_joint: a pass whose streams each ran their own rows with skip_joint issues the one small
+                           * product over all rows wherever it has room (every segment may be joint_only) */
+  void* table_stream;     /* optional second hipStream_t: the row table of the d feats_embed kernel (a function of the ids
+                           * alone, one block's latency chain) is built there, forked off `stream` at entry and joined in front
+                           * of the kernel, beside the launches of this call instead of between them.  NULL = on `stream` */
 } CarcaEmbedBwdDesc;
 size_t carca_embed_bwd_workspace(const int32_t* rows /*host [nseg]*/, int nseg, int d, int g);
 int carca_embed_bwd(const CarcaEmbedBwdDesc* desc /*host*/, void* stream);

@@ -157,3 +157,147 @@ def test_two_rank_gloo_gradient_allreduce_equals_full_batch():
         assert worst < 1e-4, worst
         assert sums == [3.0, 4.0]
         assert ok_flat and ok_sparse
+
+
+# ---- GraphedTrainStep(sharded=True): what happens around a replay, on two gloo ranks ---------------------------------------
+# (The capture itself needs a GPU -- tests/test_hip_optim.py runs it in a one-rank process group.  Here the step object is
+# built by hand around a stand-in "graph" whose replay() writes this rank's gradients into the flat buffer the way the
+# captured backward does, and engine.GraphedTrainStep.__call__ -- the real code -- runs everything behind it: the loss
+# normaliser's all-reduce, the in-place reduction of the early and late ranges, the row exchange of a big item table with
+# UNEVEN shards padded to the host-known length, the exchanged ids handed to the gradient cache and to the optimizer.)
+class _FakeGraph:
+    def __init__(self, fill):
+        self.fill, self.replays = fill, 0
+
+    def replay(self):
+        self.replays += 1
+        self.fill()
+
+
+class _FakeOptim:
+    def __init__(self):
+        self.marked, self.steps = [], 0
+
+    def mark_rows(self, w, ids):
+        self.marked.append((w, ids.clone()))
+
+    def step(self):
+        self.steps += 1
+
+
+def _graphed_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    cdist.init(backend="gloo")
+    from carca_replication_amd import engine
+
+    engine.SPARSE_TABLE_BYTES = 1024  # (a 50 x 6 table counts as "big": row exchange instead of the dense all-reduce)
+    users = [4, 3][rank]              # uneven shards of a 7-user batch
+    L = 5
+    g = torch.Generator().manual_seed(100 + rank)
+    p_x = torch.randint(1, 50, (users, L), generator=g).int()
+    o_x = torch.randint(1, 50, (users, 2 * L), generator=g).int()
+    o_x[0, :2] = 0
+
+    class _Emb(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.items_embed = torch.nn.Embedding(50, 6, padding_idx=0)
+
+    class _Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embeds = _Emb()
+            self.early = torch.nn.Parameter(torch.zeros(5, 3))
+            self.late = torch.nn.Parameter(torch.zeros(7))
+
+    model = _Model()
+    table = model.embeds.items_embed.weight
+    params = [model.early, model.late, table]
+    r4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+    n_early, n_late = r4(15), r4(15) + r4(7)
+    front = n_late + 8  # (8 staging floats)
+    flat = torch.zeros(front + table.numel())
+    model.early.grad = flat[:15].view(5, 3)
+    model.late.grad = flat[n_early: n_early + 7]
+    table.grad = flat[front:].view(50, 6)
+    model.__dict__["_flat_grad"] = dict(flat=flat, early=(0, n_early), late=(n_early, n_late), front=front, big=[table],
+                                        n_params=3)
+    ids_all = torch.cat([p_x.reshape(-1), o_x.reshape(-1)]).long()
+    row_g = torch.randn(ids_all.numel(), 6, generator=g)
+
+    def fill():  # "the captured backward": this rank's gradients, every replay
+        flat.zero_()
+        flat[:15] = torch.arange(15.0) * (rank + 1)
+        flat[n_early: n_early + 7] = 10.0 * (rank + 1)
+        flat[n_late: front] = -7.0  # staging: nobody's gradient
+        dense = torch.zeros(50, 6)
+        dense.index_add_(0, ids_all, row_g)
+        dense[0] = 0
+        flat[front:] = dense.reshape(-1)
+
+    step = object.__new__(engine.GraphedTrainStep)
+    optim = _FakeOptim()
+    step.model, step.optim, step.sharded, step.global_batch = model, optim, True, 7
+    step.inputs = (p_x.clone(), None, torch.zeros(users, L, 2), o_x.clone(), None, torch.zeros(users, 2 * L, 2),
+                   torch.zeros(users, 2 * L, dtype=torch.int32))
+    step.denom = torch.ones(1)
+    per_rank = engine._row_exchange_len(p_x, o_x, 7)
+    assert per_rank == 4 * 3 * L
+    step.foreign = torch.zeros(world * per_rank, dtype=torch.int32)
+    step.ev_early = None  # (CPU: no event, both ranges go out behind the replay)
+    step.graph = _FakeGraph(fill)
+    step.params, step.grads = params, [p.grad for p in params]
+    step.loss = torch.zeros(1)
+    ok = True
+    for it in range(2):
+        step(step.inputs)
+        # the normaliser: non-pad target slots of BOTH ranks
+        want_denom = torch.count_nonzero(o_x).float().reshape(1)
+        dist.all_reduce(want_denom)
+        ok = ok and float(step.denom) == float(want_denom)
+        # dense ranges summed over the ranks in place, staging untouched
+        ok = ok and bool(torch.equal(flat[:15], torch.arange(15.0) * 3)) and bool(torch.equal(flat[n_early: n_early + 7], torch.full((7,), 30.0)))
+        ok = ok and bool(torch.equal(flat[n_late: front], torch.full((8,), -7.0)))
+        ok = ok and cdist.last_reduce["path"] == "flat-inplace"
+        # the table: the dense all-reduce of the ranks' scatter-adds, reached through the row exchange
+        mine = torch.zeros(50, 6)
+        mine.index_add_(0, ids_all, row_g)
+        mine[0] = 0
+        want = mine.clone()
+        dist.all_reduce(want)
+        ok = ok and bool(torch.allclose(table.grad, want, atol=1e-5))
+        # every rank's ids reached the gradient cache's buffer (padded with the pad row's id) and the optimizer
+        every = [torch.zeros(per_rank, dtype=torch.int64) for _ in range(world)]
+        pad = torch.zeros(per_rank, dtype=torch.int64)
+        pad[: ids_all.numel()] = ids_all
+        dist.all_gather(every, pad)
+        seen = set(torch.cat(every).tolist())
+        ok = ok and set(step.foreign.tolist()) == seen and model.__dict__["_grad_foreign"] is step.foreign
+        ok = ok and len(optim.marked) == it + 1 and set(optim.marked[-1][1].tolist()) == seen and optim.steps == it + 1
+        ok = ok and step.graph.replays == it + 1
+    # global_batch that the shards do not fit: EVERY rank raises (rank 1's three users alone would pass ceil(6 / 2) = 3),
+    # before the step's first collective -- nobody is left waiting in an all-reduce
+    raised = False
+    try:
+        cdist.validate_global_batch(users, 6)
+    except ValueError:
+        raised = True
+    cdist.validate_global_batch(users, 7)  # (and the right one passes on both)
+    ret[rank] = (ok, raised)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_graphed_sharded_step_control_flow():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_graphed_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        ok, raised = ret[rank]
+        assert ok, rank
+        assert raised, rank  # rank 1 holds 3 <= ceil(6 / 2) users and still raises: the check is collective

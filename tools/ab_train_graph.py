@@ -1,6 +1,6 @@
 """A/B of the GRAPHED train step (engine.GraphedTrainStep at C2, B = 128) under settings of the backward's two-stream
 split (autograd.SPLIT_EMBED_BWD / SPLIT_SIDE_CUS / SPLIT_MAIN_TARGET_USERS), interleaved in one process.
-usage: ab_train_graph.py "split=0" "split=1,side=128,frac=0.0" "split=1,side=96,main=256,frac=0.1" ...   (+ "t<key>=<value>" = tuning keys)"""
+usage: ab_train_graph.py "split=0" "split=1,side=128,frac=0.0" "tail=0" "tail=1,tfrac=0.3,tmain=128,table=1" ...   (+ "t<key>=<value>" = tuning keys)"""
 import os
 import sys
 
@@ -30,6 +30,8 @@ for rnd in range(int(os.environ.get("ROUNDS", "4"))):
     for s in settings:
         autograd.SPLIT_EMBED_BWD, autograd.SPLIT_SIDE_CUS, autograd.SPLIT_MAIN_TARGET_USERS = "graph", 128, 0.25
         autograd.SPLIT_MAIN_CUS = 256
+        autograd.SPLIT_TAIL_ON_SIDE, autograd.SPLIT_TABLE_STREAM = True, True
+        autograd.SPLIT_TAIL_MAIN_CUS, autograd.SPLIT_TAIL_MAIN_TARGET_USERS = 128, 0.35
         for k in range(8):
             lib.carca_set_tuning(k, 0)
         for kv in filter(None, s.split(",")):
@@ -42,6 +44,14 @@ for rnd in range(int(os.environ.get("ROUNDS", "4"))):
                 autograd.SPLIT_MAIN_CUS = int(v)
             elif k == "frac":
                 autograd.SPLIT_MAIN_TARGET_USERS = float(v)
+            elif k == "tail":       # round 5: the weight gradients that feed nothing on the second stream's tail
+                autograd.SPLIT_TAIL_ON_SIDE = bool(int(v))
+            elif k == "table":      # ... and the row tables on a third stream
+                autograd.SPLIT_TABLE_STREAM = bool(int(v))
+            elif k == "tmain":
+                autograd.SPLIT_TAIL_MAIN_CUS = int(v)
+            elif k == "tfrac":
+                autograd.SPLIT_TAIL_MAIN_TARGET_USERS = float(v)
             elif k.startswith("t"):
                 lib.carca_set_tuning(int(k[1:]), int(v))
         step = engine.GraphedTrainStep(model, opt, batch)
