@@ -330,7 +330,9 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, wg, cp, d_wpad):
         st["B"], st["L"], d, H, dec.residual, st["training"], cpd, wg)
 
 
-EARLY_PREP = "graph"  # the backward's zero fill (gradients + staging) and its pack launch (transposed weight copies) read nothing
+import os as _os
+
+EARLY_PREP = {"0": False, "1": True}.get(_os.environ.get("CARCA_EARLY_PREP", ""), "graph")  # the backward's zero fill (gradients + staging) and its pack launch (transposed weight copies) read nothing
                       # the forward produces: "graph" = while a hipGraph is captured they are issued on the second stream at the
                       # START of the forward and joined in front of the backward's first kernel (14 us off the step's critical
                       # path); False = at the start of the backward, as eager steps always do
@@ -415,9 +417,12 @@ class _CarcaFn(torch.autograd.Function):
                 blk._check_mode()
             dec._check_mode()
             # EARLY_PREP: what the backward sets up before its first kernel depends on the weights and the ids alone
-            early = None
+            early_box: list = []
             want_early = torch.cuda.is_current_stream_capturing() if EARLY_PREP == "graph" else bool(EARLY_PREP)
-            if want_early and p_x.is_cuda and not ops.deterministic() and ops.early_event is None:
+
+            def fork_prep():
+                # (forked BEHIND the forward's first launch -- its pack kernel --, not at the very start of a capture: a
+                # stream that waits on an event recorded into a still EMPTY capture crashed hipStreamEndCapture here)
                 key = p_x.device.index if p_x.device.index is not None else torch.cuda.current_device()
                 if key not in _SIDE_STREAMS:
                     _SIDE_STREAMS[key] = torch.cuda.Stream(device=p_x.device)
@@ -428,9 +433,12 @@ class _CarcaFn(torch.autograd.Function):
                     prep = _prepare_backward(model, params, pst)
                     ev = torch.cuda.Event()
                     ev.record(ps)
-                early = (prep, ev)
+                early_box.append((prep, ev))
+
+            hook = fork_prep if (want_early and p_x.is_cuda and not ops.deterministic() and ops.early_event is None) else None
             tr: dict = {}
-            ys = model._forward_fused((p_x, p_a, p_c), [sg[:3] for sg in segs[1:]], train=tr)
+            ys = model._forward_fused((p_x, p_a, p_c), [sg[:3] for sg in segs[1:]], train=tr, after_pack=hook)
+            early = early_box[0] if early_box else None
             st = dict(p_x=p_x, segs=segs, es=tr["es"], emb_saved=tr["zq"], blocks=tr["blocks"], enc_out=tr["enc_out"],
                       training=model.training, B=B, L=L, m_embed=tr["m_embed"], p_emb=tr["p_emb"], dpi=dpi, is_ca=True,
                       p_normed=tr["p_normed"], csave=tr["csave"], cw=tr["cw"], keep=tr["keep"], ngroups=len(ys))

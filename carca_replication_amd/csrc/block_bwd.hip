@@ -290,9 +290,6 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
   const int d = D->d, g = D->g, ldz = d + g;
   int rc;
   CARCA_CHECK_ARG(!(D->only_joint && D->skip_joint), "embed_bwd: only_joint and skip_joint exclude each other");
-  // the d feats_embed kernel's row table on its own stream, beside everything this call launches in front of that kernel
-  if (D->table_stream && !D->only_joint)
-    if ((rc = carca_wgrad_table_fork((hipStream_t)stream, (hipStream_t)D->table_stream))) return rc;
   // d LearnableEncoding.encoding.weight[t] += sum over users of (d e * mask)[t]   (carca.py:25-31)
   if (D->g_pos) {
     const CarcaEmbedBwdSeg& p = D->seg[0];
@@ -338,6 +335,15 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
   CARCA_CHECK_ARG(nf >= 1 || D->only_joint, "embed_bwd: every segment is joint_only");
   wj.nseg = nj;
   gz.nseg = wf.nseg = nf;
+  wf.ld_dy = ldz; wf.ld_x = D->n_attrs; wf.ld_x1 = D->n_ctx; wf.N = g; wf.K = D->n_attrs; wf.K1 = D->n_ctx;
+  wf.dw = D->g_feats_w; wf.ldw = D->n_attrs + D->n_ctx; wf.db = D->g_feats_b;
+  // (rows of pad items: their d q is zero already -- d [z ; q] below is masked -- but SAYING so lets the weight-gradient
+  // kernel leave them out of its row table instead of multiplying zeros: 47 % of a C2 training batch's rows)
+  wf.mask_rows = 1;
+  // the d feats_embed kernel's row table on its own stream, beside everything this call launches in front of that kernel
+  // -- only when that kernel WILL be launched (an unused fork is an empty branch of a capture)
+  if (D->table_stream && !D->only_joint && nf >= 1 && carca_wgrad_cu_suited(&wf))
+    if ((rc = carca_wgrad_table_fork((hipStream_t)stream, (hipStream_t)D->table_stream))) return rc;
   if (nj) {
     wj.ld_dy = D->ld_de; wj.ld_x = ldz; wj.N = d; wj.K = ldz; wj.dw = D->g_joint_w; wj.ldw = ldz; wj.db = D->g_joint_b;
     wj.mask_rows = 1;
@@ -349,11 +355,6 @@ extern "C" int carca_embed_bwd(const CarcaEmbedBwdDesc* D, void* stream) {
   if ((rc = carca_gemm_rows(&gz, stream))) return rc;
   // nn.Embedding(padding_idx = 0): z = E[ids] * sqrt(d); every segment in one launch
   if ((rc = carca_embed_scatter_segs(dzq, ldz, sids, srows, nf, d, (float)sqrt((double)d), D->g_items, stream))) return rc;
-  wf.ld_dy = ldz; wf.ld_x = D->n_attrs; wf.ld_x1 = D->n_ctx; wf.N = g; wf.K = D->n_attrs; wf.K1 = D->n_ctx;
-  wf.dw = D->g_feats_w; wf.ldw = D->n_attrs + D->n_ctx; wf.db = D->g_feats_b;
-  // (rows of pad items: their d q is zero already -- d [z ; q] above is masked -- but SAYING so lets the weight-gradient
-  // kernel leave them out of its row table instead of multiplying zeros: 47 % of a C2 training batch's rows)
-  wf.mask_rows = 1;
   if (D->ev_early) {
     // While the stream is being captured the record must become an EXTERNAL event-record node of the graph: every replay
     // then records the caller's event when it gets here, and a stream outside the graph -- the one that all-reduces the

@@ -260,7 +260,9 @@ int carca_embed_joint_ztab(const CarcaRowSeg* segs, int nseg, int d, int g, cons
                            const float* pos, const float* zq, int ld_e, const float* z_table, int ld_z_table, void* stream);
 // the persistent weight-gradient kernel's row table on a second stream, forked at the caller's entry (wgrad_cu.hip)
 int carca_wgrad_table_fork(hipStream_t stream, hipStream_t table_stream);
-int carca_wgrad_table_join(hipStream_t stream);
+int carca_wgrad_table_join(hipStream_t stream, bool used = false);
+struct CarcaWgradDesc;
+bool carca_wgrad_cu_suited(const CarcaWgradDesc* desc);
 // carca_embed_scatter over several row segments in one launch (backward.hip)
 int carca_embed_scatter_segs(const float* const* dz, int ld_dz, const int32_t* const* ids, const int* rows, int nseg,
                              int d, float scale, float* d_items, void* stream);

@@ -1009,6 +1009,7 @@ __global__ __launch_bounds__(768) void gemm_rows_sk_kernel(const GemmDev args) {
 constexpr int SKC_RB = 8;       // row blocks one workgroup's stretch may touch (the launcher checks rows against it)
 constexpr int SKC_CH = 1536;    // 64-row chunks of all segments (+ one entry per segment)
 constexpr int SKC_LDS_IDS = 2 * 384 * 36;  // ids the prologue keeps in LDS (the A buffers' space: 27,648)
+constexpr int SKC_MIN_STEPS = 64;  // K steps of k-source 0 below which the product stays on the one-tile-per-workgroup kernels
 constexpr int SKC_OV_MAX = 12;  // bound on the row-block ownership cost in K steps (a stretch holds at least 16 steps)
 // defaults (tuning keys 17 / 18 = value + 1).  MEASURED, round 5, interleaved A/B at C2 (tools/ab_eval.py): ownership cost 0 / 4
 // / 8 steps -> feature GEMM 468.1 / 470.4 / 475.6 us: although the workgroups that own a row block END ~20 us after those
@@ -1547,10 +1548,13 @@ __global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) 
   // are 2 kh and 2 kh + 1
   const float* a_frag = &As[ln * LS + 32 * kh + 4 * mq];
   const float* b_frag = &Bs[(16 * ct + ln) * LS + 32 * kh + 4 * mq];
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int kleft) {  // kleft: columns of K0 from this stage's first one on (>= 64: a full stage)
     // (reading all twelve fragments of the stage ahead of its 40 MFMAs measured 1 us SLOWER than chunk by chunk)
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
+      // (the ragged last stage: a 16-wide chunk that starts past K0 is all zeros in both operands -- K0 = 450 ends two
+      // columns into its eighth stage, K0 = 540 twenty-eight into its ninth: the wave-uniform test skips 20 MFMAs a chunk)
+      if (32 * kh + 16 * ch >= kleft) continue;
       const f32x4 b = *reinterpret_cast<const f32x4*>(b_frag + buf * B_BUF + 16 * ch);
       f32x4 a[5];
 #pragma unroll
@@ -1572,7 +1576,7 @@ __global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) 
   if (st + (o) < nst) {                                                    \
     if (st + (o) + 1 < nst) store_stage(st + (o) + 1, R1, B1);             \
     if (st + (o) + 3 < nst && !(diag & 1)) load_stage(st + (o) + 3, R3);   \
-    if (!(diag & 2)) compute(B0);                                          \
+    if (!(diag & 2)) compute(B0, D.K0 - (st + (o)) * BK);                  \
     __syncthreads();                                                       \
   }
   for (int st = (diag & 16) ? nst : 0; st < nst; st += 6) {
@@ -2113,7 +2117,8 @@ static int launch_gemm_rows_skc(const CarcaGemmDesc* desc, hipStream_t stream, c
   const int nfast = desc->K0 / 32;
   const int ncu = carca_num_cus();
   // (worth a persistent grid: at least most of a round of tiles if every row counted, and K long enough to share)
-  if (nfast < 64 || ((rows + 383) / 384) * ncb < ncu / 2 || ncu > 1024) return 1;
+  const int min_fast = carca_tuning(19) > 0 ? carca_tuning(19) : SKC_MIN_STEPS;  // (tuning key 19: the bound, A/B)
+  if (nfast < min_fast || ((rows + 383) / 384) * ncb < ncu / 2 || ncu > 1024) return 1;
   // (what the kernel's LDS lists hold: 64-row chunks of all segments, and SKC_RB row blocks per workgroup's stretch)
   {
     // a stretch of S row blocks touches at most ceil(S) + 1 of them; the longer stretches are the lone workgroups' (the

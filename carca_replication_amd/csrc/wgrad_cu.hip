@@ -579,10 +579,15 @@ int carca_wgrad_table_fork(hipStream_t stream, hipStream_t table_stream) {
   f.open = true;
   return CARCA_OK;
 }
-int carca_wgrad_table_join(hipStream_t stream) {
+namespace {
+__global__ void table_fork_noop_kernel() {}
+}  // namespace
+int carca_wgrad_table_join(hipStream_t stream, bool used) {
   TableFork& f = g_fork;
   if (!f.open) return CARCA_OK;
   f.open = false;
+  // (a fork nothing was launched on: give the branch a node before it is joined -- see carca_wgrad_cu_suited)
+  if (!used) hipLaunchKernelGGL(table_fork_noop_kernel, dim3(1), dim3(64), 0, f.ts);
   if (hipEventRecord(f.eb, f.ts) != hipSuccess || hipStreamWaitEvent(stream, f.eb, 0) != hipSuccess) {
     carca_set_error("wgrad_table_join: cannot join the row-table stream: %s", hipGetErrorString(hipGetLastError()));
     return CARCA_ERR_BADARG;
@@ -591,7 +596,16 @@ int carca_wgrad_table_join(hipStream_t stream) {
 }
 
 // CARCA_OK: launched.  1: shape not suited / operands too large for 31-bit offsets -> caller uses the tiled kernel.
-int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
+static int wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream, bool dry);
+int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) { return wgrad_cu_try(desc, stream, false); }
+// would carca_gemm_wgrad send this product to the persistent kernel?  (no launch, no allocation: carca_embed_bwd asks
+// before it forks a stream for the row table -- a fork that nothing is launched on is an EMPTY branch of a capture, and
+// hipStreamEndCapture of this runtime crashes on one)
+bool carca_wgrad_cu_suited(const CarcaWgradDesc* desc) {
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
+  return variant != 4 && variant != 5 && wgrad_cu_try(desc, nullptr, true) == CARCA_OK;
+}
+static int wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream, bool dry) {
   WgradCuDev g{};
   g.d = *desc;
   int chunks = 0;
@@ -652,6 +666,7 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   g.gpx = per_xcd / g.nnb;
   g.ngroups = g.nxcd * g.gpx + (g.nxcd * (per_xcd - g.gpx * g.nnb)) / g.nnb;
   if (g.ngroups < 1) return 1;  // (more n blocks than CUs: the tile kernel)
+  if (dry) return CARCA_OK;
   // (g.ngroups stays the number of groups the chip can HOST; how many of them get units, and which, is the row-table
   // kernel's decision once it has counted the rows that take part: WgPlan)
   g.slow_w = carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 13 ? 256 : 264;  // (variant 13: equal item counts -- A/B switch)
@@ -684,7 +699,7 @@ int carca_wgrad_cu_try(const CarcaWgradDesc* desc, hipStream_t stream) {
   }
   if (g_fork.open) {  // (the caller forked a stream for the table at its entry: see carca_wgrad_table_fork)
     hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3(1), dim3(1024), 0, g_fork.ts, g, tab);
-    if (int rc = carca_wgrad_table_join(stream)) return rc;
+    if (int rc = carca_wgrad_table_join(stream, true)) return rc;
   } else {
     hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3(1), dim3(1024), 0, stream, g, tab);
   }

@@ -1076,7 +1076,7 @@ class CARCA(_PackedModule, Model):
             return False
         return True
 
-    def _forward_fused(self, profile, targets, events=None, train: Optional[dict] = None) -> List[Tensor]:
+    def _forward_fused(self, profile, targets, events=None, train: Optional[dict] = None, after_pack=None) -> List[Tensor]:
         """One host call for the whole forward (carca_forward).  train: None = inference (workspaces cached per shape);
         a dict = the TRAINING forward: fresh buffers, the backward's saved tensors and the dropout sites, all handed back
         through that dict (the keys autograd._CarcaFn keeps in its state)."""
@@ -1166,6 +1166,8 @@ class CARCA(_PackedModule, Model):
             D.sa_residual[i] = int(bool(blk.residual))
         D.ca = dec.weights_struct(dev, self.norm, repack)
         ops.pack_many(repack)
+        if after_pack is not None:  # (the training forward: a point BEHIND its first launch, ahead of everything else --
+            after_pack()            # where autograd forks the backward's fill + pack onto a second stream)
         D.ca_residual, D.training = int(bool(dec.residual)), int(bool(self.training))
         # the groups' scores are written as column blocks of ONE [B, sum N] tensor: what carca.py:431's torch.cat builds,
         # without the copy (and without the split / re-gather of its gradient in the backward pass)

@@ -411,3 +411,39 @@ def test_the_compacting_kernel_with_four_segments(tuning, rows):
         scale = float(y[:, :N].abs().max())
         assert float((x[:, :N] - y[:, :N]).abs().max()) <= 4e-6 * scale
     _check_against_fp64(got, _fp64_product(segs, ids_all, w, b, N), ids_all, N)
+
+
+@pytest.mark.parametrize("N", [450, 256])
+def test_the_compacting_kernel_on_a_short_k(tuning, N):
+    """K0 = 512 (16 K steps: BASELINE's C5 / the CLI's default n_attrs) through gemm_rows_skc_kernel -- admitted below its
+    default bound of 64 steps by tuning key 19: stretches of about one row block, every piece a few steps long.  N = 256 is
+    the CLI's g (a narrow block of exactly two MFMA column tiles, teams of two)."""
+    from carca_replication_amd import ops
+
+    K0, K1 = 512, 6
+    g = torch.Generator(device="cuda").manual_seed(13)
+    w = (torch.rand(N, K0 + K1, device="cuda", generator=g) * 2 - 1) * 0.05
+    b = torch.randn(N, device="cuda", generator=g) * 0.01
+    segs, ids_all = [], []
+    for r in (12800, 25856):
+        ids = torch.randint(1, 1000, (r,), device="cuda", dtype=torch.int32, generator=g)
+        if r == 12800:
+            t = torch.arange(r, device="cuda") % 50
+            ids[t < torch.randint(0, 48, (r // 50,), device="cuda", generator=g).repeat_interleave(50)] = 0
+        segs.append(dict(a0=torch.rand(r, K0, device="cuda", generator=g), a1=torch.rand(r, K1, device="cuda", generator=g), ids=ids))
+        ids_all.append(ids)
+    ld = (N + 3) // 4 * 4
+
+    def run():
+        return ops.gemm_rows(segs, w[:, :K0], N, K0, ld, bt1=w[:, K0:], K1=K1, bias=b, mask_rows=True, ncols_out=N)
+
+    tuning(19, 16)
+    ops.gemm_rows_log(True)
+    got = run()
+    log = ops.gemm_rows_log()
+    ops.gemm_rows_log(False)
+    tuning(19, 0)
+    assert "gemm_rows_skc_kernel" in log
+    torch.cuda.synchronize()
+    ops.poll_errors()
+    _check_against_fp64(got, _fp64_product(segs, ids_all, w, b, N), ids_all, N)

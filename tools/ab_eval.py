@@ -17,8 +17,9 @@ from tests.model_util import build_model  # noqa: E402
 B = int(os.environ.get("B", 128))
 N = int(os.environ.get("N", 101))
 NA = int(os.environ.get("NA", 4096))
+D_, G_, H_, NB_ = (int(os.environ.get(k, v)) for k, v in (("D", 90), ("G", 450), ("H", 3), ("NB", 2)))  # other shapes: B N NA D G H NB
 torch.manual_seed(0)
-model = build_model(dict(d=90, H=3, n_blocks=2), 12102, 450, 6, NA, 50).cuda().eval()
+model = build_model(dict(d=D_, H=H_, n_blocks=NB_), 12102, G_, 6, NA, 50).cuda().eval()
 profile, target, _ = synth_eval_batch(B, 50, N, 12102, NA, 6, seed=1)
 profile, target = tuple(t.cuda() for t in profile), tuple(t.cuda() for t in target)
 settings = sys.argv[1:] or [""]
