@@ -177,6 +177,22 @@ SPLIT_TAIL_MAIN_CUS = 128  # CU budget of the first stream's big kernel under SP
 SPLIT_TAIL_MAIN_TARGET_USERS = 0.35  # ... and the share of the first target segment's users it takes (SPLIT_MAIN_TARGET_USERS' role)
 _SIDE_STREAMS = {}
 _TABLE_STREAMS = {}
+import os as _os0  # (A/B switches of the captured schedule from the environment: CARCA_SPLIT_TAIL / CARCA_SPLIT_TABLE = 0 | 1)
+
+SPLIT_TAIL_ON_SIDE = {"0": False, "1": True}.get(_os0.environ.get("CARCA_SPLIT_TAIL", ""), SPLIT_TAIL_ON_SIDE)
+SPLIT_TABLE_STREAM = {"0": False, "1": True}.get(_os0.environ.get("CARCA_SPLIT_TABLE", ""), SPLIT_TABLE_STREAM)
+
+
+def ensure_side_streams(device) -> None:
+    """The second / third stream of the captured schedule, created OUTSIDE a capture (engine.GraphedTrainStep calls this before
+    it captures).  Creating them lazily worked while the first use sat in the backward; with the prep fork in the FORWARD a
+    stream created by the capturing thread inside the capture crashed hipStreamEndCapture on this runtime (segfault; the same
+    schedule with the streams created by an eager warm-up step passes)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    if key not in _TABLE_STREAMS:
+        _TABLE_STREAMS[key] = torch.cuda.Stream(device=device)
 
 
 class _SideEmbed:
@@ -833,7 +849,7 @@ class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, a, c, target, *params):
         d = module.d
-        dpi, _, _ = ops.padded_dims(d, 1)
+        dpi = ops.row_ld(d)
         seg = (x, a, c, bool(target))
         (e,), saved = module.embed_segments([seg], ld_e=dpi)
         ctx.module, ctx.params, ctx.seg, ctx.saved, ctx.dpi = module, params, seg, saved, dpi

@@ -204,14 +204,81 @@ __global__ void embed_scatter_segs_kernel(ScatterSegs S, int ld_dz, int d, float
   }
 }
 
+// LayerNorm backward for rows wider than 128 features (d <= 1024; the composed path of long_profile.py): one wave per row,
+// a lane holds columns lane + 64 j; gamma / beta gradients are summed per wave over its rows and added once per column.
+#define LNB_WIDE_MAX 16
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __restrict__ dy, int ld_dy,
+                                                                 const float* __restrict__ x, int ld_x,
+                                                                 const float* __restrict__ gamma, int rows, int d,
+                                                                 const float* __restrict__ addend, int ld_add,
+                                                                 float* __restrict__ dx, int ld_dx, int ncols_out,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_d = 1.0f / (float)d;
+  float dg[LNB_WIDE_MAX], db[LNB_WIDE_MAX], gm[LNB_WIDE_MAX];
+#pragma unroll
+  for (int j = 0; j < LNB_WIDE_MAX; ++j) {
+    dg[j] = db[j] = 0.f;
+    gm[j] = lane + 64 * j < d ? gamma[lane + 64 * j] : 0.f;
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * ld_x;
+    const float* dr = dy + (size_t)row * ld_dy;
+    float xv[LNB_WIDE_MAX], yv[LNB_WIDE_MAX];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNB_WIDE_MAX; ++j) {
+      const int c = lane + 64 * j;
+      xv[j] = c < d ? xr[c] : 0.f;
+      yv[j] = c < d ? dr[c] : 0.f;
+      s += xv[j];
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNB_WIDE_MAX; ++j) {
+      xv[j] = lane + 64 * j < d ? xv[j] - mean : 0.f;
+      q += xv[j] * xv[j];
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNB_WIDE_MAX; ++j) {
+      xv[j] *= rstd;  // x hat
+      const float a = yv[j] * gm[j];
+      s1 += a;
+      s2 += a * xv[j];
+    }
+    const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+    float* outr = dx + (size_t)row * ld_dx;
+    const float* ar = addend ? addend + (size_t)row * ld_add : nullptr;
+#pragma unroll
+    for (int j = 0; j < LNB_WIDE_MAX; ++j) {
+      const int c = lane + 64 * j;
+      if (c < ncols_out) outr[c] = c < d ? rstd * (yv[j] * gm[j] - m1 - xv[j] * m2) + (ar ? ar[c] : 0.f) : 0.f;
+      dg[j] += yv[j] * xv[j];
+      db[j] += yv[j];
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int j = 0; j < LNB_WIDE_MAX; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d) {
+        grad_add(&dgamma[c], dg[j]);
+        grad_add(&dbeta[c], db[j]);
+      }
+    }
+  }
+}
+
 // out[(row % T)][c] += sum over this block's rows of  w(row) * x[row][c],  w = rowscale * (ids != 0)
 // grid.x blocks of 256 threads; thread = column (cols <= 256), rows strided by block
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld_x, int rows, int cols,
                                                      const float* __restrict__ rowscale,
                                                      const int32_t* __restrict__ ids, int T,
                                                      float* __restrict__ out) {
-  const int c = threadIdx.x;
-  if (c >= cols) return;
+  for (int c = threadIdx.x; c < cols; c += 256) {  // (one pass for cols <= 256: every row GEMM-sized caller; wider rows loop)
   if (T == 1) {
     float s = 0.f;
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -230,6 +297,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
       s += w * x[(size_t)row * ld_x + c];
     }
     grad_add(&out[(size_t)t * cols + c], s);
+  }
   }
 }
 
@@ -767,9 +835,17 @@ extern "C" int carca_layernorm_bwd(const float* dy, int ld_dy, const float* x, i
                                    float* dgamma, float* dbeta, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(dy && x && gamma && dx && rows >= 1 && d >= 1, "layernorm_bwd: null pointer or bad dims");
-  CARCA_CHECK_SUPPORTED(d <= 128, "layernorm_bwd: d=%d > 128", d);
+  CARCA_CHECK_SUPPORTED(d <= 64 * LNB_WIDE_MAX && ncols_out <= 64 * LNB_WIDE_MAX, "layernorm_bwd: d=%d / ncols_out=%d > %d", d,
+                        ncols_out, 64 * LNB_WIDE_MAX);
   CARCA_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
-  CARCA_CHECK_ARG(ncols_out <= ld_dx && ncols_out <= 128 && ld_dy >= d && ld_x >= d, "layernorm_bwd: bad strides");
+  CARCA_CHECK_ARG(ncols_out <= ld_dx && ld_dy >= d && ld_x >= d && (!addend || ld_add >= d), "layernorm_bwd: bad strides");
+  if (d > 128 || ncols_out > 128) {  // (rows beyond the fused kernels' width: long_profile.py's composed path)
+    const int blocks = min((rows + 15) / 16, 256);
+    hipLaunchKernelGGL(layernorm_bwd_wide_kernel, dim3(blocks), dim3(256), 0, stream, dy, ld_dy, x, ld_x, gamma, rows, d,
+                       addend, ld_add, dx, ld_dx, ncols_out, dgamma, dbeta);
+    CARCA_LAUNCH_CHECK();
+    return CARCA_OK;
+  }
   // padded internal buffers (every stride a multiple of 4 floats, width <= the strides): the row-pair kernel, one block
   // per CU, four pairs in flight per wave
   const bool vec = ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && (!addend || ld_add % 4 == 0) &&
@@ -850,7 +926,6 @@ extern "C" int carca_colsum(const float* x, int ld_x, int rows, int cols, const 
                             int T, float* out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   CARCA_CHECK_ARG(x && out && rows >= 1 && cols >= 1 && ld_x >= cols && T >= 1, "colsum: bad arguments");
-  CARCA_CHECK_SUPPORTED(cols <= 256, "colsum: cols=%d > 256", cols);
   const int blocks = T == 1 ? min(rows, 512) : T;
   hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, stream, x, ld_x, rows, cols, rowscale, ids, T, out);
   CARCA_LAUNCH_CHECK();

@@ -25,6 +25,43 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// The same LayerNorm for rows WIDER than 128 features (d <= 1024: the composed path of long_profile.py takes any d the
+// reference takes -- its only constraint is d % H == 0, carca.py:208; the fused per-user kernels stop at 128).  One wave per
+// row, a lane holds columns lane + 64 j.
+#define LN_WIDE_MAX 16  // 64-column groups per row
+__global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                                 int ldy, int rows, int d, const float* __restrict__ w,
+                                                                 const float* __restrict__ b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_d = 1.0f / (float)d;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * ldx;
+    float v[LN_WIDE_MAX];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_WIDE_MAX; ++j) {
+      const int c = lane + 64 * j;
+      v[j] = c < d ? xr[c] : 0.f;
+      s += v[j];
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_WIDE_MAX; ++j) {
+      const int c = lane + 64 * j;
+      v[j] = c < d ? v[j] - mean : 0.f;
+      q += v[j] * v[j];
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+    float* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int j = 0; j < LN_WIDE_MAX; ++j) {
+      const int c = lane + 64 * j;
+      if (c < ldy) yr[c] = c < d ? v[j] * rstd * w[c] + b[c] : 0.f;
+    }
+  }
+}
+
 // y[b][t] = link(p_row . o[b][t]); p_row = p[b][t] (slotwise, T == L) or p[b][L-1]
 __global__ __launch_bounds__(256) void dot_score_fwd_kernel(const float* __restrict__ p, int ldp,
                                                             const float* __restrict__ o, int ldo,
@@ -357,9 +394,13 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restri
 extern "C" int carca_layernorm_fwd(const float* x, int ldx, float* y, int ldy, int rows, int d, const float* w,
                                    const float* b, void* stream_) {
   CARCA_CHECK_ARG(x && y && w && b && rows >= 1 && d >= 1 && ldx >= d && ldy >= d, "layernorm_fwd: bad arguments");
-  CARCA_CHECK_SUPPORTED(d <= 128 && ldy <= 128, "layernorm_fwd: d=%d / ldy=%d > 128", d, ldy);
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream_, x, ldx, y, ldy,
-                     rows, d, w, b);
+  CARCA_CHECK_SUPPORTED(d <= 64 * LN_WIDE_MAX && ldy <= 64 * LN_WIDE_MAX, "layernorm_fwd: d=%d / ldy=%d > %d", d, ldy, 64 * LN_WIDE_MAX);
+  if (d > 128 || ldy > 128)
+    hipLaunchKernelGGL(layernorm_fwd_wide_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream_, x, ldx, y, ldy,
+                       rows, d, w, b);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream_, x, ldx, y, ldy,
+                       rows, d, w, b);
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }

@@ -219,6 +219,10 @@ class GraphedTrainStep:
         ops.set_dropout_seed_offset(self.replays)
         ops.early_event = self.ev_early
         try:
+            if self.inputs[0].is_cuda:  # (the captured backward's side streams must exist before the capture begins)
+                from . import autograd
+
+                autograd.ensure_side_streams(self.inputs[0].device)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):  # lazily built state (code objects, workspaces, descriptor rings) first

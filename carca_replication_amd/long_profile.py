@@ -1,5 +1,5 @@
-"""Profiles LONGER than the fused per-user kernels hold (L > 64 slots): CARCA.forward composed from the library's
-row-level kernels, differentiable through torch.autograd.
+"""Profiles LONGER than the fused per-user kernels hold (L > 64 slots), models WIDER than they hold (d > 128), more than three
+target groups: CARCA.forward composed from the library's row-level kernels, differentiable through torch.autograd.
 
 The fused attention kernels (sa_eval / sa_block / cross_stream / cross_score and their backward kernels) keep one user's
 whole profile -- keys, values, the block's activations -- in one workgroup's LDS: 64 slots at d <= 128.  The reference
@@ -94,7 +94,7 @@ class _EmbedSegsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, segs, *params):
         d = module.d
-        dpi, _, _ = ops.padded_dims(d, 1)
+        dpi = ops.row_ld(d)
         es, saved = module.embed_segments(segs, ld_e=dpi)
         ctx.module, ctx.params, ctx.segs, ctx.saved, ctx.dpi = module, params, segs, saved, dpi
         return tuple(e[..., :d] for e in es)
@@ -226,7 +226,7 @@ def forward(model, profile, targets, trace: Optional[dict] = None) -> List[Tenso
         if grad:
             es += list(_EmbedSegsFn.apply(emb, chunk, *cached_parameters(emb)))
         else:
-            dpi, _, _ = ops.padded_dims(d, 1)
+            dpi = ops.row_ld(d)
             es += [e[..., :d] for e in emb.embed_segments(chunk, ld_e=dpi)[0]]
     x = es[0]
     if trace is not None:

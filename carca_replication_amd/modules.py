@@ -887,7 +887,7 @@ class SelfAttentionBlock(_PackedModule, Encoder):
     def forward(self, x: Tensor, mask: Tensor) -> Tensor:
         """x [B, L, >=d], mask [B, L] (0 = pad) -> [B, L, d] (a view of a padded buffer)."""
         self._check_mode()
-        if x.shape[1] > _lib.MAX_L:
+        if x.shape[1] > _lib.MAX_L or self.attn.d > ops.FUSED_MAX_D:
             from . import long_profile
 
             return long_profile.sa_block(self, x[..., : self.attn.d], mask != 0, ops.new_dropout_seed() if self.training else 0)
@@ -959,7 +959,7 @@ class CrossAttentionBlock(_PackedModule, Decoder):
     def forward(self, o: Tensor, o_mask: Tensor, p: Tensor, p_mask: Tensor) -> Tensor:
         """Standalone decoder call: p is already final-normed (as in carca.py:421-428)."""
         self._check_mode()
-        if p.shape[1] > _lib.MAX_L:
+        if p.shape[1] > _lib.MAX_L or self.attn.d > ops.FUSED_MAX_D:
             from . import long_profile
 
             d = self.attn.d
@@ -1033,7 +1033,7 @@ class CARCA(_PackedModule, Model):
     def forward(self, profile: Tuple[Tensor, Tensor, Tensor], targets: List[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
         self._check_built()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in cached_parameters(self))
-        if profile[0].shape[1] > _lib.MAX_L or len(targets) > _lib.MAX_GROUPS:
+        if profile[0].shape[1] > _lib.MAX_L or len(targets) > _lib.MAX_GROUPS or self.embeds.d > ops.FUSED_MAX_D:
             # longer than the fused kernels' 64 profile slots (or more target groups than one fused call takes, carca.py:424):
             # the same arithmetic from the row-level kernels
             from . import long_profile
@@ -1228,7 +1228,7 @@ class CARCA(_PackedModule, Model):
 
     def forward_nograd(self, profile, targets, trace: Optional[dict] = None) -> List[Tensor]:
         p_x, p_a, p_c = profile
-        if p_x.shape[1] > _lib.MAX_L or len(targets) > _lib.MAX_GROUPS:
+        if p_x.shape[1] > _lib.MAX_L or len(targets) > _lib.MAX_GROUPS or self.embeds.d > ops.FUSED_MAX_D:
             from . import long_profile
 
             return long_profile.forward(self, profile, targets, trace)

@@ -112,6 +112,15 @@ def padded_dims(d: int, H: int) -> Tuple[int, int, int]:
     return a.value, b.value, c.value
 
 
+FUSED_MAX_D = 128  # the per-user kernels keep rows of at most this many floats (carca_padded_dims); wider models run composed
+
+
+def row_ld(d: int) -> int:
+    """Row stride of the [rows, ld] activations between kernels: the fused kernels' padded width up to FUSED_MAX_D, the
+    next multiple of four floats beyond (long_profile.py's composed path takes any d the reference takes)."""
+    return padded_dims(d, 1)[0] if d <= FUSED_MAX_D else (d + 3) // 4 * 4
+
+
 # --------------------------------------------------------------------------------------------------
 # dropout plumbing
 # --------------------------------------------------------------------------------------------------

@@ -326,7 +326,8 @@ def test_two_stream_embedding_backward_agrees_with_the_single_stream_pass(n_grou
 
 
 @pytest.mark.parametrize("rows,d,ld,out_ld", [(6400, 90, 96, 96), (6401, 128, 128, 128), (333, 50, 64, 64),
-                                              (77, 6, 8, 8), (129, 90, 91, 96), (64, 128, 256, 128)])
+                                              (77, 6, 8, 8), (129, 90, 91, 96), (64, 128, 256, 128),
+                                              (130, 192, 192, 192), (77, 300, 301, 304), (9, 1024, 1024, 1024)])
 def test_layernorm_backward_kernels_against_torch(rows, d, ld, out_ld):
     """Both LayerNorm-backward kernels (16-byte row pairs for the padded internal strides, one row per wave otherwise)
     against torch.autograd of nn.LayerNorm (carca.py:421 / 440, eps 1e-5), with the fused addend and pad columns."""
