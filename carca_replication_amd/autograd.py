@@ -167,12 +167,19 @@ SPLIT_MAIN_TARGET_USERS = 0.25  # share of the FIRST target segment's users left
                                 # -> 1.215 / 1.196 / 1.188 / 1.185 / 1.203 / 1.207 ms per graphed step; round 3: 0 / 0.04 / 0.08
                                 # -> 1.654 / 1.642 / 1.655)
 SPLIT_MIN_GFLOP = 20.0     # the split pays when d feats_embed is long against the launches it doubles (C2: 71 GFLOP per pass)
-SPLIT_TAIL_ON_SIDE = True  # round 5: the weight gradients that feed nothing -- the grouped d x d products of the decoder and the
+SPLIT_TAIL_ON_SIDE = False  # round 5 (MEASURED AND OFF, see below): the weight gradients that feed nothing -- the grouped d x d products of the decoder and the
                            # blocks, d joint_embed -- leave the FIRST stream's chain: they are issued on the second stream behind
                            # its big kernel (which ends first), gated by an event behind the encoder's backward; the first
                            # stream goes from the chain straight into its own rows' embedding backward.  False: round 4's order
-SPLIT_TABLE_STREAM = True  # ... and each stream's row table (wgrad_rowtab_kernel: a function of the ids) is built on a third
-                           # stream beside that stream's d [z ; q] / scatter launches instead of between them and the big kernel
+SPLIT_TABLE_STREAM = False  # ... and each stream's row table (wgrad_rowtab_kernel: a function of the ids) built on a third
+                            # stream beside that stream's d [z ; q] / scatter launches instead of between them and the big kernel.
+                            # OFF: with it the C2-sized capture segfaults in hipStreamEndCapture on this runtime (ROCm 7.2; the
+                            # fixture-sized one passes) -- the fork is NESTED, a third stream forked off the second one
+# Interleaved A/B of the graphed C2 step (tools/ab_train_graph.py, round 5): round 4's order 1.1929 ms; tail on the second stream
+# with the first stream's big kernel on 128 CUs and 0.35 / 0.5 / 0.15 of the first target segment's users: 1.1977 / 1.1989 /
+# 1.2109; on 192 CUs: 1.2286; on 256: 1.2193-1.2276.  Two big kernels held to half a chip each for their whole length lose more
+# (the one that ends first leaves its half idle) than the ~110 us of small products gain by leaving the first stream's chain:
+# round 4's order -- second stream's kernel on 128 CUs beside the chain, the first stream's LAST kernel on all 256 -- stays.
 SPLIT_TAIL_MAIN_CUS = 128  # CU budget of the first stream's big kernel under SPLIT_TAIL_ON_SIDE
 SPLIT_TAIL_MAIN_TARGET_USERS = 0.35  # ... and the share of the first target segment's users it takes (SPLIT_MAIN_TARGET_USERS' role)
 _SIDE_STREAMS = {}
@@ -348,10 +355,15 @@ def _cross_decoder_backward(model, st, ys, dys, gbp, wg, cp, d_wpad):
 
 import os as _os
 
-EARLY_PREP = {"0": False, "1": True}.get(_os.environ.get("CARCA_EARLY_PREP", ""), "graph")  # the backward's zero fill (gradients + staging) and its pack launch (transposed weight copies) read nothing
+# MEASURED AND OFF (round 5): graphed C2 step 1.1912 ms with it, 1.1919 without -- the fill and the pack (14 us of kernels) were
+# not on the critical path for long enough to matter, and the fork is one more thing for a capture to go wrong on.
+EARLY_PREP = {"0": False, "1": True, "graph": "graph"}.get(_os.environ.get("CARCA_EARLY_PREP", ""), False)  # the backward's zero fill (gradients + staging) and its pack launch (transposed weight copies) read nothing
                       # the forward produces: "graph" = while a hipGraph is captured they are issued on the second stream at the
                       # START of the forward and joined in front of the backward's first kernel (14 us off the step's critical
                       # path); False = at the start of the backward, as eager steps always do
+
+
+GRAPH_WARMUP = [False]  # set by engine.GraphedTrainStep around its eager warm-up steps
 
 
 def _prepare_backward(model, params, st) -> dict:
@@ -434,7 +446,10 @@ class _CarcaFn(torch.autograd.Function):
             dec._check_mode()
             # EARLY_PREP: what the backward sets up before its first kernel depends on the weights and the ids alone
             early_box: list = []
-            want_early = torch.cuda.is_current_stream_capturing() if EARLY_PREP == "graph" else bool(EARLY_PREP)
+            # ("graph": inside the capture AND in the eager warm-up steps GraphedTrainStep runs right before it -- the first
+            # pass through this fork must not be the captured one: taken for the first time inside a capture it crashed
+            # hipStreamEndCapture on this runtime, taken once eagerly before it the same capture passes)
+            want_early = (GRAPH_WARMUP[0] or torch.cuda.is_current_stream_capturing()) if EARLY_PREP == "graph" else bool(EARLY_PREP)
 
             def fork_prep():
                 # (forked BEHIND the forward's first launch -- its pack kernel --, not at the very start of a capture: a

@@ -640,20 +640,24 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
   const int nt0 = (D.K0 + BK - 1) / BK, nt1 = (D.K1 + BK - 1) / BK;
   const int ntiles = nt0 + nt1;
 
-  size_t aoff0[A_PER], aoff1[A_PER];
+  // element offset of staging slot i's row inside k-source 0 / 1 (recomputed where the tail tiles need it: kept in registers
+  // across the K loop -- sixteen VGPRs of 64-bit offsets -- they were what the 168-register kernel spilled)
+  auto a_off = [&](int i, bool src1) -> size_t {
+    const int slot = tid + i * NT, r = slot / C4;
+    int gr = min(row0 + r, nrows - 1);
+    if constexpr (IDX) gr = dyn.rows[gr];
+    const int ub = gr / sg.T, ut = gr - ub * sg.T;
+    if (src1) return sg.a1_bstride ? (size_t)ub * sg.a1_bstride + (size_t)ut * D.lda1 : (size_t)gr * D.lda1;
+    return sg.a0_gather ? (size_t)sg.ids[gr] * D.lda0
+           : sg.a0_bstride ? (size_t)ub * sg.a0_bstride + (size_t)ut * D.lda0
+                           : (size_t)gr * D.lda0;
+  };
   unsigned a_byte[A_PER];
   int a_lds[A_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int slot = tid + i * NT, r = slot / C4, c4 = slot - r * C4;
-    int gr = min(row0 + r, nrows - 1);
-    if constexpr (IDX) gr = dyn.rows[gr];
-    const int ub = gr / sg.T, ut = gr - ub * sg.T;
-    aoff0[i] = sg.a0_gather ? (size_t)sg.ids[gr] * D.lda0
-               : sg.a0_bstride ? (size_t)ub * sg.a0_bstride + (size_t)ut * D.lda0
-                               : (size_t)gr * D.lda0;
-    aoff1[i] = sg.a1_bstride ? (size_t)ub * sg.a1_bstride + (size_t)ut * D.lda1 : (size_t)gr * D.lda1;
-    a_byte[i] = (unsigned)((aoff0[i] + c4 * 4) * sizeof(float));
+    a_byte[i] = (unsigned)((a_off(i, false) + c4 * 4) * sizeof(float));
     a_lds[i] = r * LS + c4 * 4;
   }
   const bool b_live = tid < BNS * C4;  // (threads past the B tile's slots load a clamped row and store into the dummy strip)
@@ -705,7 +709,7 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int c4 = (tid + i * NT) % C4;
-      ra[i] = load4(abase + (src1 ? aoff1[i] : aoff0[i]) + k0 + c4 * 4, full, k0 + c4 * 4, klen);
+      ra[i] = load4(abase + a_off(i, src1) + k0 + c4 * 4, full, k0 + c4 * 4, klen);
     }
     rbv = load4(bbase + (size_t)b_gn * ldb + k0 + b_c4 * 4, full, k0 + b_c4 * 4, klen);
   };

@@ -565,9 +565,13 @@ thread_local TableFork g_fork;
 int carca_wgrad_table_fork(hipStream_t stream, hipStream_t table_stream) {
   if (!table_stream || table_stream == stream) return CARCA_OK;
   TableFork& f = g_fork;
-  if (!f.ea && (hipEventCreateWithFlags(&f.ea, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&f.eb, hipEventDisableTiming) != hipSuccess)) {
+  // (a fresh pair of events per fork, destroyed at the join -- what torch's wait_stream does: an event object recorded a
+  // second time from another stream of the same capture is one more thing this runtime's capture has not been seen to survive)
+  f.ea = f.eb = nullptr;
+  if (hipEventCreateWithFlags(&f.ea, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&f.eb, hipEventDisableTiming) != hipSuccess) {
     (void)hipGetLastError();
+    if (f.ea) (void)hipEventDestroy(f.ea);
     f.ea = f.eb = nullptr;
     return CARCA_OK;  // (no events: no fork -- the table is built on `stream` as before)
   }
@@ -588,7 +592,11 @@ int carca_wgrad_table_join(hipStream_t stream, bool used) {
   f.open = false;
   // (a fork nothing was launched on: give the branch a node before it is joined -- see carca_wgrad_cu_suited)
   if (!used) hipLaunchKernelGGL(table_fork_noop_kernel, dim3(1), dim3(64), 0, f.ts);
-  if (hipEventRecord(f.eb, f.ts) != hipSuccess || hipStreamWaitEvent(stream, f.eb, 0) != hipSuccess) {
+  const bool ok = hipEventRecord(f.eb, f.ts) == hipSuccess && hipStreamWaitEvent(stream, f.eb, 0) == hipSuccess;
+  (void)hipEventDestroy(f.ea);
+  (void)hipEventDestroy(f.eb);
+  f.ea = f.eb = nullptr;
+  if (!ok) {
     carca_set_error("wgrad_table_join: cannot join the row-table stream: %s", hipGetErrorString(hipGetLastError()));
     return CARCA_ERR_BADARG;
   }

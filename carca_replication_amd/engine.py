@@ -226,8 +226,14 @@ class GraphedTrainStep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):  # lazily built state (code objects, workspaces, descriptor rings) first
-                for _ in range(warmup):
-                    _forward_backward(model, optim, self.inputs, self.denom)
+                from . import autograd as _ag
+
+                _ag.GRAPH_WARMUP[0] = True  # (the warm-up steps take the captured pass's prep fork: see autograd.EARLY_PREP)
+                try:
+                    for _ in range(warmup):
+                        _forward_backward(model, optim, self.inputs, self.denom)
+                finally:
+                    _ag.GRAPH_WARMUP[0] = False
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             self.scope = 0

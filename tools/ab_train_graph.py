@@ -30,7 +30,7 @@ for rnd in range(int(os.environ.get("ROUNDS", "4"))):
     for s in settings:
         autograd.SPLIT_EMBED_BWD, autograd.SPLIT_SIDE_CUS, autograd.SPLIT_MAIN_TARGET_USERS = "graph", 128, 0.25
         autograd.SPLIT_MAIN_CUS = 256
-        autograd.SPLIT_TAIL_ON_SIDE, autograd.SPLIT_TABLE_STREAM = True, True
+        autograd.SPLIT_TAIL_ON_SIDE, autograd.SPLIT_TABLE_STREAM = False, False
         autograd.SPLIT_TAIL_MAIN_CUS, autograd.SPLIT_TAIL_MAIN_TARGET_USERS = 128, 0.35
         for k in range(8):
             lib.carca_set_tuning(k, 0)
