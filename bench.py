@@ -466,6 +466,8 @@ def main():
     ap.add_argument("--no-table", action="store_true", help="skip the attribute-table (ids-only batch) measurement")
     ap.add_argument("--no-split", action="store_true", help="skip the opt-in split-precision feature GEMM measurement")
     ap.add_argument("--train-steps", type=int, default=24, help="extra, untimed-by-the-headline train-step measurement")
+    ap.add_argument("--no-full-profiles", action="store_true", help="skip the side pass with every profile at L = 50 (the PMC "
+                    "passes of tools/profile_round.sh: their per-launch averages must cover the headline batch only)")
     ap.add_argument("--no-scoring-scaling", action="store_true", help="skip the scoring kernel's B = 1024 / 4096 side pass")
     args = ap.parse_args()
 
@@ -601,7 +603,7 @@ def main():
                                         torch.cuda.synchronize, args.steps, args.warmup, 1, fl)
 
     full_info = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_full_profiles:
         full_info = measure_full_profiles(c, model, device, fence, args.steps, args.warmup, fl)
 
     # extension path: attribute table resident in HBM, ids-only batches, gather fused into the GEMM

@@ -241,11 +241,13 @@ def test_cpu_tensors_fail_loudly():
 def test_unsupported_shape_is_an_error_not_a_fallback():
     from carca_replication_amd import CarcaHipError
 
-    cfg = O.CarcaConfig(d=160, H=2, n_blocks=1)
-    P = O.init_params(cfg, 30, 16, 1, 4, 8, seed=0)
-    profile, target, _ = O.synth_eval_batch(2, 8, 4, 30, 4, 1, seed=2)
+    # (d > 128 runs the composed path since round 5: tests/test_hip_long_profile.py; what stays an error is a profile of more
+    # than 1024 slots -- carca_mha_core keeps a query's weights in registers)
+    cfg = O.CarcaConfig(d=32, H=2, n_blocks=1)
+    P = O.init_params(cfg, 1200, 16, 1, 4, 1030, seed=0)
+    profile, target, _ = O.synth_eval_batch(2, 1030, 4, 1200, 4, 1, seed=2)
     model = model_from_params(P, cfg).eval()
-    with pytest.raises(CarcaHipError):
+    with pytest.raises(CarcaHipError, match="1024"):
         with torch.no_grad():
             model(profile=dev(profile), targets=[dev(target)])
 
