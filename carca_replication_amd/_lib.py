@@ -18,7 +18,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libcarca_hip.so")
 _STAMP = LIB_PATH + ".srchash"
-SOURCES = ["api.hip", "gemm.hip", "gemm_split.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "sa_eval.hip", "cross_score.hip", "cross_stream.hip", "loss_metrics.hip", "backward.hip", "block_bwd.hip", "row_chain.hip", "optim.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_split.hip", "gemm_stream.hip", "wgrad_cu.hip", "decoders.hip", "batch_build.hip", "embed.hip", "sa_block.hip", "sa_eval.hip", "cross_score.hip", "cross_stream.hip", "loss_metrics.hip", "backward.hip", "block_bwd.hip", "row_chain.hip", "optim.hip"]
 HEADERS = ["carca_common.h", "attn_common.h", "gemm_epilogue.h", "cross_fold.h"]
 
 MAX_SEGS = 4

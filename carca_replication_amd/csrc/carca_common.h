@@ -247,6 +247,9 @@ struct CarcaGemmDesc;
 void carca_rows_log(const char* kernel, const CarcaGemmDesc* d, int grid);
 // the opt-in split-precision feature GEMM (gemm_split.hip, tuning key 16): CARCA_OK = launched, 1 = not its product
 int carca_gemm_rows_split_try(const CarcaGemmDesc* desc, hipStream_t stream);
+// the persistent short-K kernel (gemm_stream.hip: many tiles per CU, K steps of consecutive tiles as one stream); fits32: every
+// operand offset fits 32 bits of bytes (gemm_rows_choose).  CARCA_OK = launched, 1 = not its product
+int carca_gemm_rows_stream_try(const CarcaGemmDesc* desc, bool fits32, hipStream_t stream);
 // carca_gemm_rows with the item-row gather riding along where the kernel choice leaves a CU idle; *rode tells whether
 // it did (otherwise the caller launches the gather itself)
 int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* ga, int* rode, void* stream);

@@ -2339,11 +2339,15 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
       rc = launch_gemm_rows_skc(desc, stream, nullptr, nullptr);
       if (rc != 1) return rc;
       rc = launch_gemm_rows_sk(desc, stream, nullptr, nullptr);
+      if (rc != 1) return rc;
+      rc = carca_gemm_rows_stream_try(desc, fits, stream);  // (short K, many tiles per CU: gemm_stream.hip)
       return rc == 1 ? launch_gemm_rows_cu<0>(desc, stream) : rc;
     }
     case GEMM_CU_STAMPS: return launch_gemm_rows_cu<1>(desc, stream);
     case GEMM_CU128: {  // (384 x 128 tiles fill one round where 96-wide ones would not -- unless the rows with id 0 can go)
-      const int rc = launch_gemm_rows_skc(desc, stream, nullptr, nullptr);
+      int rc = launch_gemm_rows_skc(desc, stream, nullptr, nullptr);
+      if (rc != 1) return rc;
+      rc = carca_gemm_rows_stream_try(desc, fits, stream);
       return rc == 1 ? launch_gemm_rows_cu<0, 4>(desc, stream) : rc;
     }
     case GEMM_WIDE64: return launch_gemm_rows<64, 96, 32, 4, true>(desc, stream);
@@ -2358,7 +2362,8 @@ int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* 
   hipStream_t stream = (hipStream_t)stream_;
   *rode = 0;
   GemmChoice c;
-  if (int rc = gemm_rows_choose(desc, &c)) return rc;
+  bool fits = false;
+  if (int rc = gemm_rows_choose(desc, &c, &fits)) return rc;
   if (carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 8 || carca_tuning(CARCA_TUNE_GEMM_VARIANT) == 158) ga = nullptr;  // (8: never let the gather ride -- A/B switch)
   if (c == GEMM_CU) {
     int rc = carca_gemm_rows_split_try(desc, stream);  // (the gather keeps its own launch beside this kernel: rode stays 0)
@@ -2366,10 +2371,14 @@ int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* 
     rc = launch_gemm_rows_skc(desc, stream, ga, rode);
     if (rc != 1) return rc;
     rc = launch_gemm_rows_sk(desc, stream, ga, rode);
+    if (rc != 1) return rc;
+    rc = carca_gemm_rows_stream_try(desc, fits, stream);  // (the gather keeps its own launch beside it: rode stays 0)
     return rc == 1 ? launch_gemm_rows_cu<0, 3>(desc, stream, ga, rode) : rc;
   }
   if (c == GEMM_CU128) {
-    const int rc = launch_gemm_rows_skc(desc, stream, ga, rode);
+    int rc = launch_gemm_rows_skc(desc, stream, ga, rode);
+    if (rc != 1) return rc;
+    rc = carca_gemm_rows_stream_try(desc, fits, stream);
     return rc == 1 ? launch_gemm_rows_cu<0, 4>(desc, stream, ga, rode) : rc;
   }
   return carca_gemm_rows(desc, stream_);
