@@ -250,6 +250,8 @@ int carca_gemm_rows_split_try(const CarcaGemmDesc* desc, hipStream_t stream);
 // the persistent short-K kernel (gemm_stream.hip: many tiles per CU, K steps of consecutive tiles as one stream); fits32: every
 // operand offset fits 32 bits of bytes (gemm_rows_choose).  CARCA_OK = launched, 1 = not its product
 int carca_gemm_rows_stream_try(const CarcaGemmDesc* desc, bool fits32, hipStream_t stream);
+// ... and the persistent narrow-output kernel (64 < N <= 96, many rows per CU: the joint embedding at C5 / C3)
+int carca_gemm_rows_n96s_try(const CarcaGemmDesc* desc, bool fits32, hipStream_t stream);
 // carca_gemm_rows with the item-row gather riding along where the kernel choice leaves a CU idle; *rode tells whether
 // it did (otherwise the caller launches the gather itself)
 int carca_gemm_rows_passenger(const CarcaGemmDesc* desc, const CarcaGatherArgs* ga, int* rode, void* stream);

@@ -2324,6 +2324,10 @@ extern "C" int carca_gemm_rows(const CarcaGemmDesc* desc, void* stream_) {
   GemmChoice c;
   bool fits = false;
   if (int rc = gemm_rows_choose(desc, &c, &fits)) return rc;
+  if (desc->N <= 96) {  // (a narrow output over many rows per CU: gemm_stream.hip)
+    const int rc = carca_gemm_rows_n96s_try(desc, fits, stream);
+    if (rc != 1) return rc;
+  }
   if ((carca_tuning(CARCA_TUNE_SPLIT_GEMM) & 16) && fits && c != GEMM_CU) {
     // (key 16, bit 4: the split-precision kernel wherever its own conditions hold, whatever the grid -- how the fixture-sized
     // parity tests reach it)

@@ -410,3 +410,454 @@ int carca_gemm_rows_stream_try(const CarcaGemmDesc* desc, bool fits32, hipStream
   CARCA_LAUNCH_CHECK();
   return CARCA_OK;
 }
+
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_rows_n96s_kernel: the NARROW-output row product (64 < N <= 96: AllEmbedding.joint_embed, carca.py:89, e = [z ; q]
+// W_j^T + b_j -- in inference over q's g columns with the item term from the projected table, CarcaGemmDesc.add_table) for
+// MANY rows per CU: BASELINE's C5 has 134,528 rows, C3 77,312.  gemm_rows_n96_kernel is one 80-row block per CU and is only
+// chosen for a single round (C2: 242 blocks); beyond it the tiled kernel ran (C5: 177 us, 44 % of the fp32 MFMA peak), every
+// 128-row block paying its own start, fill and epilogue.  Here ONE persistent workgroup per CU takes an EQUAL share of the
+// rows (cut at 16-row granularity, not at block granularity: 841 blocks of 160 rows over 256 CUs would be 3 or 4 each) and
+// walks it in blocks of 160 rows x all 96 columns:
+//   * wave (ct = wave % 6, rh = wave / 6) owns column tile ct for the row tiles 2 j + rh, j = 0..4, over the WHOLE K -- no
+//     K halves to add up in LDS at the end (gemm_rows_n96_kernel's 80-row blocks need that exchange to occupy twelve waves),
+//     80 MFMAs (16x16x4) per 64-wide K stage and wave in five independent chains, one barrier per stage;
+//   * the K stages of consecutive blocks are ONE stream: a stage is requested two stages ahead of its MFMAs into registers
+//     and stored to the LDS double buffer one stage ahead, across block boundaries;
+//   * a block's row ids are requested when it starts, its table rows / positional rows two stages before its end: the
+//     epilogue is arithmetic and buffer stores (row in the scalar offset);
+//   * a partial block (the share's last, a segment's last) skips the row tiles it does not have, wave by wave.
+// Same K order per output element as the other row kernels (stages of 64 in order); agrees with them to round-off.
+namespace n96s {
+constexpr int BM = 160, BN = 96, BK = 64, LS = BK + 4, NT = 768, C4 = BK / 4;
+constexpr int A_BUF = BM * LS, B_BUF = BN * LS;  // floats per stage
+constexpr int NA = 4, NB = 2;                    // staging slots per thread and stage: A rows r0 + 48 i (i = 3: threads < 256), B rows r0 + 48 j
+constexpr size_t LDS_BYTES = sizeof(float) * 2 * (A_BUF + B_BUF) + sizeof(int) * 2 * BM;  // + the row ids of two blocks
+static_assert(BM * C4 == 3 * NT + 256 && BN * C4 == NB * NT, "slot map");
+}  // namespace n96s
+
+struct N96sDev {
+  CarcaGemmDesc d;
+  int row_start[CARCA_MAX_SEGS + 1];  // global row (all segments laid end to end) of each segment's first row
+  unsigned long long* dbg;            // tools/stamp_n96s.py: wall-clock stamps (100 MHz) of a diagnostic run, or null
+};
+
+// DIAG (tuning key 5, timing experiments with WRONG results): 1 no global loads, 2 no MFMAs, 4 no LDS stores, 8 no addends /
+// output stores, 16 no fragment reads
+template <int DIAG>
+__global__ __launch_bounds__(768) void gemm_rows_n96s_kernel(const N96sDev args) {
+  using namespace n96s;
+  extern __shared__ __attribute__((aligned(16))) float Sm[];  // [2][A stage | B stage]
+  carca_warm_kernargs<sizeof(N96sDev)>();
+  const CarcaGemmDesc& D = args.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, mq = lane >> 4;
+  const int ct = wave % 6, rh = wave / 6;
+  const int K0 = D.K0, nst = (K0 + BK - 1) / BK;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define N96S_STAMP(k) do { if (args.dbg && tid == 0 && (k) < 64) args.dbg[65536 + blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
+  N96S_STAMP(0);
+  // this workgroup's share of the rows, in 16-row units
+  const int R = args.row_start[CARCA_MAX_SEGS];
+  const int units = (R + 15) / 16;
+  const int g_lo = (int)((long)units * blockIdx.x / gridDim.x) * 16, g_hi = min(R, (int)((long)units * (blockIdx.x + 1) / gridDim.x) * 16);
+  if (g_lo >= g_hi) return;
+
+  // ---- staging ----------------------------------------------------------------------------------------------------
+  const int r0 = tid >> 4, c = tid & 15;  // slot i: A row r0 + 48 i (i < 4), B row r0 + 48 j; 16-byte group c of the stage
+  const int lds0 = r0 * LS + c * 4;
+  const int i3 = tid < 256 ? 3 : 2;  // (A has 3 1/3 slots per thread: the others repeat their third one)
+  unsigned offb[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) offb[j] = (unsigned)min(r0 + 48 * j, D.N - 1) * (unsigned)D.ldb0 * 4u;
+  const __amdgpu_buffer_rsrc_t r_b = carca_rsrc(D.bt0);
+  // the cursor's block (the block whose stages are being requested)
+  int l_g = g_lo;            // its first global row
+  const float* l_a0 = D.seg[0].a0;
+  unsigned offa[NA];
+  auto block_end = [&](int g) {  // one past the block that starts at global row g: 160 rows, the segment's end or the share's
+    int e = min(g + BM, g_hi);
+#pragma unroll
+    for (int s = 1; s <= CARCA_MAX_SEGS; ++s)
+      if (g < args.row_start[s]) e = min(e, args.row_start[s]);
+    return e;
+  };
+  auto seg_of = [&](int g) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < CARCA_MAX_SEGS; ++i)
+      if (i < D.nseg && g >= args.row_start[i]) s = i;
+    return s;
+  };
+  auto retarget = [&](int g) {
+    const int s = seg_of(g);
+    const CarcaGemmSeg sg = D.seg[s];
+    const int row0 = g - args.row_start[s], last = sg.rows - 1;
+    l_a0 = sg.a0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) offa[i] = (unsigned)min(row0 + r0 + 48 * (i < 3 ? i : i3), last) * (unsigned)D.lda0 * 4u;
+  };
+  f32x4 rg[NA + NB];
+  auto to_f = [](const u32x4 v) {
+    return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+  };
+  auto load_stage = [&](int st) {  // (a group past K0 is clamped to end at K0 and moved / zeroed when stored: gemm_rows_n96_kernel)
+    if constexpr (DIAG & 1) return;
+    const unsigned kc = 4u * (unsigned)min(st * BK + c * 4, K0 - 4);
+    const __amdgpu_buffer_rsrc_t r_a = carca_rsrc(l_a0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rg[i] = to_f(__builtin_amdgcn_raw_buffer_load_b128(r_a, offa[i] + kc, 0, 0));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rg[NA + j] = to_f(__builtin_amdgcn_raw_buffer_load_b128(r_b, offb[j] + kc, 0, 0));
+  };
+  auto store_stage = [&](int st, int buf) {
+    if constexpr (DIAG & 4) return;
+    float* As = Sm + buf * (A_BUF + B_BUF);
+    float* Bs = As + A_BUF;
+    const int kb = st * BK;
+    if (kb + BK <= K0) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[lds0 + 48 * LS * (i < 3 ? i : i3)]) = rg[i];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(&Bs[lds0 + 48 * LS * j]) = rg[NA + j];
+      return;
+    }
+    const int kcol = kb + c * 4, sh = kcol - min(kcol, K0 - 4);
+    auto fix = [&](const f32x4 r) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = sh == 0 ? r[e] : (sh == 1 ? r[(e + 1) & 3] : (sh == 2 ? r[(e + 2) & 3] : r[(e + 3) & 3]));
+        v[e] = (kcol + e < K0) ? x : 0.f;
+      }
+      return v;
+    };
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[lds0 + 48 * LS * (i < 3 ? i : i3)]) = fix(rg[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(&Bs[lds0 + 48 * LS * j]) = fix(rg[NA + j]);
+  };
+
+  // ---- MFMAs: acc[j][r] = C[block row 16 (2 j + rh) + 4 mq + r][16 ct + ln] --------------------------------------------
+  f32x4 acc[5];
+  const int a_frag = (16 * rh + ln) * LS + 4 * mq, b_frag = A_BUF + (16 * ct + ln) * LS + 4 * mq;
+  auto compute = [&](int buf, int kleft, int nj) {  // kleft: columns of K0 from this stage's first one on; nj: the wave's row tiles
+    if constexpr (DIAG & 2) return;
+    const float* S = Sm + buf * (A_BUF + B_BUF);
+    if (nj == 5) {
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        if (16 * ch >= kleft) continue;  // (the ragged last stage: a chunk past K0 is zeros in both operands)
+        const f32x4 b = *reinterpret_cast<const f32x4*>(S + b_frag + 16 * ch);
+        f32x4 a[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) a[j] = *reinterpret_cast<const f32x4*>(S + a_frag + 32 * j * LS + 16 * ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc[j] = mfma16(a[j][e], b[e], acc[j]);
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        if (16 * ch >= kleft) continue;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(S + b_frag + 16 * ch);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          if (j < nj) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(S + a_frag + 32 * j * LS + 16 * ch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j] = mfma16(a[e], b[e], acc[j]);
+          }
+        }
+      }
+    }
+  };
+
+  // The hot step -- a full 64-wide stage of a full block -- hand-scheduled as gemm_rows_cu_kernel's: four groups of twenty
+  // MFMAs (one 16-k chunk each: five accumulator chains), every gap between two MFMAs pinned; the gaps of a group carry
+  // the six fragment reads of the NEXT chunk (two fragment sets alternate), the gaps of group 1 the six LDS stores of stage
+  // st + 1, those of group 2 the six requests of stage st + 2; ONE barrier behind group 2, the next stage's first
+  // fragments read under group 3.  Left to the compiler (store, request, multiply, barrier: the generic step below, kept
+  // for the ragged last stage and for partial blocks) a stage took 5.5 us against 3.3 us of MFMA time.
+  f32x4 fa0[5], fa1[5], fb0, fb1;
+  const int lds3 = lds0 + 48 * LS * i3;
+#define N96S_PIN() __builtin_amdgcn_sched_barrier(0)
+  auto read_slot = [&](int i, const float* S, int ch, f32x4(&fa)[5], f32x4& fb) {
+    if constexpr (DIAG & 16) return;
+    if (i == 0)
+      fb = *reinterpret_cast<const f32x4*>(S + b_frag + 16 * ch);
+    else
+      fa[i > 0 ? i - 1 : 0] = *reinterpret_cast<const f32x4*>(S + a_frag + 32 * (i > 0 ? i - 1 : 0) * LS + 16 * ch);
+  };
+  auto mfma_group = [&](const f32x4(&fa)[5], const f32x4& fb, auto&& aux) {
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+      if constexpr (!(DIAG & 2)) acc[i % 5] = mfma16(fa[i % 5][i / 5], fb[i / 5], acc[i % 5]);
+      N96S_PIN();
+      aux(i);
+      N96S_PIN();
+    }
+  };
+  auto store_slot = [&](auto rag_tag, int i, float* So, const int kb1) {  // rag: the stored stage (first column kb1) ends past K0
+    if constexpr (DIAG & 4) return;
+    f32x4 v = rg[i];
+    if constexpr (decltype(rag_tag)::value) {
+      const int kcol = kb1 + c * 4, sh = kcol - min(kcol, K0 - 4);
+      const f32x4 r = v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = sh == 0 ? r[e] : (sh == 1 ? r[(e + 1) & 3] : (sh == 2 ? r[(e + 2) & 3] : r[(e + 3) & 3]));
+        v[e] = (kcol + e < K0) ? x : 0.f;
+      }
+    }
+    if (i < NA)
+      *reinterpret_cast<f32x4*>(So + (i < 3 ? lds0 + 48 * LS * i : lds3)) = v;
+    else
+      *reinterpret_cast<f32x4*>(So + A_BUF + lds0 + 48 * LS * (i - NA)) = v;
+  };
+  auto load_slot = [&](int i, const unsigned kcv) {
+    if constexpr (DIAG & 1) return;
+    if (i < NA)
+      rg[i] = to_f(__builtin_amdgcn_raw_buffer_load_b128(carca_rsrc(l_a0), offa[i < NA ? i : 0] + kcv, 0, 0));
+    else
+      rg[i] = to_f(__builtin_amdgcn_raw_buffer_load_b128(r_b, offb[i >= NA ? i - NA : 0] + kcv, 0, 0));
+  };
+  auto pre_read = [&](int buf) {
+    const float* S = Sm + buf * (A_BUF + B_BUF);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) read_slot(i, S, 0, fa0, fb0);
+  };
+  // (taken only while two more stages follow: a branch per staging slot between the pinned MFMAs cuts the groups to pieces)
+  auto step_full = [&](auto rag_tag, int buf, const unsigned kcv, const int kb1) __attribute__((always_inline)) {
+    const float* S = Sm + buf * (A_BUF + B_BUF);
+    float* So = Sm + (buf ^ 1) * (A_BUF + B_BUF);
+    mfma_group(fa0, fb0, [&](int i) {
+      if (i < 6) read_slot(i, S, 1, fa1, fb1);
+    });
+    mfma_group(fa1, fb1, [&](int i) {
+      if (i < 6) read_slot(i, S, 2, fa0, fb0);
+      if (i >= 6 && i < 6 + NA + NB) store_slot(rag_tag, i - 6, So, kb1);
+    });
+    mfma_group(fa0, fb0, [&](int i) {
+      if (i < 6) read_slot(i, S, 3, fa1, fb1);
+      if (i >= 6 && i < 6 + NA + NB) load_slot(i - 6, kcv);
+    });
+    N96S_PIN();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // raw: the requested stage stays in flight across it
+    N96S_PIN();
+    mfma_group(fa1, fb1, [&](int i) {
+      if (i < 6) read_slot(i, So, 0, fa0, fb0);
+    });
+  };
+#undef N96S_PIN
+
+  // ---- epilogue operands -------------------------------------------------------------------------------------------
+  // (Measured and dropped, round 5: the raw sums through the free stage buffer as a [160][100] tile and 16-byte row-wise
+  // table reads / stores -- 153 us against 140 at C5; what the epilogue costs, ~6 us per block by the kernel's stamps, is the
+  // WAIT for the table rows behind the next block's freshly requested stages, not the width of its accesses:
+  // tools/stamp_n96s.py, DIAG 32 / 64.)
+  const int n = 16 * ct + ln;
+  const bool n_ok = n < D.N;
+  const int nn = min(n, D.N - 1);
+  const float bias = D.bias ? gload1(D.bias, nn) : 0.f;
+  const bool use_tab = D.add_table != nullptr;
+  float addv[5][4];  // the table's rows + the positional rows of the lane's twenty outputs
+  // A block's row ids wait in LDS (requested one block ahead by threads 0..159, one each: twenty per lane kept in registers
+  // across the K stages were what the hand-scheduled step spilled): Ids[parity of the block][row of the block]
+  int* const Ids = reinterpret_cast<int*>(Sm + 2 * (A_BUF + B_BUF));
+  int id_mine = 0;
+  auto request_ids = [&](int g) {  // thread t < 160: the id of row t of the block at global row g (clamped into the segment)
+    const int s = seg_of(g);
+    const CarcaGemmSeg sg = D.seg[s];
+    const int row0 = g - args.row_start[s];
+    const int32_t* idp = sg.ids ? sg.ids : reinterpret_cast<const int32_t*>(D.bt0);
+    id_mine = gload1i(idp, sg.ids ? min(row0 + min(tid, BM - 1), sg.rows - 1) : 0);
+  };
+  auto park_ids = [&](int par) {
+    if (tid < BM) Ids[par * BM + tid] = id_mine;
+  };
+  auto request_addends = [&](int g, int par) {
+    if constexpr (DIAG & 8) return;
+    const int s = seg_of(g);
+    const CarcaGemmSeg sg = D.seg[s];
+    const int row0 = g - args.row_start[s];
+    const bool use_pos = sg.add_pos && D.pos;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) addv[j][r] = 0.f;
+    if (use_tab) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          addv[j][r] = gload1(D.add_table, Ids[par * BM + 16 * (2 * j + rh) + 4 * mq + r] * D.ld_add_table + nn);
+    }
+    if (use_pos) {  // (positional rows: row % T, twenty divisions -- only where an encoding is configured)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(row0 + 16 * (2 * j + rh) + 4 * mq + r, sg.rows - 1);
+          addv[j][r] += gload1(D.pos, (row % sg.T) * D.N + nn);
+        }
+    }
+  };
+  auto epilogue = [&](int g, int g_end, int par) __attribute__((always_inline)) {
+    const int s = seg_of(g);
+    const CarcaGemmSeg sg = D.seg[s];
+    const int row0 = g - args.row_start[s], nrows = g_end - g;
+    const __amdgpu_buffer_rsrc_t c_rsrc = carca_rsrc(sg.c);
+    const unsigned c_v = (unsigned)((4 * mq * D.ldc + n) * 4);
+    const float alpha = D.alpha != 0.f ? D.alpha : 1.0f;
+    if (n >= D.ncols_out) return;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int br = 16 * (2 * j + rh) + 4 * mq + r;  // row inside the block
+        float v = alpha * acc[j][r] + bias + addv[j][r];
+        if (D.mask_rows) v = Ids[par * BM + br] != 0 ? v : 0.f;
+        v = n_ok ? v : 0.f;
+        const int so = (row0 + 16 * (2 * j + rh) + r) * D.ldc * 4;
+        if (br < nrows && (!(DIAG & 8) || v == 123.456f)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, c_v, so, 0);
+      }
+  };
+  auto tiles_of = [&](int nrows) {  // the wave's row tiles 2 j + rh that start inside a block of nrows rows
+    const int nt = (nrows + 15) >> 4;
+    return max(0, min(5, (nt - rh + 1) >> 1));
+  };
+
+  // ---- the stream ------------------------------------------------------------------------------------------------------
+  retarget(g_lo);
+  load_stage(0);
+  request_ids(g_lo);
+  store_stage(0, 0);
+  park_ids(0);
+  load_stage(1);
+  __syncthreads();
+  pre_read(0);
+  N96S_STAMP(1);
+  int buf = 0, par = 0, nblk_done = 0;
+  // stages st of a block whose step can be the pinned one: stage st full, stage st + 1 full (it is stored without shifting),
+  // two more stages behind it INSIDE the block (the block's last two steps request the next block's stages: generic)
+  const int npin_full = max(0, min(K0 / BK - 1, nst - 2));  // (= nst - 2 whenever at most the last stage is ragged)
+  auto generic_step = [&](int st, int g, int g_end, bool more, int nj) __attribute__((always_inline)) {
+    const bool has1 = st + 1 < nst || more, has2 = st + 2 < nst || more;
+    const int st1 = st + 1 < nst ? st + 1 : 0, st2 = st + 2 < nst ? st + 2 : st + 2 - nst;
+    if (st + 2 == nst && more) retarget(g_end);
+    if (st + 2 == nst) request_addends(g, par);
+    if (has1) store_stage(st1, buf ^ 1);
+    if (has2) load_stage(st2);
+    compute(buf, K0 - st * BK, nj);
+    __syncthreads();
+    if (has1) pre_read(buf ^ 1);
+    buf ^= 1;
+  };
+  constexpr std::integral_constant<bool, false> kPlain{};
+  for (int g = g_lo; g < g_hi;) {
+    const int g_end = block_end(g), nj = tiles_of(g_end - g);
+    const bool more = g_end < g_hi;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // stage st multiplies out of LDS buffer `buf`; stage st + 1 (in registers) goes to the other buffer; stage st + 2 is
+    // requested -- behind a block's last stages the NEXT block's first ones (behind the share's last block: nothing).
+    // The NEXT block's ids: requested here, parked in LDS behind the pinned steps (a few stages later).
+    if (more) request_ids(g_end);
+    const int sb = 2 + 14 * nblk_done;  // stamps of this block: start, behind the pinned steps, behind each later step, around the epilogue
+    N96S_STAMP(sb);
+    int st = 0;
+    if (nj == 5) {
+      // (a loop of nothing but pinned steps: with the generic step as an alternative inside the same loop the compiler kept
+      // the accumulators in scratch between steps; pinned steps for the block's last two stages as well -- three more places
+      // where the two kinds of step meet -- cost 150-280 spilled registers: they stay generic)
+      for (; st < npin_full; ++st) {
+        step_full(kPlain, buf, 4u * (unsigned)min((st + 2) * BK + c * 4, K0 - 4), 0);
+        buf ^= 1;
+      }
+    }
+    N96S_STAMP(sb + 1);
+    if (st == 0) generic_step(st++, g, g_end, more, nj);
+    if (more) park_ids(par ^ 1);
+    for (; st < nst; ++st) {
+      generic_step(st, g, g_end, more, nj);
+      N96S_STAMP(sb + 2 + min(max(st - (nst - 2), 0), 9));
+    }
+    N96S_STAMP(sb + 12);
+    epilogue(g, g_end, par);
+    N96S_STAMP(sb + 13);
+    ++nblk_done;
+    par ^= 1;
+    g = g_end;
+  }
+}
+
+}  // namespace
+
+int carca_gemm_rows_n96s_try(const CarcaGemmDesc* desc, bool fits32, hipStream_t stream) {
+  using namespace n96s;
+  const int variant = carca_tuning(CARCA_TUNE_GEMM_VARIANT);
+  if (variant == 26 || !fits32) return 1;  // (26: never -- A/B switch)
+  if (desc->K1 != 0 || desc->N <= 64 || desc->N > 96 || desc->ncols_out > 96 || desc->K0 < 4 * BK) return 1;
+  if (desc->colvec) return 1;
+  N96sDev g{};
+  g.d = *desc;
+  long rows = 0;
+  for (int s = 0; s < desc->nseg; ++s) {
+    const CarcaGemmSeg& sg = desc->seg[s];
+    if (sg.add || sg.gate || sg.rowscale || sg.a0_gather || sg.a0_bstride) return 1;
+    if ((desc->mask_rows || desc->add_table) && !sg.ids) return 1;
+    if (sg.add_pos && (!desc->pos || sg.T < 1)) return 1;
+    if ((uint64_t)sg.rows * (uint64_t)desc->ldc * 4ull >= (1ull << 32)) return 1;
+    if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
+    g.row_start[s] = (int)rows;
+    rows += sg.rows;
+  }
+  for (int s = desc->nseg; s <= CARCA_MAX_SEGS; ++s) g.row_start[s] = (int)rows;
+  if (rows >= (1l << 30)) return 1;
+  const int ncu = carca_num_cus();
+  // worth it: from 2.5 blocks per CU on (tuning variant 27 forces the kernel wherever it is correct).  Measured, interleaved A/B
+  // of the joint product: C5 (134,528 rows, 3.3 blocks per CU) 142 against 174 us on the tiled kernel; C3 (77,312 rows, 1.9
+  // blocks per CU) 97 against 88 us -- a share's last, partial block costs its seven latency-bound steps whatever it holds
+  if (variant != 27 && rows < (long)ncu * BM * 5 / 2) return 1;
+  const int grid = (int)std::min<long>(ncu, (rows + BM - 1) / BM);
+  const int diag = carca_tuning(5);
+  static bool attr_set[128] = {false};
+  auto launch = [&](auto kern) -> int {
+    if (!attr_set[diag & 127]) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+      }
+      attr_set[diag & 127] = true;
+    }
+    hipEvent_t e0, e1;
+    if (carca_take_launch_events(&e0, &e1))
+      hipExtLaunchKernelGGL(kern, dim3(grid), dim3(768), LDS_BYTES, stream, e0, e1, 0, g);
+    else
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(768), LDS_BYTES, stream, g);
+    return 0;
+  };
+  g.dbg = carca_debug_buffer();
+  carca_rows_log("gemm_rows_n96s_kernel", desc, grid);
+  int lrc;
+  switch (diag) {
+    case 1: lrc = launch(gemm_rows_n96s_kernel<1>); break;
+    case 2: lrc = launch(gemm_rows_n96s_kernel<2>); break;
+    case 4: lrc = launch(gemm_rows_n96s_kernel<4>); break;
+    case 8: lrc = launch(gemm_rows_n96s_kernel<8>); break;
+    case 16: lrc = launch(gemm_rows_n96s_kernel<16>); break;
+    case 5: lrc = launch(gemm_rows_n96s_kernel<5>); break;
+    case 21: lrc = launch(gemm_rows_n96s_kernel<21>); break;
+    default: lrc = launch(gemm_rows_n96s_kernel<0>); break;
+  }
+  if (lrc) return 1;
+  CARCA_LAUNCH_CHECK();
+  return CARCA_OK;
+}

@@ -555,7 +555,8 @@ def gemm_rows_group(calls) -> List[List[Tensor]]:
 def _gemm_desc(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional[Tensor] = None, K1: int = 0,
                bias: Optional[Tensor] = None, pos: Optional[Tensor] = None, colvec: Optional[Tensor] = None,
                gate_slope: float = 0.01, mask_rows: bool = False, ncols_out: Optional[int] = None,
-               gate_scale: float = 1.0, gate_zero_drops: bool = False, alpha: float = 1.0):
+               gate_scale: float = 1.0, gate_zero_drops: bool = False, alpha: float = 1.0,
+               add_table: Optional[Tensor] = None):
     """C_s[m][n] = sum_k A_s[m][k] Bt[n][k] (+ epilogue) for every row segment s: builds the descriptor.
 
     segs: list of dicts with keys a0 [rows, lda0] and optionally a1, ids, add, gate, rowscale, T, add_pos, out.
@@ -637,7 +638,9 @@ def _gemm_desc(segs, bt0: Tensor, N: int, K0: int, out_ld: int, *, bt1: Optional
     D.bias, D.pos, D.colvec = _ptr(bias), _ptr(pos), _ptr(colvec)
     D.ld_add, D.ld_gate, D.gate_slope, D.mask_rows = ld_add or 0, ld_gate or 0, gate_slope, int(mask_rows)
     D.gate_scale, D.gate_zero_drops, D.alpha = gate_scale, int(gate_zero_drops), alpha
-    keep += [bt0, bt1, bias, pos, colvec]
+    if add_table is not None:  # v += add_table[ids[row]] (CarcaGemmDesc.add_table: the joint embedding's projected item rows)
+        D.add_table, D.ld_add_table = add_table.data_ptr(), ld_of(add_table, "add_table")
+    keep += [bt0, bt1, bias, pos, colvec, add_table]
     return D, outs, keep
 
 

@@ -143,3 +143,104 @@ def test_shapes_it_declines_stay_on_the_other_kernels(tuning):
         got, log = _run(segs, w, b, 450, K0, K1)
         assert "gemm_rows_cus_kernel" not in log, log
         _check(got, _fp64(segs, ids_all, w, b, True), ids_all, 450, True)
+
+
+# ---- gemm_rows_n96s_kernel: the narrow-output product (joint embedding, carca.py:89) over many rows per CU ---------------
+
+
+def _joint_case(rows_list, K0, N, seed, lda_extra=0, a_off=0, table=True, pos_T=0, pad=True):
+    """Rows as the joint embedding meets them: A is a column slice [a_off : a_off + K0] of a wider workspace (zq), the
+    weights a column slice of joint_embed.weight, the item term gathered by id from a table, positions for the first segment."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ldw = a_off + K0 + lda_extra
+    w_full = (torch.rand(N, ldw, device="cuda", generator=g) * 2 - 1) * 0.05
+    w = w_full[:, a_off:a_off + K0]
+    b = torch.randn(N, device="cuda", generator=g) * 0.01
+    tab = torch.randn(1000, N + 6, device="cuda", generator=g)[:, :N] if table else None
+    pos = torch.randn(pos_T, N, device="cuda", generator=g) if pos_T else None
+    segs, ids_all = [], []
+    for i, r in enumerate(rows_list):
+        ids = torch.randint(1, 1000, (r,), device="cuda", dtype=torch.int32, generator=g)
+        if pad:
+            ids[torch.rand(r, device="cuda", generator=g) < 0.2] = 0
+        big = torch.rand(r, ldw, device="cuda", generator=g)
+        sg = dict(a0=big[:, a_off:a_off + K0], ids=ids)
+        if pos_T and i == 0:
+            sg.update(T=pos_T, add_pos=True)
+        segs.append(sg)
+        ids_all.append(ids)
+    return w, b, tab, pos, segs, ids_all
+
+
+def _joint_fp64(segs, ids_all, w, b, tab, pos, mask_rows=True, alpha=1.0):
+    outs = []
+    for sg, ids in zip(segs, ids_all):
+        y = alpha * (sg["a0"].double() @ w.double().t()) + b.double()
+        if tab is not None:
+            y = y + tab.double()[ids.long()]
+        if sg.get("add_pos"):
+            T = sg["T"]
+            y = y + pos.double()[torch.arange(y.shape[0], device="cuda") % T]
+        outs.append(y * (ids != 0).double()[:, None] if mask_rows else y)
+    return outs
+
+
+def _joint_run(segs, w, b, tab, pos, N, K0, ld=96, mask_rows=True, alpha=1.0):
+    from carca_replication_amd import ops
+
+    ops.gemm_rows_log(True)
+    got = ops.gemm_rows(segs, w, N, K0, ld, bias=b, pos=pos, mask_rows=mask_rows, ncols_out=ld, alpha=alpha, add_table=tab)
+    log = ops.gemm_rows_log()
+    ops.gemm_rows_log(False)
+    torch.cuda.synchronize()
+    return got, log
+
+
+@pytest.mark.parametrize("rows_list,K0,a_off", [([6400, 128128], 450, 90), ([6400, 128128], 540, 0), ([110000], 450, 90),
+                                               ([159, 70001, 17, 65000], 450, 90), ([120001], 256, 0), ([200001], 640, 128)])
+def test_joint_product_streams_and_matches_float64(tuning, rows_list, K0, a_off):
+    """C5's joint product and its like (inference: K = g = 450 out of zq's q columns, rows 8-byte aligned, K no multiple of 4, the
+    item term from the table; training's order: K = d + g = 540), four segments with ragged ends (a share cut by a segment's
+    end, segments shorter than a block, one row past a multiple of 16), K = 256 (four full stages) and 640 / N = 128-wide
+    workspace.  Every element against the float64 product; columns N .. 95 of the output are zeros; and against the
+    tiled kernels (tuning variant 26)."""
+    N = 90
+    w, b, tab, pos, segs, ids_all = _joint_case(rows_list, K0, N, seed=len(rows_list) * 7 + K0, a_off=a_off)
+    got, log = _joint_run(segs, w, b, tab, pos, N, K0)
+    assert "gemm_rows_n96s_kernel" in log, log
+    want = _joint_fp64(segs, ids_all, w, b, tab, pos)
+    _check(got, want, ids_all, N, True)
+    for x in got:
+        assert float(x[:, N:96].abs().max()) == 0.0
+    tuning(0, 26)
+    ref, log2 = _joint_run(segs, w, b, tab, pos, N, K0)
+    tuning(0, 0)
+    assert "gemm_rows_n96s_kernel" not in log2, log2
+    for x, y in zip(got, ref):
+        assert float((x[:, :N] - y[:, :N]).abs().max()) <= 2e-6 * float(y[:, :N].abs().max())
+
+
+@pytest.mark.parametrize("N,ld", [(96, 96), (65, 68), (90, 92)])
+def test_joint_product_widths_positions_alpha(tuning, N, ld):
+    """N = 96 (no padding column), 65 (the last column tile holds one column), output rows narrower than 96 floats; positional
+    rows on the first segment (T = 50: row % T), no table, alpha, no row mask."""
+    K0 = 320
+    w, b, tab, pos, segs, ids_all = _joint_case([50 * 1000, 70000], K0, N, seed=N, table=False, pos_T=50)
+    got, log = _joint_run(segs, w, b, None, pos, N, K0, ld=ld, mask_rows=False, alpha=1.7)
+    assert "gemm_rows_n96s_kernel" in log, log
+    _check(got, _joint_fp64(segs, ids_all, w, b, None, pos, mask_rows=False, alpha=1.7), ids_all, N, False)
+
+
+def test_joint_product_declines_small_batches(tuning):
+    """C2's row count (19,328: one round of the one-block-per-CU kernel) and C3's (77,312: under 2.5 blocks per CU, measured
+    slower) stay where they were; tuning variant 27 forces the kernel there and it is still right."""
+    for rows_list in ([6400, 12928], [25600, 51712]):
+        w, b, tab, pos, segs, ids_all = _joint_case(rows_list, 450, 90, seed=1, a_off=90)
+        got, log = _joint_run(segs, w, b, tab, pos, 90, 450)
+        assert "gemm_rows_n96s_kernel" not in log, log
+        _check(got, _joint_fp64(segs, ids_all, w, b, tab, pos), ids_all, 90, True)
+    tuning(0, 27)
+    got, log = _joint_run(segs, w, b, tab, pos, 90, 450)
+    tuning(0, 0)
+    assert "gemm_rows_n96s_kernel" in log, log
+    _check(got, _joint_fp64(segs, ids_all, w, b, tab, pos), ids_all, 90, True)

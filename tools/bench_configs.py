@@ -66,7 +66,7 @@ for name, c in CONFIGS.items():
     }
     dominant = max(stages, key=lambda k: stages[k][0] * stages[k][1])
     feat_kernel = next((t for t in rows_log.split(";") if f"N={g_} " in t), "?")
-    joint_kernel = next((t for t in rows_log.split(";") if f"N={d_} K={d_ + g_} " in t), "?")
+    joint_kernel = next((t for t in rows_log.split(";") if f"N={d_} K={d_ + g_} " in t or f"N={d_} K={g_} " in t), "?")  # (K = g: the item term from the projected table)
     LEAVES_ROWS_OUT = ("gemm_rows_skc_kernel", "gemm_rows_cuc_kernel", "gemm_rows_n96c_kernel")
     kname = {"feature_gemm": feat_kernel, "joint_gemm": joint_kernel, "cross_score": "cross_stream_kernel / cross_fold_kernel",
              "sa_block": "sa_eval_kernel"}
