@@ -14,8 +14,8 @@
 //     a wave's 32 rows is ONE id per lane and a ballot), issued while the next tile's loads fly.
 // Tiles and the K step itself are gemm_rows_cu_kernel's (384 x 96, twelve waves, wave w owns rows 32 w .. + 31 x 96
 // columns, hand-scheduled step with LDS double buffer and one barrier); the narrow last column block (N = 450 = 4 x 96 +
-// 66) is two MFMA column tiles + up to two VALU columns as in gemm_rows_sk_kernel, run by workgroups of their own, their
-// number chosen so that both kinds finish together.  Same products in the same order as gemm_rows_cu_kernel per output
+// 66) is two MFMA column tiles + up to two VALU columns as in gemm_rows_sk_kernel; its (cheaper) tiles are dealt BEHIND the
+// full ones -- fewer to the workgroups that hold one full tile more -- so that all workgroups end together.  Same products in the same order as gemm_rows_cu_kernel per output
 // element (K steps in order, the context group last): results agree to the last bit where that kernel's tail tile adds its
 // 32-wide step in the same grouping, and to round-off otherwise (tests/test_hip_gemm_stream.py: float64 products).
 #include <hip/hip_ext.h>
@@ -30,7 +30,11 @@ struct StreamDev {
   CarcaGemmDesc d;
   int rb_start[CARCA_MAX_SEGS + 1];  // 384-row blocks in front of each segment
   int nrb, nfull;                    // row blocks of all segments; full (96-column) column blocks
-  int x, y;                          // workgroups per full column block; workgroups of the narrow block (0: there is none)
+  // x TEAMS of nfull workgroups walk the full column blocks: the first `rem` teams base + 1 row blocks each, the others base.
+  // The narrow last column block's tiles (cheaper: two MFMA column tiles) are dealt BEHIND them so that everybody ends
+  // together: n1 each to the workgroups of the long teams, n0 to those of the short ones, n2 to the workgroups beyond the
+  // teams (which have nothing else); in workgroup order, the last ones clipped at nrb.  All 0 when there is no narrow block.
+  int x, base, rem, n1, n0, n2;
 };
 
 enum { IT_FAST = 1, IT_CTX = 2 };
@@ -326,15 +330,30 @@ __global__ __launch_bounds__(768) void gemm_rows_cus_kernel(const StreamDev args
   const int id = blockIdx.x, nw = gridDim.x;
   const int xcd = id & 7, q8 = nw >> 3, r8 = nw & 7;
   const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-  const int nfull = args.nfull, x = args.x;
+  const int nfull = args.nfull, x = args.x, rem = args.rem;
   if (w < x * nfull) {
     const int j = w / nfull, cb = w - j * nfull;
-    const int rbA = (int)((long)args.nrb * j / x), rbB = (int)((long)args.nrb * (j + 1) / x);
+    const int rbA = j * args.base + min(j, rem), rbB = rbA + args.base + (j < rem ? 1 : 0);
     stream_tiles<3, 0>(args, As, Bs, cb * 96, rbA, rbB);
+  }
+  // its share of the narrow column block's tiles
+  const int c1 = rem * nfull, c0 = (x - rem) * nfull;
+  int nA, nB;
+  if (w < c1) {
+    nA = w * args.n1;
+    nB = nA + args.n1;
+  } else if (w < c1 + c0) {
+    nA = c1 * args.n1 + (w - c1) * args.n0;
+    nB = nA + args.n0;
   } else {
-    const int j = w - x * nfull, y = args.y;
-    const int rbA = (int)((long)args.nrb * j / y), rbB = (int)((long)args.nrb * (j + 1) / y);
-    stream_tiles<2, XC>(args, As, Bs, nfull * 96, rbA, rbB);
+    nA = c1 * args.n1 + c0 * args.n0 + (w - c1 - c0) * args.n2;
+    nB = nA + args.n2;
+  }
+  nA = min(nA, args.nrb);
+  nB = min(nB, args.nrb);
+  if (nA < nB) {
+    __syncthreads();  // (everybody is done with the LDS buffers of the full tiles)
+    stream_tiles<2, XC>(args, As, Bs, nfull * 96, nA, nB);
   }
 }
 
@@ -372,28 +391,33 @@ int carca_gemm_rows_stream_try(const CarcaGemmDesc* desc, bool fits32, hipStream
   const int nfast = desc->K0 / 32;
   // worth it: several tiles per workgroup (a single round belongs to the one-tile kernels and their stream-K relatives)
   // and a K short enough that the per-tile costs matter (tuning variant 25 forces the kernel wherever it is correct)
-  if (variant != 25 && ((long)rb * ncb < 2l * ncu || nfast >= 64)) return 1;
-  // x workgroups per full column block, y for the narrow one: the smaller maximum of their tile counts, in 1/100 tiles
+  // (B = 256 at C5's other dimensions, 505 tiles: 152 against 168 us on the one-tile kernel; the CLI's default shape, 303 tiles:
+  // 139 against 113 -- the bound sits between them)
+  if (variant != 25 && ((long)rb * ncb * 4 < 7l * ncu || nfast >= 64)) return 1;
+  // Everybody in teams on the full column blocks, the narrow block's tiles behind them (StreamDev): the smallest common end T
+  // (in 1/100 of a full tile's time) for which the narrow tiles all find a place.  C5: 64 teams of four, 31 of them six row
+  // blocks and 33 five; T = 6.74 tiles -- one narrow tile behind six full ones, two behind five -- where separate workgroups
+  // for the narrow block made it 7.
   const long cheap = rem == 96 ? 0 : (xc == 2 ? 74 : (xc == 1 ? 71 : 68));
-  int bx = 1, by = cheap ? 1 : 0;
-  long best = -1;
-  for (int x = 1; x * nfull + (cheap ? 1 : 0) <= ncu && x <= rb; ++x) {
-    const int y = cheap ? std::min(rb, ncu - x * nfull) : 0;
-    const long tf = (long)((rb + x - 1) / x) * 100, tn = cheap ? (long)((rb + y - 1) / y) * cheap : 0;
-    const long t = std::max(tf, tn);
-    if (best < 0 || t < best) {
-      best = t;
-      bx = x;
-      by = y;
+  const int grid = (int)std::min<long>(ncu, (long)rb * nfull + (cheap ? rb : 0));
+  int x = std::min(rb, grid / nfull);
+  if (x < 1) return 1;
+  g.x = x;
+  g.base = rb / x;
+  g.rem = rb - g.base * x;
+  g.n1 = g.n0 = g.n2 = 0;
+  if (cheap) {
+    const long c1 = (long)g.rem * nfull, c0 = (long)(x - g.rem) * nfull, ce = grid - (long)x * nfull;
+    for (long T = 100l * g.base;; ++T) {
+      const long n1 = std::max(0l, (T - 100l * (g.base + 1)) / cheap), n0 = std::max(0l, (T - 100l * g.base) / cheap), n2 = T / cheap;
+      if (c1 * n1 + c0 * n0 + ce * n2 >= rb) {
+        g.n1 = (int)n1;
+        g.n0 = (int)n0;
+        g.n2 = (int)n2;
+        break;
+      }
     }
   }
-  if (cheap) {  // (no more narrow workgroups than it takes to stay under the full ones' time)
-    while (by > 1 && (long)((rb + by - 2) / (by - 1)) * cheap <= (long)((rb + bx - 1) / bx) * 100) --by;
-  }
-  g.x = bx;
-  g.y = by;
-  const int grid = bx * nfull + by;
-  if (grid < 1 || grid > ncu) return 1;
   carca_rows_log(xc == 0 ? "gemm_rows_cus_kernel<0>" : (xc == 1 ? "gemm_rows_cus_kernel<1>" : "gemm_rows_cus_kernel<2>"), desc, grid);
   hipEvent_t e0, e1;
   const bool ev = carca_take_launch_events(&e0, &e1);
