@@ -193,6 +193,19 @@ typedef struct CarcaGemmDesc {
   int32_t ld_add_table;
 } CarcaGemmDesc;
 int carca_gemm_rows(const CarcaGemmDesc* desc /*host*/, void* stream);
+/* Kernels behind it and what they assume of the GPU (the launcher picks by shape; carca_gemm_rows_log names the choice):
+ *  - gemm_rows_sk_kernel / gemm_rows_skc_kernel (K0 >= 2048 with a grid of about one 384 x 96 tile per CU: the feature
+ *    product at C2 / C3 / C4) are PERSISTENT grids of one workgroup per CU in which a workgroup may WAIT for a partial tile
+ *    that another workgroup of the same launch writes (stream-K hand-over).  Every workgroup of the launch must become
+ *    resident: give such a launch the whole device -- ONE stream of this library per device at a time, no CU mask smaller
+ *    than the grid, no long-running kernel of another stream holding CUs.  The wait is bounded (tuning key 12, ~5 s): a
+ *    taker that gives up writes the library's error word, and carca_poll_errors / the next such launch fail loudly instead
+ *    of the GPU hanging; the results of that launch are wrong.  The captured train step's second stream runs its kernels
+ *    under a CU budget (tuning key 10) and never one of these two beside another.
+ *  - gemm_rows_cus_kernel (short K, >= 1.75 tiles per CU: the feature product at C5) and gemm_rows_n96s_kernel (narrow
+ *    output over >= 2.5 blocks of 160 rows per CU: the joint embedding at C5) are persistent too, but no workgroup ever
+ *    waits for another: they are correct under any scheduling, beside any other stream.
+ *  - every other kernel is an ordinary grid of independent tiles. */
 /* Opt-in split-precision path of the product above (tuning key 16; csrc/gemm_split.hip): the weight matrix as packed
  * 16-bit planes, prepared once per weight version.  It takes products with K0 % 4 == 0 (k-source 0 in 32-wide K steps;
  * k-source 1, at most 8 columns, is added as exact fp32 multiply-adds) and the plain epilogue, on 384 x 96 tiles.
