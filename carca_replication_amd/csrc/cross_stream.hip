@@ -26,6 +26,7 @@
 // the u dot products are grouped differently (per lane, then across the four lanes of a slot), so results agree to
 // round-off (tests/test_hip_forward.py compares both with the oracle and with each other).
 #include <hip/hip_ext.h>
+#include <type_traits>
 #include "attn_common.h"
 #include "cross_fold.h"
 #include "../../include/carca_hip.h"
@@ -58,7 +59,8 @@ struct XsLds {  // offsets in floats; every region starts on a 16-byte boundary
   static constexpr int BK = BQ + G::DPO;
   static constexpr int FW = BK + G::DPO;                       // decoder.ffn.weight, plain order
   static constexpr int CU = FW + DPI;                          // [16]
-  static constexpr int TOTAL = CU + 16;
+  static constexpr int XS = CU + 16;                           // [4][DPI] normalised rows of a nearly empty last slot tile
+  static constexpr int TOTAL = XS + 4 * DPI;
 };
 
 template <int DPI, int DHP, int NH>
@@ -236,23 +238,79 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
             }
           }
         }
-        // K^T tiles: Ks[16 st + ln][16 ft + 4 mq + r] = sum_k W_K[16 ft + 4 mq + r][k] x[16 st + ln][k] + b_K
-        f32x4 acc[G::NF];
-#pragma unroll
-        for (int ft = 0; ft < G::NF; ++ft) acc[ft] = lds4(Bk + 16 * ft + 4 * mq);
-#pragma unroll
-        for (int kg = 0; kg < G::NKG; ++kg) {
-          f32x4 wf[G::NF];
-#pragma unroll
-          for (int ft = 0; ft < G::NF; ++ft) wf[ft] = lds4(Wk + ((ft * G::NKG + kg) * 64 + lane) * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int ft = 0; ft < G::NF; ++ft) acc[ft] = mfma16(wf[ft][e], x[kg][e], acc[ft]);
-        }
         float* Ks = Ks2 + buf * ATT_LMAX * G::SO;
+        const int nvalid = nk - 16 * st;  // slots of this tile that the profile holds (>= 1: st < LTc)
+        if (nvalid <= 4 && !(a.opt & 2)) {
+          // A NEARLY EMPTY last slot tile (a full profile of L = 50 re-based: slots 48, 49): its K rows on the VALU.  The
+          // MFMA tile below costs 144 MFMAs whatever it holds, and at full profiles it sits on the SIMD that also runs six
+          // of the user's 21 jobs where the others run five: 49 instead of 48 slots cost 25 % of the kernel
+          // (tools/k4_length_probe.py: 224 against 169 us at B = 4096).  Here: the <= 4 normalised rows through LDS, every
+          // lane the dot products of features lane and lane + 64 with them (W_K fragments and rows as 16-byte reads; the
+          // rows' reads are broadcasts), rows nvalid .. 15 of the image zero (masked keys: anything finite).  a.opt bit 1
+          // (tuning key 14) switches back to the MFMA tile.
+          float* Xs = lds + M::XS;
+          if (ln < 4) {
 #pragma unroll
-        for (int ft = 0; ft < G::NF; ++ft) *reinterpret_cast<f32x4*>(Ks + t * G::SO + 16 * ft + 4 * mq) = acc[ft];
+            for (int kg = 0; kg < G::NKG; ++kg) *reinterpret_cast<f32x4*>(Xs + ln * DPI + 16 * kg + 4 * mq) = x[kg];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave writes and reads: its LDS operations are in order)
+          // v_mfma_f32_4x4x1 (16 blocks of 4 x 4, one k per instruction): block b = features 4 b .. 4 b + 3 (A: lane l supplies
+          // W_K[feature l][k]), columns = the four slots (B: lane l supplies x[slot l & 3][k]), D: lane l holds
+          // K[slot l & 3][features 4 (l >> 2) .. + 3] -- 64 features x 4 slots per instruction at 8 cycles, 2 DPO / 64 x DPI of
+          // them = 1.5 k cycles where the 16 x 16 tile costs 4.6 k.  (First tried on the VALU, 768 FMAs for four rows: fp32
+          // VALU and MFMA share the SIMD's issue, the path cost as much as the tile it replaced -- 215 against 224 us.)
+          constexpr int FPL = (G::DPO + 63) / 64;  // halves of 64 features
+          const int fb = 4 * (lane >> 2);
+          f32x4 dk[FPL];
+          int fo[FPL];  // float offset of feature (lane + 64 q)'s fragment row inside a (feature tile, k group) block of W_K
+#pragma unroll
+          for (int q = 0; q < FPL; ++q) {
+            const int f = min(lane + 64 * q, G::DPO - 1);
+            fo[q] = ((f >> 4) * G::NKG * 64 + (f & 15)) * 4;
+            dk[q] = lds4(Bk + min(64 * q + fb, G::DPO - 4));
+          }
+          const float* xrow = Xs + (lane & 3) * DPI;
+#pragma unroll 2
+          for (int kg = 0; kg < G::NKG; ++kg) {
+#pragma unroll
+            for (int m4 = 0; m4 < 4; ++m4) {
+              const f32x4 xv = lds4(xrow + 16 * kg + 4 * m4);
+              f32x4 w[FPL];
+#pragma unroll
+              for (int q = 0; q < FPL; ++q) w[q] = lds4(Wk + fo[q] + (kg * 64 + m4 * 16) * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < FPL; ++q) dk[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[q][e], xv[e], dk[q], 0, 0, 0);
+            }
+          }
+          // rows 0..3 of the tile (rows at or past nvalid: x = 0, i.e. the bias -- masked keys, anything finite), rows 4..15 zeros
+#pragma unroll
+          for (int q = 0; q < FPL; ++q)
+            if (64 * q + fb < G::DPO) *reinterpret_cast<f32x4*>(Ks + (16 * st + (lane & 3)) * G::SO + 64 * q + fb) = dk[q];
+          constexpr int QPR = G::DPO / 4;  // 16-byte groups per row
+          for (int u = lane; u < 12 * QPR; u += 64) {
+            const int r = 4 + u / QPR, c4 = u - (u / QPR) * QPR;
+            *reinterpret_cast<f32x4*>(Ks + (16 * st + r) * G::SO + 4 * c4) = zero4();
+          }
+        } else {
+          // K^T tiles: Ks[16 st + ln][16 ft + 4 mq + r] = sum_k W_K[16 ft + 4 mq + r][k] x[16 st + ln][k] + b_K
+          f32x4 acc[G::NF];
+#pragma unroll
+          for (int ft = 0; ft < G::NF; ++ft) acc[ft] = lds4(Bk + 16 * ft + 4 * mq);
+#pragma unroll
+          for (int kg = 0; kg < G::NKG; ++kg) {
+            f32x4 wf[G::NF];
+#pragma unroll
+            for (int ft = 0; ft < G::NF; ++ft) wf[ft] = lds4(Wk + ((ft * G::NKG + kg) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int ft = 0; ft < G::NF; ++ft) acc[ft] = mfma16(wf[ft][e], x[kg][e], acc[ft]);
+          }
+#pragma unroll
+          for (int ft = 0; ft < G::NF; ++ft) *reinterpret_cast<f32x4*>(Ks + t * G::SO + 16 * ft + 4 * mq) = acc[ft];
+        }
         // folded value u[h][slot] = x[slot] . wu[h] + cu[h]
 #pragma unroll
         for (int h = 0; h < NH; ++h) {

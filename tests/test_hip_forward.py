@@ -574,7 +574,10 @@ def test_one_block_per_cu_joint_gemm_equals_the_tiled_one(B, L, N, enc):
     (90, 3, 50, [1], 270, "holes"), (90, 3, 50, [17], 270, "uniform"), (90, 3, 50, [300], 260, "holes"),
     (90, 3, 50, [5, 130, 33], 270, "holes"), (90, 2, 50, [50, 50], 300, "holes"), (90, 1, 33, [101], 280, "holes"),
     (64, 2, 50, [101], 300, "holes"), (64, 4, 7, [40], 300, "holes"), (64, 1, 64, [20], 300, "full"),
-    (96, 3, 64, [129], 300, "holes")])
+    (96, 3, 64, [129], 300, "holes"),
+    # every profile with a NEARLY EMPTY last slot tile (1..4 slots: its K rows are computed on the VALU, csrc/cross_stream.hip)
+    (90, 3, 50, [101], 300, "full"), (90, 3, 49, [101], 270, "full"), (64, 2, 36, [40], 300, "full"),
+    (90, 3, 4, [33], 280, "full"), (64, 4, 20, [101], 300, "full"), (96, 3, 35, [50], 300, "full")])
 def test_stream_scoring_kernel_equals_oracle_and_per_user_kernels(d, H, L, Ns, B, lengths):
     """cross_stream_kernel (what B > #CUs launches in eval mode; forced here with tuning key 7 = 3 at any B) against the
     oracle's final norm + cross_block and against the two per-user kernels (folded: key 7 = 2, V-materialising: key 6 = 1):
