@@ -1575,6 +1575,65 @@ __global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) 
   if (nst > 2) load_stage(2, 2);
   store_stage(0, 0, 0);
   __syncthreads();
+  // ---- six HAND-SCHEDULED steps in front (round 5; the schedule of gemm_rows_n96s_kernel's step, gemm_stream.hip): a full
+  // stage is two groups of twenty pinned MFMAs (this wave's two 16-k chunks, five accumulator chains); the gaps of group 0
+  // carry the six fragment reads of chunk 1 and the four LDS stores of stage st + 1, ONE barrier, the gaps of group 1 the six
+  // fragment reads of the next stage's chunk 0 and the four requests of stage st + 3.  Left to the compiler (N96_STEP below:
+  // store, request, multiply, barrier) a stage took ~2.5 us against 1.6 us of MFMA time.  Six of them, or none: LDS buffer and
+  // ring slot are compile-time constants of a step (period six), and a loop in which a pinned and a generic step are
+  // alternatives costs a second copy of the accumulators; taken when stages 0..6 are full ones.
+  int st0 = 0;
+  if (!(diag & 32) && nst >= 8 && 7 * BK <= D.K0 && !(diag & 3)) {
+#define N96_PIN() __builtin_amdgcn_sched_barrier(0)
+    f32x4 fa0[5], fa1[5], fb0, fb1;
+    auto read_slot = [&](int i, int buf, int ch, f32x4(&fa)[5], f32x4& fb) {
+      if (i == 0)
+        fb = *reinterpret_cast<const f32x4*>(b_frag + buf * B_BUF + 16 * ch);
+      else
+        fa[i > 0 ? i - 1 : 0] = *reinterpret_cast<const f32x4*>(a_frag + buf * A_BUF + (i > 0 ? i - 1 : 0) * 16 * LS + 16 * ch);
+    };
+    auto group = [&](const f32x4(&fa)[5], const f32x4& fb, auto&& aux) {
+#pragma unroll
+      for (int i = 0; i < 20; ++i) {
+        acc[i % 5] = mfma16(fa[i % 5][i / 5], fb[i / 5], acc[i % 5]);
+        N96_PIN();
+        aux(i);
+        N96_PIN();
+      }
+    };
+    auto pinned = [&](auto b0_tag, auto r1_tag, auto r3_tag, int st) {
+      constexpr int B0 = decltype(b0_tag)::value, B1 = B0 ^ 1, R1 = decltype(r1_tag)::value, R3 = decltype(r3_tag)::value;
+      const int kb3 = (st + 3) * BK;
+      group(fa0, fb0, [&](int i) {
+        if (i < 6) read_slot(i, B0, 1, fa1, fb1);
+        if (i >= 6 && i < 6 + NSL) *reinterpret_cast<f32x4*>(&Sm[ldsx[i - 6 < NSL ? i - 6 : 0] + B1 * bstr[i - 6 < NSL ? i - 6 : 0]]) = rg[R1][i - 6 < NSL ? i - 6 : 0];
+      });
+      N96_PIN();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // raw: the requested stages stay in flight across it
+      N96_PIN();
+      group(fa1, fb1, [&](int i) {
+        if (i < 6) read_slot(i, B1, 0, fa0, fb0);
+        if (i >= 6 && i < 6 + NSL) {  // stage st + 3 (st <= 5 and nst >= 8: it exists; its clamp matters for the ragged one)
+          const int j = i - 6 < NSL ? i - 6 : 0;
+          const unsigned kc = 4u * (unsigned)min(kb3 + c4s[j] * 4, D.K0 - 4);
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(slot_a[j] ? r_a : r_b, off[j] + kc, 0, 0);
+          rg[R3][j] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+        }
+      });
+    };
+#pragma unroll
+    for (int i = 0; i < 6; ++i) read_slot(i, 0, 0, fa0, fb0);
+    using std::integral_constant;
+    pinned(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, 0);
+    pinned(integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 1>{}, 1);
+    pinned(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 2>{}, 2);
+    pinned(integral_constant<int, 1>{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, 3);
+    pinned(integral_constant<int, 0>{}, integral_constant<int, 2>{}, integral_constant<int, 1>{}, 4);
+    pinned(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, 2>{}, 5);
+#undef N96_PIN
+    st0 = 6;
+  }
   // stage st: LDS buffer st % 2, ring slot st % 3; unrolled by six so that both are compile-time constants
 #define N96_STEP(o, R1, B1, R3, B0)                                        \
   if (st + (o) < nst) {                                                    \
@@ -1583,7 +1642,7 @@ __global__ __launch_bounds__(768) void gemm_rows_n96_kernel(const GemmDev args) 
     if (!(diag & 2)) compute(B0, D.K0 - (st + (o)) * BK);                  \
     __syncthreads();                                                       \
   }
-  for (int st = (diag & 16) ? nst : 0; st < nst; st += 6) {
+  for (int st = (diag & 16) ? nst : st0; st < nst; st += 6) {
     N96_STEP(0, 1, 1, 0, 0)
     N96_STEP(1, 2, 0, 1, 1)
     N96_STEP(2, 0, 1, 2, 0)

@@ -379,7 +379,7 @@ int carca_gemm_rows_stream_try(const CarcaGemmDesc* desc, bool fits32, hipStream
     const CarcaGemmSeg& sg = desc->seg[s];
     if (sg.add || sg.gate || sg.rowscale || sg.add_pos || sg.a0_gather || (desc->mask_rows && !sg.ids)) return 1;
     if (sg.a0_bstride || sg.a1_bstride) return 1;  // (dense rows only: a row's offset is row x lda)
-    if ((uint64_t)sg.rows * (uint64_t)desc->ldc * 4ull >= (1ull << 32)) return 1;  // (the epilogue's 32-bit store offsets)
+    if ((uint64_t)sg.rows * (uint64_t)desc->ldc * 4ull >= (1ull << 31)) return 1;  // (the epilogue's store offsets are signed 32-bit scalars)
     if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
     g.rb_start[s] = rb;
     rb += (sg.rows + 383) / 384;
@@ -837,7 +837,7 @@ int carca_gemm_rows_n96s_try(const CarcaGemmDesc* desc, bool fits32, hipStream_t
     if (sg.add || sg.gate || sg.rowscale || sg.a0_gather || sg.a0_bstride) return 1;
     if ((desc->mask_rows || desc->add_table) && !sg.ids) return 1;
     if (sg.add_pos && (!desc->pos || sg.T < 1)) return 1;
-    if ((uint64_t)sg.rows * (uint64_t)desc->ldc * 4ull >= (1ull << 32)) return 1;
+    if ((uint64_t)sg.rows * (uint64_t)desc->ldc * 4ull >= (1ull << 31)) return 1;  // (signed 32-bit store offsets)
     if (g.d.seg[s].T < 1) g.d.seg[s].T = 1;
     g.row_start[s] = (int)rows;
     rows += sg.rows;
