@@ -571,7 +571,40 @@ __global__ __launch_bounds__(768) void gemm_rows_cu_kernel(const GemmDev args) {
   }
 #undef CARCA_PIN
   // ---- tail tiles (ragged end of k-source 0, all of k-source 1): plain load -> LDS -> multiply ----
-  for (int t = nfast; t < ntiles; ++t) {
+  // (the context columns as ONE 8-k group where they are all of the tail: see cu_tile)
+  const bool ctx8 = D.K1 >= 4 && D.K1 <= 8 && D.K0 % BK == 0 && !(args.diag & 64);
+  if (ctx8) {
+    const int xr = tid >> 1, xh = tid & 1;
+    const int cs = min(4 * xh, D.K1 - 4), sh = 4 * xh - cs;
+    const int gr = min(row0 + xr, sg.rows - 1);
+    const int ub = gr / sg.T, ut = gr - ub * sg.T;
+    const size_t ao = sg.a1_bstride ? (size_t)ub * sg.a1_bstride + (size_t)ut * D.lda1 : (size_t)gr * D.lda1;
+    const bool bx_live = tid < 2 * BN;
+    const f32x4 av = *reinterpret_cast<const f32x4_u*>(sg.a1 + ao + cs);
+    const f32x4 bv = *reinterpret_cast<const f32x4_u*>(D.bt1 + (size_t)min(n0 + (bx_live ? xr : 0), D.N - 1) * D.ldb1 + cs);
+    auto fix = [&](const f32x4 v) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = sh == 0 ? v[e] : (sh == 1 ? v[(e + 1) & 3] : (sh == 2 ? v[(e + 2) & 3] : v[(e + 3) & 3]));
+        o[e] = (4 * xh + e < D.K1) ? x : 0.f;
+      }
+      return o;
+    };
+    __syncthreads();  // every wave is done with both LDS buffers
+    *reinterpret_cast<f32x4*>(&As[xr * LS + xh * 4]) = fix(av);
+    if (bx_live) *reinterpret_cast<f32x4*>(&Bs[xr * LS + xh * 4]) = fix(bv);
+    __syncthreads();
+    const f32x4 a = *reinterpret_cast<const f32x4*>(a_frag);
+    f32x4 b[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(b_frag + tn * 32 * LS);
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tn] = mfma32(a[st], b[tn][st], acc[tn]);
+  }
+  for (int t = ctx8 ? ntiles : nfast; t < ntiles; ++t) {
     load_tail(t);
     __syncthreads();  // every wave is done with both LDS buffers
 #pragma unroll
@@ -810,7 +843,52 @@ __device__ __forceinline__ void cu_tile(const GemmDev& args, float* __restrict__
     if (t < t_hi) step(std::integral_constant<int, 0>{}, t);
   }
 #undef CARCA_PIN
-  if (with_tail) {
+  // The context columns (k-source 1 with 4 <= K1 <= 8 behind a K0 of whole 32-steps: AllEmbedding's six) as ONE 8-k group
+  // (round 5; the scheme of gemm_rows_cus_kernel's context item, gemm_stream.hip): every thread requests one 16-byte group
+  // of its row -- thread = (row tid >> 1, half tid & 1), the second half clamped to END at K1 and shifted / zeroed when
+  // stored --, two barriers, 4 TN MFMAs.  The general tail below stages a whole 32-wide tile through element-wise
+  // conditional loads (twenty dword loads per thread) and multiplies four 8-k groups, three of them zeros: ~7 us per
+  // owned tile against ~3.  Same products in the same order (the other groups added zeros): bit-identical results.
+  const bool ctx8 = with_tail && D.K1 >= 4 && D.K1 <= 8 && D.K0 % BK == 0 && !(args.diag & 64);
+  if (ctx8) {
+    const int xr = tid >> 1, xh = tid & 1;
+    const int cs = min(4 * xh, D.K1 - 4), sh = 4 * xh - cs;
+    int gr = min(row0 + xr, nrows - 1);
+    if constexpr (IDX) gr = dyn.rows[gr];
+    const int ub = gr / sg.T, ut = gr - ub * sg.T;
+    const size_t ao = sg.a1_bstride ? (size_t)ub * sg.a1_bstride + (size_t)ut * D.lda1 : (size_t)gr * D.lda1;
+    const bool bx_live = tid < 2 * BNS;
+    const f32x4 av = *reinterpret_cast<const f32x4_u*>(sg.a1 + ao + cs);
+    const f32x4 bv = *reinterpret_cast<const f32x4_u*>(D.bt1 + (size_t)min(n0 + (bx_live ? xr : 0), D.N - 1) * D.ldb1 + cs);
+    auto fix = [&](const f32x4 v) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = sh == 0 ? v[e] : (sh == 1 ? v[(e + 1) & 3] : (sh == 2 ? v[(e + 2) & 3] : v[(e + 3) & 3]));
+        o[e] = (4 * xh + e < D.K1) ? x : 0.f;
+      }
+      return o;
+    };
+    __syncthreads();  // every wave is done with both LDS buffers
+    *reinterpret_cast<f32x4*>(&As[xr * LS + xh * 4]) = fix(av);
+    *reinterpret_cast<f32x4*>(&Bs[bx_live ? xr * LS + xh * 4 : 2 * B_BUF + ((tid - 2 * BNS) & 255) * 4]) = fix(bv);
+    __syncthreads();
+    const f32x4 a = *reinterpret_cast<const f32x4*>(a_frag);
+    f32x4 b[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(b_frag + tn * 32 * LS);
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tn] = mfma32(a[st], b[tn][st], acc[tn]);
+    if constexpr (XC > 0) {
+#pragma unroll
+      for (int c = 0; c < XC; ++c) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(x_frag + c * LS);
+        xacc[c] = __builtin_elementwise_fma(a, w, xacc[c]);
+      }
+    }
+  } else if (with_tail) {
     for (int t = D.K0 / BK; t < ntiles; ++t) {
       load_tail(t);
       __syncthreads();
@@ -2009,6 +2087,7 @@ static int launch_gemm_rows_cu(const CarcaGemmDesc* desc, hipStream_t stream, co
   g.nrb = rb;
   g.ncb = (desc->ncols_out + 32 * TN - 1) / (32 * TN);
   g.dbg = carca_debug_buffer();
+  g.diag = carca_tuning(CARCA_TUNE_DIAG);  // (bit 6: the general tail instead of the 8-wide context group -- A/B)
   int grid = rb * g.ncb;
   // A CU left over in the (single) round takes the gather -- if the tiles keep the others busy for longer than the lone
   // workgroup needs: ~4.2 us per 32-k step here, ~12 ns per gathered row there (19 k rows: 0.2 ms against 0.54 ms at C2).
