@@ -946,7 +946,11 @@ extern "C" int carca_cross_score_fwd(const float* p_raw, int ldp, const int32_t*
     // no instantiation above d = 96: the per-user kernel below then runs.
     const int t7 = carca_tuning(7);
     const int tune1 = carca_tuning(CARCA_TUNE_ATTN_VARIANT);
-    if (!p_normed && t7 != 2 && (tune1 == 0 || tune1 == 2) && (t7 == 3 || B > carca_num_cus())) {
+    // (... and from 48 target tiles per user on -- C5's 1 + 1000 candidates are 63 --: the per-user kernel fetches W_Q and the
+    // target rows per (tile, head) job through the CU's load path, 53.4 us at C5 against 47.7 here; at 301 candidates 24.1
+    // against 23.1, at C2's 101 14.3 against 14.7)
+    if (!p_normed && t7 != 2 && (tune1 == 0 || tune1 == 2) &&
+        (t7 == 3 || B > carca_num_cus() || gd.tile_start[ngroups] >= 48)) {
       fa.nparts = (gd.tile_start[ngroups] > 1 && (tune1 == 2 || 2 * B <= carca_num_cus())) ? 2 : 1;
       const int rc = carca_cross_stream_launch(fa, dpi, dhp, H, B, stream);
       if (rc != CARCA_ERR_UNSUPPORTED) return rc;
