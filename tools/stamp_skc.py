@@ -11,8 +11,12 @@ from oracle.carca_oracle import synth_eval_batch  # noqa: E402
 from tests.model_util import build_model  # noqa: E402
 
 torch.manual_seed(0)
-model = build_model(dict(d=90, H=3, n_blocks=2), 12102, 450, 6, 4096, 50).cuda().eval()
-profile, target, _ = synth_eval_batch(128, 50, 101, 12102, 4096, 6, seed=1)
+# other shapes from the environment (B NA D G H NB; K19 = tuning key 19, the compacting kernel's lower bound on K steps)
+B_, NA_, D_, G_, H_, NB_ = (int(os.environ.get(k, v)) for k, v in (("B", 128), ("NA", 4096), ("D", 90), ("G", 450), ("H", 3), ("NB", 2)))
+if os.environ.get("K19"):
+    ops.set_tuning(19, int(os.environ["K19"]))
+model = build_model(dict(d=D_, H=H_, n_blocks=NB_), 12102, G_, 6, NA_, 50).cuda().eval()
+profile, target, _ = synth_eval_batch(B_, 50, 101, 12102, NA_, 6, seed=1)
 profile, target = tuple(t.cuda() for t in profile), tuple(t.cuda() for t in target)
 lib = _lib.load()
 buf = torch.zeros(65536 + 2 * 256 * 16, dtype=torch.int64, device="cuda")
