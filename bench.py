@@ -16,7 +16,8 @@ AllEmbedding, 97% of the model's flops): the flops it EXECUTES per launch (rows 
 algorithmic flops over every padded row; `*_full_profiles` = the same step with nothing to leave out) / its mean duration measured
 with events bound to its own dispatch on the launch stream inside the timed region (every fourth step:
 a pair costs ~5 us per step); the smaller kernels' entries come from a pass right behind it.  `cpu_baseline` is the CPU oracle
-(oracle/carca_oracle.py, a port of the reference's PyTorch-CPU path) on all host cores.
+(oracle/carca_oracle.py, a port of the reference's PyTorch-CPU path) on all host cores.  `other_configs` (side pass, one GPU):
+BASELINE.json's C3 and C5 configurations by the same protocol -- never `value`.
 """
 import argparse
 import gc
@@ -377,6 +378,36 @@ def measure_full_profiles(c, model, device, fence, steps, warmup, fl):
             "feat_gemm_tflops": tf, "feat_gemm_frac": tf / PEAK_F32_MFMA_TFLOPS}
 
 
+def measure_other_configs(device, fence, steps=60, warmup=10):
+    """BASELINE.json's other single-GPU configurations, eval forward, by the headline's protocol (inputs resident in HBM,
+    pre-heated, `steps` timed steps): C3 (Fashion-shape: B = 512, same per-user dimensions) and C5 (Games-shape: n_attrs =
+    512, 1 + 1000 candidates).  Side pass, never `value`; tools/bench_configs.py is the same measurement with per-stage
+    kernel times (profiles/*_configs.json)."""
+    import torch
+
+    from carca_replication_amd import ops
+
+    out = {}
+    for name, over in (("C3", dict(B=512)), ("C5", dict(n_attrs=512, N=1001))):
+        c = dict(C2, **over)
+        model = build_model(c, device)
+        _, _, profile, target = build_inputs(c, 4321, device)
+        with torch.no_grad():
+            ops.gemm_rows_log(True)
+            model(profile=profile, targets=[target])
+            log = ops.gemm_rows_log()
+            ops.gemm_rows_log(False)
+            dt = timed_loop(lambda: model(profile=profile, targets=[target]), steps, warmup, fence)
+        fl = flops_per_user(c)
+        out[name] = {"users_per_s": c["B"] * steps / dt, "ms_per_step": 1e3 * dt / steps,
+                     "model_tflops": c["B"] * steps / dt * fl["total"] / 1e12,
+                     "workload": f"B={c['B']} L={c['L']} N={c['N']} d={c['d']} g={c['g']} H={c['H']} n_attrs={c['n_attrs']}",
+                     "row_kernels": [t.split(" rows=")[0] for t in log.split(";") if t]}
+        del model, profile, target
+        torch.cuda.empty_cache()
+    return out
+
+
 def measure_epoch_pipeline(c, model, device, world, fence, n_batches=256):
     """END-TO-END evaluation epoch of the assembled fast loop: users/s INCLUDING batch construction
     and the metrics.  A synthetic interaction log lives in HBM (device_data.DeviceInteractions: per user a history whose
@@ -468,6 +499,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=24, help="extra, untimed-by-the-headline train-step measurement")
     ap.add_argument("--no-full-profiles", action="store_true", help="skip the side pass with every profile at L = 50 (the PMC "
                     "passes of tools/profile_round.sh: their per-launch averages must cover the headline batch only)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side pass over BASELINE's C3 / C5 configurations")
     ap.add_argument("--no-scoring-scaling", action="store_true", help="skip the scoring kernel's B = 1024 / 4096 side pass")
     args = ap.parse_args()
 
@@ -783,6 +815,8 @@ def main():
             out["folded_embedding_path"] = fold_info
         if split_info is not None:
             out["split_bf16_path"] = split_info
+        if world == 1 and not args.no_configs:
+            out["other_configs"] = measure_other_configs(device, fence)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, model, profile_cpu, target_cpu)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 # (the stats pass keeps the split-precision and B = 1024 / 4096 scoring side passes -- their kernels have rows of their own in the
 # summary; the side pass with full profiles launches the SAME feature-GEMM kernel over more rows and is left out of every pass, so
 # that the kernel's per-launch averages are the headline batch's)
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-table --no-fold --no-full-profiles --train-steps 0"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-table --no-fold --no-full-profiles --no-configs --train-steps 0"
 BENCH_PMC="$BENCH --no-split --no-scoring-scaling"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log" || exit 1
 echo "stats pass done"
