@@ -168,10 +168,22 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
       const int v = user_of(min(k, nu - 1));
       return gload1i(a.p_ids + (size_t)v * L, lane < L ? lane : L - 1);
     };
+    // A ONE-TILE profile (5..16 slots: 29 % of BASELINE's draws) leaves three of the four B waves idle and its whole build --
+    // 144 MFMAs + the LayerNorm -- on the SIMD of the fourth, beside five of the user's jobs: that SIMD sets the step (18.2 k
+    // cycles against a mean of 14.2 k).  The waves of slot tiles 0, 1, 2 then share tile 0: each loads and normalises its rows
+    // (cheap) and projects a THIRD of the K features; wave st = 0 alone writes u and the mask.  (NF % 3 == 0: d = 90 / 96;
+    // a.opt bit 2 -- tuning key 14 -- switches it off.)  Measured (tools/k4_length_probe.py, B = 4096, every profile 16 / 8 slots):
+    // 140.6 -> 134.9 / 125.6 us; with BASELINE's mixed lengths the launch reads the same (0.79): a short profile's jobs are
+    // short, and their steps wait for the next job's target rows, not for the build.
+    constexpr bool HELP = (G::NF % 3) == 0;
+    auto shares_tile0 = [&](unsigned long long pm) {
+      const int nk_ = pm ? L - (int)__builtin_ctzll(pm) : 0;
+      return HELP && !(a.opt & 4) && st < 3 && nk_ >= 1 && nk_ <= 16;  // (1..4 slots too: a third of the tile each beats the 4 x 4 x 1 path on one SIMD, 126 against 142 us)
+    };
     auto request_rows = [&](int k, unsigned long long pm) {
       const int v = user_of(min(k, nu - 1));
       const int s0 = pm ? (int)__builtin_ctzll(pm) : L;
-      const int r = s0 + 16 * st + ln;
+      const int r = s0 + 16 * (shares_tile0(pm) ? 0 : st) + ln;
       const float* pu = a.p_raw + (size_t)v * L * a.ldp;
       const int ro = (r < L ? r : L - 1) * a.ldp + 4 * mq;
 #pragma unroll
@@ -185,6 +197,9 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
       const int nk = L - s0;
       const int LTc = (nk + 15) >> 4;
       if (st == XS_NBW - 1 && lane == 0) Hdr[buf * 4] = LTc;  // (the wave that most often has no tile of its own)
+      const bool third = shares_tile0(pmask);  // this wave projects a third of tile 0's K features
+      const int st_own = st;
+      const int st = third ? 0 : st_own;       // (shadows the wave's own tile inside the build)
       if (st < LTc) {  // (uniform) tiles beyond the profile are never read
         const int t = 16 * st + ln, r = s0 + t;
         const bool valid = r < L;
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
         }
         float* Ks = Ks2 + buf * ATT_LMAX * G::SO;
         const int nvalid = nk - 16 * st;  // slots of this tile that the profile holds (>= 1: st < LTc)
-        if (nvalid <= 4 && !(a.opt & 2)) {
+        if (nvalid <= 4 && !third && !(a.opt & 2)) {
           // A NEARLY EMPTY last slot tile (a full profile of L = 50 re-based: slots 48, 49): its K rows on the VALU.  The
           // MFMA tile below costs 144 MFMAs whatever it holds, and at full profiles it sits on the SIMD that also runs six
           // of the user's 21 jobs where the others run five: 49 instead of 48 slots cost 25 % of the kernel
@@ -293,6 +308,24 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
             const int r = 4 + u / QPR, c4 = u - (u / QPR) * QPR;
             *reinterpret_cast<f32x4*>(Ks + (16 * st + r) * G::SO + 4 * c4) = zero4();
           }
+        } else if (third) {
+          constexpr int NT3 = HELP ? G::NF / 3 : 1;
+          const int ft0 = st_own * NT3;
+          f32x4 acc[NT3];
+#pragma unroll
+          for (int i = 0; i < NT3; ++i) acc[i] = lds4(Bk + 16 * (ft0 + i) + 4 * mq);
+#pragma unroll
+          for (int kg = 0; kg < G::NKG; ++kg) {
+            f32x4 wf[NT3];
+#pragma unroll
+            for (int i = 0; i < NT3; ++i) wf[i] = lds4(Wk + (((ft0 + i) * G::NKG + kg) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int i = 0; i < NT3; ++i) acc[i] = mfma16(wf[i][e], x[kg][e], acc[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < NT3; ++i) *reinterpret_cast<f32x4*>(Ks + t * G::SO + 16 * (ft0 + i) + 4 * mq) = acc[i];
         } else {
           // K^T tiles: Ks[16 st + ln][16 ft + 4 mq + r] = sum_k W_K[16 ft + 4 mq + r][k] x[16 st + ln][k] + b_K
           f32x4 acc[G::NF];
@@ -311,7 +344,8 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
 #pragma unroll
           for (int ft = 0; ft < G::NF; ++ft) *reinterpret_cast<f32x4*>(Ks + t * G::SO + 16 * ft + 4 * mq) = acc[ft];
         }
-        // folded value u[h][slot] = x[slot] . wu[h] + cu[h]
+        // folded value u[h][slot] = x[slot] . wu[h] + cu[h]  (of a shared tile 0: by its own wave only)
+        if (!third || st_own == 0) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
           float p = 0.f;
@@ -324,6 +358,7 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
           if (mq == 0) Ut2[(buf * NH + h) * ATT_SK + t] = p;
         }
         if (mq == 0) Km2[buf * ATT_LMAX + t] = (t < nk && ((pmask >> (t + s0)) & 1ull)) ? 0.f : FOLD_NEG;
+        }
       }
       pmask = __ballot(lane < L && id_next != 0);
       request_rows(k + 1, pmask);
