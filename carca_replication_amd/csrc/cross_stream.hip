@@ -415,20 +415,16 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
   } else {
     // =================================================== C waves ==========================================================
     const int cw = wave;
-    // TWO sets of job operands (the target tile's rows in the operand layout + the targets' ids): a job's rows are requested
-    // at the START of the job before it, into the other set -- a whole job of cover.  (One set, requested behind the previous
-    // job's projection, left a short profile's jobs waiting for their rows: ~1.5 k cycles of cover against an HBM round trip.)
     struct Ops {
       f32x4 q[G::NKG];
       int id;
-    };
-    Ops opA, opB;
-    auto load_ops = [&](Ops& dst, int k, int rd, int job) {
+    } cur;
+    auto load_ops = [&](int k, int rd, int job) {
       Job c;
       decode_tile(tlo_of(k) + rd * XS_TPR + job / NH, user_of(k), c);
 #pragma unroll
-      for (int kg = 0; kg < G::NKG; ++kg) dst.q[kg] = gload4s(c.o, c.lrow * a.ldo + 4 * mq, 16 * kg);
-      dst.id = gload1i(c.ids, c.lrow);
+      for (int kg = 0; kg < G::NKG; ++kg) cur.q[kg] = gload4s(c.o, c.lrow * a.ldo + 4 * mq, 16 * kg);
+      cur.id = gload1i(c.ids, c.lrow);
     };
     // the job this wave runs after (k, rd, job); false when there is none
     auto find_next = [&](int k, int rd, int cand, int& k2, int& rd2, int& job2) {
@@ -464,11 +460,11 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
         rd2 = 0;
         job2 = 0;
       }
-      load_ops(opA, k2, rd2, job2);
+      load_ops(k2, rd2, job2);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // W_Q landed (and the first job's operands)
     const float qs = a.qscale;
-    int k = 0, rd = 0, sp = 0, par = 0;  // par: which operand set holds the job about to run
+    int k = 0, rd = 0, sp = 0;
     for (int s = 0; s < nu * R; ++s) {
       const int buf = k & 1;
       const int LTc = __builtin_amdgcn_readfirstlane(Hdr[buf * 4]);
@@ -478,7 +474,7 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
       float* Yp = Yp2 + sp * XS_TPR * NH * 16;
       const int nj = njobs_of(k, rd);
       XS_WSTAMP(s, 0);
-      auto run_job = [&](Ops& mine, Ops& other, const int job) __attribute__((always_inline)) -> int {
+      for (int job = cw; job < nj;) {
         // Which job comes next: job + 12 (static dealing).  a.opt bit 0 (tuning key 3, A/B): a wave's first job of a step
         // stays fixed (its operands are requested across the step's barrier) and the others are drawn from a ticket
         // counter.  Measured SLOWER (B = 4096: 204 against 198 us): the ticket has to be drawn at the start of the previous
@@ -487,23 +483,12 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
         if (a.opt & 1) {
           if (lane == 0) ticket = __hip_atomic_fetch_add(&Cnt[sp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        {  // the next job's operands, into the other set
-          int k2 = k, rd2 = rd, job2 = job;
-          if (!find_next(k, rd, ticket, k2, rd2, job2)) {
-            k2 = k;
-            rd2 = rd;
-            job2 = job;
-          }
-          load_ops(other, k2, rd2, job2);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // (left alone, hipcc sinks these requests behind the projection: no cover gained)
         const int tl = job / NH, h = job - tl * NH;
         const float* const w0 = Wq + (h * G::NFH * G::NKG) * 256 + 4 * lane;
         const float* const bq0 = Bq + h * DHP + 4 * mq;
         Job c;
         decode_tile(tlo_of(k) + rd * XS_TPR + tl, user_of(k), c);
-        const bool q_ok = c.in_range && mine.id != 0;
+        const bool q_ok = c.in_range && cur.id != 0;
         // Q^T tiles of the head: NFH interleaved accumulator chains that start from the bias, W_Q fragments from LDS.  The
         // softmax scale is applied inside the exponent below (one fma per score either way), not to the tile.
         f32x4 qt[G::NFH];
@@ -518,7 +503,7 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int ft = 0; ft < G::NFH; ++ft) qt[ft] = mfma16(af[ft][e], mine.q[kg][e], qt[ft]);
+              for (int ft = 0; ft < G::NFH; ++ft) qt[ft] = mfma16(af[ft][e], cur.q[kg][e], qt[ft]);
           }
         }
         // residual part of the logit (w . o, once per target)
@@ -528,9 +513,20 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
           for (int kg = 0; kg < G::NKG; ++kg) {
             const f32x4 wv = lds4(Fw + 16 * kg + 4 * mq);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ypart += wv[e] * mine.q[kg][e];
+            for (int e = 0; e < 4; ++e) ypart += wv[e] * cur.q[kg][e];
           }
           ypart = quad4_sum(ypart);
+        }
+        // the next job's operands into the same registers: they land under this job's scores and softmax
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        {
+          int k2 = k, rd2 = rd, job2 = job;
+          if (!find_next(k, rd, ticket, k2, rd2, job2)) {
+            k2 = k;
+            rd2 = rd;
+            job2 = job;
+          }
+          load_ops(k2, rd2, job2);
         }
         // scores^T tiles (rows = keys, cols = targets) on top of the additive mask.  Exactly the LTc key tiles that hold a
         // slot of the re-based profile: whole pairs as two accumulator chains (one per tile), an odd last tile as two
@@ -593,11 +589,7 @@ __global__ __launch_bounds__(XS_NW * 64) void cross_stream_kernel(const FoldArgs
         const float attn = (q_ok && mx > 0.5f * FOLD_NEG) ? dot * __builtin_amdgcn_rcpf(sum) : 0.f;  // (1 ulp; a division is ten instructions)
         if (mq == 0) Yp[(tl * NH + h) * 16 + ln] = attn + ypart;
         if (job == cw) XS_WSTAMP(s, 32);
-        return ticket;
-      };
-      for (int job = cw; job < nj;) {
-        job = par ? run_job(opB, opA, job) : run_job(opA, opB, job);
-        par ^= 1;
+        job = ticket;
       }
       XS_WSTAMP(s, 16);
       XS_BARRIER();
